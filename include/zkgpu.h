@@ -1,0 +1,182 @@
+/* zkgpu.h -- C ABI of the MI355X-native Groth16 prover (drop-in boundary).
+ *
+ * The reference (republicprotocol/zksnark-rs, crate `zksnark` 0.0.2) is pure Rust with no FFI of
+ * its own; this header IS the seam a maintainer binds from
+ * `src/groth16/gpu.rs` (binding shown in INTEGRATION.md).  Every entry point cites the
+ * reference interface it replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - Return value: 0 (ZK_OK) or a negative zk_status; nothing aborts or throws across the ABI.
+ *     The reference panics instead (fr.rs:54,69; field/mod.rs:440); the Rust shim turns a
+ *     non-zero status back into the same panic.
+ *   - Fr / Fq element: uint64_t[4], little-endian limbs, CANONICAL integer < modulus
+ *     (not Montgomery).  Conversions to the device's Montgomery form happen on the GPU.
+ *   - G1 affine point: uint64_t[8]  = x[4] | y[4];                 infinity = all zero.
+ *   - G2 affine point: uint64_t[16] = x.c0 | x.c1 | y.c0 | y.c1;   infinity = all zero.
+ *     (Fq2 = Fq[i]/(i^2+1), element c0 + c1*i.)
+ *   - Proof bytes (build-defined canonical encoding): 259 bytes
+ *       A (G1, 65 B) | B (G2, 129 B) | C (G1, 65 B)
+ *       G1: 0x04 | x | y                          (32-byte big-endian each)
+ *       G2: 0x04 | x.c1 | x.c0 | y.c1 | y.c0      (EIP-197 order)
+ *       infinity: 0x00 followed by zero bytes (same total length).
+ *   - A zk_ctx is bound to one HIP device and must be used from one thread at a time.
+ *   - All `const uint64_t*` inputs are HOST pointers unless the parameter name starts with d_.
+ */
+#ifndef ZKGPU_H
+#define ZKGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_crs zk_crs;   /* device-resident SigmaG1 + SigmaG2 (groth16/mod.rs:105-121) */
+typedef struct zk_qap zk_qap;   /* device-resident QAP (groth16/mod.rs:60-67) */
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_ERR_ARG = -1,          /* null pointer / inconsistent sizes */
+    ZK_ERR_HIP = -2,          /* HIP runtime error (see zk_last_error) */
+    ZK_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the product path has NO CPU fallback */
+    ZK_ERR_SIZE = -4,         /* size outside the supported range */
+    ZK_ERR_DIV_BY_ZERO = -5,  /* "Dividend must be non-zero" (field/mod.rs:440) / Fr inverse of 0 (fr.rs:54,69) */
+    ZK_ERR_RANGE = -6,        /* an Fr/Fq input is >= its modulus */
+    ZK_ERR_UNSUPPORTED = -7
+} zk_status;
+
+#define ZK_PROOF_BYTES 259
+#define ZK_FR_WORDS 4
+#define ZK_G1_WORDS 8
+#define ZK_G2_WORDS 16
+
+/* ------------------------------------------------------------------------------------------
+ * Context
+ * ---------------------------------------------------------------------------------------- */
+int zk_ctx_create(int device_ordinal, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_strerror(int status);
+const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
+/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lds_buckets" (0/1), "profile" (0/1) */
+int zk_set_option(zk_ctx* ctx, const char* key, long value);
+long zk_get_option(const zk_ctx* ctx, const char* key);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks (individually parity-tested against the oracle)
+ * ---------------------------------------------------------------------------------------- */
+/* Radix-2 NTT over Fr, natural order in and out, in place on a host buffer of 2^log_n elements.
+ *   inverse=0: out[k] = sum_j in[j] * w^(jk)            == field::dft   (field/mod.rs:508-520)
+ *   inverse=1: w^-1 and scaling by n^-1                 == field::idft  (field/mod.rs:524-537)
+ * with w = 5^((r-1)/2^log_n).  coset=1 evaluates on / interpolates from the coset g*<w> with
+ * g = 5^((r-1)/2^(log_n+1)) (forward: in[j] *= g^j first; inverse: out[j] *= g^-j last). */
+int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset);
+
+/* sum_i scalars[i] * points[i]: the SigmaG1/SigmaG2 inner products of groth16::prove
+ * (groth16/mod.rs:255-272,279-290), i.e. n x exp_encrypted_g1/g2 (fr.rs:114-119) folded with
+ * Sum for G1Local/G2Local (fr.rs:191-198,217-223).  window_bits = 0 picks automatically. */
+int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out_affine[ZK_G1_WORDS]);
+int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out_affine[ZK_G2_WORDS]);
+
+/* Element-wise field / group kernels (diagnostic entry points used by the parity tests).
+ * op: 0 add, 1 sub, 2 mul, 3 inverse of a (b ignored; ZK_ERR_DIV_BY_ZERO if any a == 0)
+ * FrLocal Add/Sub/Mul/Div: fr.rs:18-71 */
+int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* out[i] = scalars[i] * points[i]  (exp_encrypted_g1 / exp_encrypted_g2, fr.rs:114-119) */
+int zk_g1_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
+int zk_g2_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
+/* out[i] = a[i] + b[i]  (Add for G1Local/G2Local, fr.rs:175-215) */
+int zk_g1_add_batch(zk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zk_g2_add_batch(zk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * QAP  (QAP<CoefficientPoly<FrLocal>>, groth16/mod.rs:60-67; built by fr.rs:140-173)
+ * ---------------------------------------------------------------------------------------- */
+/* One of u, v, w in root representation (circuit::RootRepresentation, circuit/mod.rs:201-214;
+ * DummyRep rows, dummy_rep.rs:6-13): CSR by WIRE, entry k of wire i = (gate index, value),
+ * meaning polynomial_i(root[gate]) = value.  Duplicate (wire, gate) entries add up, as the
+ * reference's Lagrange sum does (coefficient_poly.rs:159-171). */
+typedef struct {
+    const uint64_t* ptr;   /* m+1 offsets */
+    const uint32_t* gate;  /* nnz gate indices in [0, n) */
+    const uint64_t* val;   /* nnz Fr values (4 words each) */
+} zk_sparse_rows;
+
+/* Sparse QAP on the domain roots[j] = w^j, w = 5^((r-1)/n), n = 2^log_n gates: the large-circuit
+ * form.  Equivalent to QAP::from(root_rep) (fr.rs:140-173) with those roots; the dense
+ * per-wire polynomials are never materialised. t(x) = x^n - 1. */
+typedef struct {
+    unsigned log_n;
+    size_t m;       /* wires; wire 0 is the constant 1 */
+    size_t input;   /* l = number of verifier-supplied wires (qap.input) */
+    zk_sparse_rows u, v, w;
+} zk_qap_sparse_desc;
+int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** out);
+
+/* Dense coefficient form, exactly the fields of QAP<CoefficientPoly<FrLocal>>: u, v, w are
+ * m x n row-major (coefficient k of wire i at [i*n + k], zero padded), t has n+1 coefficients
+ * (any roots; e.g. ASTParser's 1..n, circuit/mod.rs:517). */
+int zk_qap_upload_dense(zk_ctx* ctx, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t,
+                        size_t m, size_t n, size_t input, zk_qap** out);
+void zk_qap_free(zk_qap* qap);
+
+/* ------------------------------------------------------------------------------------------
+ * CRS  (SigmaG1 / SigmaG2, groth16/mod.rs:105-121)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    size_t n, m, input;
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1;   /* 8 words each */
+    const uint64_t* xi_g1;          /* n       points  [x^i]_1            */
+    const uint64_t* sum_gamma_g1;   /* input+1 points  (wires 0..l)       */
+    const uint64_t* sum_delta_g1;   /* m-l-1   points  (wires l+1..m-1)   */
+    const uint64_t* xi_t_g1;        /* n-1     points  [x^i t(x)/delta]_1 */
+    const uint64_t *beta_g2, *gamma_g2, *delta_g2;   /* 16 words each */
+    const uint64_t* xi_g2;          /* n       points  [x^i]_2            */
+} zk_crs_desc;
+int zk_crs_upload(zk_ctx* ctx, const zk_crs_desc* desc, zk_crs** out);
+
+/* groth16::setup (groth16/mod.rs:134-197) on the GPU with the five random draws injected:
+ * trapdoor = alpha | beta | gamma | delta | x (4 words each, all non-zero). */
+int zk_setup(zk_ctx* ctx, const zk_qap* qap, const uint64_t trapdoor[20], zk_crs** out);
+
+/* Copy a device CRS back into caller-provided host buffers (any pointer may be NULL = skip). */
+typedef struct {
+    uint64_t *alpha_g1, *beta_g1, *delta_g1, *xi_g1, *sum_gamma_g1, *sum_delta_g1, *xi_t_g1;
+    uint64_t *beta_g2, *gamma_g2, *delta_g2, *xi_g2;
+} zk_crs_out;
+int zk_crs_dims(const zk_crs* crs, size_t* n, size_t* m, size_t* input);
+int zk_crs_download(zk_ctx* ctx, const zk_crs* crs, const zk_crs_out* out);
+void zk_crs_free(zk_crs* crs);
+
+/* ------------------------------------------------------------------------------------------
+ * prove  (groth16::prove, groth16/mod.rs:213-296) with (r, s) injected (mod.rs:231)
+ * ---------------------------------------------------------------------------------------- */
+int zk_prove(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+/* Same with the witness already resident in HBM (m x 4 words, canonical form). */
+int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                 const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+
+/* Multi-GPU: every rank holds the CRS and recomputes the NTT stage; rank g owns
+ * Pippenger windows w = g (mod world) of each of the five inner products and writes its
+ * partial sums (Jacobian, device Montgomery limbs) to d_partial_out (ZK_PARTIAL_BYTES).  The
+ * caller all-gathers the blobs (RCCL, as bytes) and any rank finishes with zk_prove_combine. */
+#define ZK_PARTIAL_BYTES 768   /* 4 G1 Jacobian (96 B) + 1 G2 Jacobian (192 B) + padding to 768 */
+int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                     int rank, int world, void* d_partial_out);
+int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
+                     const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+
+/* ------------------------------------------------------------------------------------------
+ * Profiling: HIP-event timing of the library's own kernels on the stream they run on.
+ * ---------------------------------------------------------------------------------------- */
+int zk_profile_reset(zk_ctx* ctx);
+/* n_names = number of distinct kernels recorded; name(i) / stats(i) enumerate them */
+int zk_profile_count(const zk_ctx* ctx);
+int zk_profile_entry(const zk_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches, double* algo_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKGPU_H */

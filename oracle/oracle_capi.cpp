@@ -1,0 +1,323 @@
+// oracle/oracle_capi.cpp -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+//
+// C entry points (prefix orc_) that mirror the product's C ABI (include/zkgpu.h) argument for
+// argument, so the parity tests call both libraries on the same buffers and compare bytes.
+// Loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+#include <chrono>
+#include <cstring>
+#include "../include/zkgpu.h"
+#include "zkparse.hpp"
+#include "fast.hpp"
+
+using namespace orc;
+
+namespace {
+
+U256 rd256(const uint64_t* p) { return U256{{p[0], p[1], p[2], p[3]}}; }
+void wr256(const U256& v, uint64_t* p) { for (int i = 0; i < 4; ++i) p[i] = v.l[i]; }
+template <class F> F rd_f(const uint64_t* p) { return F::from_u256(rd256(p)); }
+bool in_range_r(const uint64_t* p) { return u256_cmp(rd256(p), FrParams::P) < 0; }
+bool in_range_q(const uint64_t* p) { return u256_cmp(rd256(p), FqParams::P) < 0; }
+
+G1A rd_g1(const uint64_t* p) {
+    bool z = true;
+    for (int i = 0; i < 8; ++i) z = z && p[i] == 0;
+    if (z) return G1A::infinity();
+    return G1A{rd_f<Fq>(p), rd_f<Fq>(p + 4), false};
+}
+G2A rd_g2(const uint64_t* p) {
+    bool z = true;
+    for (int i = 0; i < 16; ++i) z = z && p[i] == 0;
+    if (z) return G2A::infinity();
+    return G2A{Fq2{rd_f<Fq>(p), rd_f<Fq>(p + 4)}, Fq2{rd_f<Fq>(p + 8), rd_f<Fq>(p + 12)}, false};
+}
+void wr_g1(const G1& j, uint64_t* p) {
+    G1A a = j.to_affine();
+    std::memset(p, 0, 64);
+    if (a.inf) return;
+    wr256(a.x.to_u256(), p); wr256(a.y.to_u256(), p + 4);
+}
+void wr_g2(const G2& j, uint64_t* p) {
+    G2A a = j.to_affine();
+    std::memset(p, 0, 128);
+    if (a.inf) return;
+    wr256(a.x.c0.to_u256(), p); wr256(a.x.c1.to_u256(), p + 4);
+    wr256(a.y.c0.to_u256(), p + 8); wr256(a.y.c1.to_u256(), p + 12);
+}
+
+template <class Fn>
+int guarded(Fn&& fn) {
+    try { fn(); return 0; }
+    catch (const std::domain_error&) { return ZK_ERR_DIV_BY_ZERO; }
+    catch (const std::out_of_range&) { return ZK_ERR_RANGE; }
+    catch (const ParseErr&) { return -100; }
+    catch (const Panic&) { return -101; }
+    catch (...) { return ZK_ERR_ARG; }
+}
+
+SparseMat rd_rows(const zk_sparse_rows& r, size_t m) {
+    SparseMat M;
+    M.ptr.assign(r.ptr, r.ptr + m + 1);
+    size_t nnz = r.ptr[m];
+    M.gate.assign(r.gate, r.gate + nnz);
+    for (size_t k = 0; k < nnz; ++k) M.val.push_back(rd_f<Fr>(r.val + 4 * k));
+    return M;
+}
+SparseQap rd_sparse(const zk_qap_sparse_desc* d) {
+    SparseQap q;
+    q.log_n = d->log_n; q.m = d->m; q.input = d->input;
+    q.u = rd_rows(d->u, d->m); q.v = rd_rows(d->v, d->m); q.w = rd_rows(d->w, d->m);
+    return q;
+}
+DummyRep<Fr> sparse_to_root_rep(const SparseQap& q) {
+    DummyRep<Fr> rr;
+    rr.roots = powers(fr_root_of_unity((int)q.log_n), q.n());
+    rr.input = q.input;
+    auto conv = [&](const SparseMat& M) {
+        std::vector<std::vector<std::pair<Fr, Fr>>> rows(q.m);
+        for (size_t i = 0; i < q.m; ++i)
+            for (size_t k = M.ptr[i]; k < M.ptr[i + 1]; ++k) rows[i].push_back({rr.roots[M.gate[k]], M.val[k]});
+        return rows;
+    };
+    rr.u = conv(q.u); rr.v = conv(q.v); rr.w = conv(q.w);
+    return rr;
+}
+QAP<Fr> rd_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input) {
+    QAP<Fr> q;
+    auto rows = [&](const uint64_t* src) {
+        std::vector<Coeffs<Fr>> out(m);
+        for (size_t i = 0; i < m; ++i) for (size_t k = 0; k < n; ++k) out[i].push_back(rd_f<Fr>(src + 4 * (i * n + k)));
+        return out;
+    };
+    q.u = rows(u); q.v = rows(v); q.w = rows(w);
+    for (size_t k = 0; k <= n; ++k) q.t.push_back(rd_f<Fr>(t + 4 * k));
+    q.input = input;
+    q.degree = degree(q.t);
+    return q;
+}
+BnCrs rd_crs(const zk_crs_desc* d) {
+    BnCrs c;
+    c.s1.alpha = G1::from_affine(rd_g1(d->alpha_g1)); c.s1.beta = G1::from_affine(rd_g1(d->beta_g1)); c.s1.delta = G1::from_affine(rd_g1(d->delta_g1));
+    for (size_t i = 0; i < d->n; ++i) c.s1.xi.push_back(G1::from_affine(rd_g1(d->xi_g1 + 8 * i)));
+    if (d->sum_gamma_g1) for (size_t i = 0; i < d->input + 1; ++i) c.s1.sum_gamma.push_back(G1::from_affine(rd_g1(d->sum_gamma_g1 + 8 * i)));
+    for (size_t i = 0; i + d->input + 1 < d->m; ++i) c.s1.sum_delta.push_back(G1::from_affine(rd_g1(d->sum_delta_g1 + 8 * i)));
+    for (size_t i = 0; i + 1 < d->n; ++i) c.s1.xi_t.push_back(G1::from_affine(rd_g1(d->xi_t_g1 + 8 * i)));
+    c.s2.beta = G2::from_affine(rd_g2(d->beta_g2)); c.s2.delta = G2::from_affine(rd_g2(d->delta_g2));
+    if (d->gamma_g2) c.s2.gamma = G2::from_affine(rd_g2(d->gamma_g2)); else c.s2.gamma = G2::zero();
+    for (size_t i = 0; i < d->n; ++i) c.s2.xi.push_back(G2::from_affine(rd_g2(d->xi_g2 + 16 * i)));
+    return c;
+}
+void wr_crs(const BnCrs& c, const zk_crs_out* o) {
+    if (o->alpha_g1) wr_g1(c.s1.alpha, o->alpha_g1);
+    if (o->beta_g1) wr_g1(c.s1.beta, o->beta_g1);
+    if (o->delta_g1) wr_g1(c.s1.delta, o->delta_g1);
+    if (o->xi_g1) for (size_t i = 0; i < c.s1.xi.size(); ++i) wr_g1(c.s1.xi[i], o->xi_g1 + 8 * i);
+    if (o->sum_gamma_g1) for (size_t i = 0; i < c.s1.sum_gamma.size(); ++i) wr_g1(c.s1.sum_gamma[i], o->sum_gamma_g1 + 8 * i);
+    if (o->sum_delta_g1) for (size_t i = 0; i < c.s1.sum_delta.size(); ++i) wr_g1(c.s1.sum_delta[i], o->sum_delta_g1 + 8 * i);
+    if (o->xi_t_g1) for (size_t i = 0; i < c.s1.xi_t.size(); ++i) wr_g1(c.s1.xi_t[i], o->xi_t_g1 + 8 * i);
+    if (o->beta_g2) wr_g2(c.s2.beta, o->beta_g2);
+    if (o->gamma_g2) wr_g2(c.s2.gamma, o->gamma_g2);
+    if (o->delta_g2) wr_g2(c.s2.delta, o->delta_g2);
+    if (o->xi_g2) for (size_t i = 0; i < c.s2.xi.size(); ++i) wr_g2(c.s2.xi[i], o->xi_g2 + 16 * i);
+}
+Trapdoor<Fr> rd_td(const uint64_t* t) { return Trapdoor<Fr>{rd_f<Fr>(t), rd_f<Fr>(t + 4), rd_f<Fr>(t + 8), rd_f<Fr>(t + 12), rd_f<Fr>(t + 16)}; }
+std::vector<Fr> rd_frs(const uint64_t* p, size_t n) { std::vector<Fr> v; for (size_t i = 0; i < n; ++i) v.push_back(rd_f<Fr>(p + 4 * i)); return v; }
+void wr_proof(const Proof<G1, G2>& p, uint8_t* out) { encode_g1(p.a, out); encode_g2(p.b, out + 65); encode_g1(p.c, out + 194); }
+
+template <class F>
+int field_batch(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return guarded([&] {
+        for (size_t i = 0; i < n; ++i) {
+            F x = rd_f<F>(a + 4 * i), r;
+            if (op == 3) r = x.inv();
+            else { F y = rd_f<F>(b + 4 * i); r = op == 0 ? x + y : (op == 1 ? x - y : x * y); }
+            wr256(r.to_u256(), out + 4 * i);
+        }
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int orc_fr_batch(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return field_batch<Fr>(op, a, b, out, n); }
+int orc_fq_batch(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return field_batch<Fq>(op, a, b, out, n); }
+
+int orc_g1_mul_batch(const uint64_t* pts, const uint64_t* sc, uint64_t* out, size_t n) {
+    return guarded([&] { for (size_t i = 0; i < n; ++i) wr_g1(G1::from_affine(rd_g1(pts + 8 * i)).mul(rd256(sc + 4 * i)), out + 8 * i); });
+}
+int orc_g2_mul_batch(const uint64_t* pts, const uint64_t* sc, uint64_t* out, size_t n) {
+    return guarded([&] { for (size_t i = 0; i < n; ++i) wr_g2(G2::from_affine(rd_g2(pts + 16 * i)).mul(rd256(sc + 4 * i)), out + 16 * i); });
+}
+int orc_g1_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return guarded([&] { for (size_t i = 0; i < n; ++i) wr_g1(G1::from_affine(rd_g1(a + 8 * i)) + G1::from_affine(rd_g1(b + 8 * i)), out + 8 * i); });
+}
+int orc_g2_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return guarded([&] { for (size_t i = 0; i < n; ++i) wr_g2(G2::from_affine(rd_g2(a + 16 * i)) + G2::from_affine(rd_g2(b + 16 * i)), out + 16 * i); });
+}
+int orc_g1_on_curve(const uint64_t* p) { return on_curve(rd_g1(p)) ? 1 : 0; }
+int orc_g2_on_curve(const uint64_t* p) { return on_curve(rd_g2(p)) ? 1 : 0; }
+void orc_enc_base_g1(uint64_t out[8]) { wr_g1(enc_base_g1(), out); }
+void orc_enc_base_g2(uint64_t out[16]) { wr_g2(enc_base_g2(), out); }
+void orc_root_of_unity(unsigned log_n, uint64_t out[4]) { wr256(fr_root_of_unity((int)log_n).to_u256(), out); }
+
+// naive field::dft (field/mod.rs:508-520) with an explicit root
+int orc_dft_fr(const uint64_t* in, size_t n, const uint64_t root[4], int inverse, uint64_t* out) {
+    return guarded([&] {
+        auto seq = rd_frs(in, n);
+        auto res = inverse ? idft(seq, rd_f<Fr>(root)) : dft(seq, rd_f<Fr>(root));
+        for (size_t i = 0; i < n; ++i) wr256(res[i].to_u256(), out + 4 * i);
+    });
+}
+// same argument meaning as zk_ntt_fr
+int orc_ntt_fr(uint64_t* data, unsigned log_n, int inverse, int coset) {
+    return guarded([&] {
+        size_t n = (size_t)1 << log_n;
+        auto a = rd_frs(data, n);
+        Fr g = fr_root_of_unity((int)log_n + 1);
+        if (coset && !inverse) { auto pw = powers(g, n); for (size_t i = 0; i < n; ++i) a[i] = a[i] * pw[i]; }
+        fr_ntt(a, log_n, inverse != 0);
+        if (coset && inverse) { auto pw = powers(g.inv(), n); for (size_t i = 0; i < n; ++i) a[i] = a[i] * pw[i]; }
+        for (size_t i = 0; i < n; ++i) wr256(a[i].to_u256(), data + 4 * i);
+    });
+}
+
+// window_bits == 0: the reference's own formulation (n double-and-add multiplications folded
+// sequentially, mod.rs:255-260 + fr.rs:114-119,191-198); otherwise Pippenger with that window.
+int orc_msm_g1(const uint64_t* pts, const uint64_t* sc, size_t n, int window_bits, uint64_t out[8]) {
+    return guarded([&] {
+        if (window_bits == 0) {
+            G1 acc = G1::zero();
+            for (size_t i = 0; i < n; ++i) acc = acc + G1::from_affine(rd_g1(pts + 8 * i)).mul(rd256(sc + 4 * i));
+            wr_g1(acc, out);
+        } else {
+            std::vector<G1A> p; std::vector<U256> s;
+            for (size_t i = 0; i < n; ++i) { p.push_back(rd_g1(pts + 8 * i)); s.push_back(rd256(sc + 4 * i)); }
+            wr_g1(msm_pippenger(p, s, (unsigned)window_bits), out);
+        }
+    });
+}
+int orc_msm_g2(const uint64_t* pts, const uint64_t* sc, size_t n, int window_bits, uint64_t out[16]) {
+    return guarded([&] {
+        if (window_bits == 0) {
+            G2 acc = G2::zero();
+            for (size_t i = 0; i < n; ++i) acc = acc + G2::from_affine(rd_g2(pts + 16 * i)).mul(rd256(sc + 4 * i));
+            wr_g2(acc, out);
+        } else {
+            std::vector<G2A> p; std::vector<U256> s;
+            for (size_t i = 0; i < n; ++i) { p.push_back(rd_g2(pts + 16 * i)); s.push_back(rd256(sc + 4 * i)); }
+            wr_g2(msm_pippenger(p, s, (unsigned)window_bits), out);
+        }
+    });
+}
+
+// ---- setup ------------------------------------------------------------------------------
+// faithful = QAP::from(root_rep) by Lagrange interpolation + reference setup (small n only)
+int orc_setup_sparse(const zk_qap_sparse_desc* d, const uint64_t trapdoor[20], int faithful, const zk_crs_out* out) {
+    return guarded([&] {
+        SparseQap q = rd_sparse(d);
+        BnCrs c;
+        if (faithful) {
+            auto qap = qap_from_root_rep(sparse_to_root_rep(q));
+            auto p = setup_with_trapdoor<BnEngine>(qap, rd_td(trapdoor));
+            c.s1 = p.first; c.s2 = p.second;
+        } else {
+            c = fast_setup(q, rd_td(trapdoor));
+        }
+        wr_crs(c, out);
+    });
+}
+int orc_setup_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input,
+                    const uint64_t trapdoor[20], const zk_crs_out* out) {
+    return guarded([&] {
+        auto p = setup_with_trapdoor<BnEngine>(rd_dense(u, v, w, t, m, n, input), rd_td(trapdoor));
+        BnCrs c; c.s1 = p.first; c.s2 = p.second;
+        wr_crs(c, out);
+    });
+}
+
+// ---- prove ------------------------------------------------------------------------------
+int orc_prove_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input,
+                    const zk_crs_desc* crs, const uint64_t* weights, size_t m_w, const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
+    return guarded([&] {
+        BnCrs c = rd_crs(crs);
+        wr_proof(prove_with_rs<BnEngine>(rd_dense(u, v, w, t, m, n, input), c.s1, c.s2, rd_frs(weights, m_w), rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+    });
+}
+int orc_prove_sparse(const zk_qap_sparse_desc* d, const zk_crs_desc* crs, const uint64_t* weights, size_t m_w,
+                     const uint64_t r[4], const uint64_t s[4], int faithful, uint8_t proof[259]) {
+    return guarded([&] {
+        SparseQap q = rd_sparse(d);
+        BnCrs c = rd_crs(crs);
+        auto wts = rd_frs(weights, m_w);
+        if (faithful) wr_proof(prove_with_rs<BnEngine>(qap_from_root_rep(sparse_to_root_rep(q)), c.s1, c.s2, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+        else wr_proof(fast_prove(q, c, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+    });
+}
+// closed-form honest proof from the trapdoor; O(n) field work
+int orc_trapdoor_proof_sparse(const zk_qap_sparse_desc* d, const uint64_t trapdoor[20], const uint64_t* weights, size_t m_w,
+                              const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
+    return guarded([&] { wr_proof(fast_trapdoor_proof(rd_sparse(d), rd_td(trapdoor), rd_frs(weights, m_w), rd_f<Fr>(r), rd_f<Fr>(s)), proof); });
+}
+int orc_trapdoor_proof_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input,
+                             const uint64_t trapdoor[20], const uint64_t* weights, size_t m_w, const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
+    return guarded([&] {
+        QAP<Fr> qap = rd_dense(u, v, w, t, m, n, input);
+        Trapdoor<Fr> td = rd_td(trapdoor);
+        auto wts = rd_frs(weights, m_w);
+        std::vector<Fr> ux, vx, wx;
+        for (size_t i = 0; i < m; ++i) { ux.push_back(evaluate(qap.u[i], td.x)); vx.push_back(evaluate(qap.v[i], td.x)); wx.push_back(evaluate(qap.w[i], td.x)); }
+        auto h = poly_div(poly_sub(poly_mul(weighted_sum(qap.u, wts), weighted_sum(qap.v, wts)), weighted_sum(qap.w, wts)), qap.t);
+        if (qap.degree >= 1 && h.size() > qap.degree - 1) h.resize(qap.degree - 1);
+        wr_proof(trapdoor_proof(td, input, ux, vx, wx, evaluate(h, td.x) * evaluate(qap.t, td.x), wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+    });
+}
+
+// ---- .zk front end ----------------------------------------------------------------------
+// dims: m wires, n gates, input; n_in = number of `in` variables
+int orc_zk_dims(const char* code, size_t* m, size_t* n, size_t* input, size_t* n_in) {
+    return guarded([&] {
+        auto rr = ast_try_parse<Fr>(code);
+        *m = rr.u.size(); *n = rr.roots.size(); *input = rr.input;
+        *n_in = expressions<Fr>(code)[0].kids.size();
+    });
+}
+// QAP::from(ASTParser::try_parse(code)) as dense m x n coefficient matrices (zero padded) + t
+int orc_zk_qap_dense(const char* code, uint64_t* u, uint64_t* v, uint64_t* w, uint64_t* t) {
+    return guarded([&] {
+        auto qap = qap_from_root_rep(ast_try_parse<Fr>(code));
+        size_t m = qap.u.size(), n = qap.degree;
+        auto put = [&](const std::vector<Coeffs<Fr>>& rows, uint64_t* dst) {
+            std::memset(dst, 0, m * n * 32);
+            for (size_t i = 0; i < m; ++i) for (size_t k = 0; k < rows[i].size() && k < n; ++k) wr256(rows[i][k].to_u256(), dst + 4 * (i * n + k));
+        };
+        put(qap.u, u); put(qap.v, v); put(qap.w, w);
+        for (size_t k = 0; k <= n; ++k) wr256(qap.t[k].to_u256(), t + 4 * k);
+    });
+}
+int orc_zk_weights(const char* code, const uint64_t* inputs, size_t n_in, uint64_t* out, size_t m) {
+    return guarded([&] {
+        auto w = zk_weights<Fr>(code, rd_frs(inputs, n_in));
+        if (w.size() != m) throw std::logic_error("weights length");
+        for (size_t i = 0; i < m; ++i) wr256(w[i].to_u256(), out + 4 * i);
+    });
+}
+
+// ---- timing helpers for bench.py's cpu_baseline leg (single thread, like the reference) -------
+// times `reps` faithful proofs on the chain circuit given as a sparse desc; returns seconds/proof
+double orc_time_prove_sparse(const zk_qap_sparse_desc* d, const zk_crs_desc* crs, const uint64_t* weights, size_t m_w,
+                             const uint64_t r[4], const uint64_t s[4], int faithful, int reps, uint8_t proof[259]) {
+    SparseQap q = rd_sparse(d);
+    BnCrs c = rd_crs(crs);
+    auto wts = rd_frs(weights, m_w);
+    QAP<Fr> qap;
+    if (faithful) qap = qap_from_root_rep(sparse_to_root_rep(q));   // QAP construction is not part of prove()
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; ++k) {
+        if (faithful) wr_proof(prove_with_rs<BnEngine>(qap, c.s1, c.s2, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+        else wr_proof(fast_prove(q, c, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+    }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+
+}  // extern "C"

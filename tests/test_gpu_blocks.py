@@ -1,0 +1,173 @@
+"""-m gpu: parity of the HIP building blocks (through the C ABI) against the CPU oracle.
+
+Bit-exact: everything here is integer arithmetic mod the BN254 primes.
+Mirrors: FrLocal ops (fr.rs:18-71), exp_encrypted_g1/g2 (fr.rs:114-119; reference test
+exp_encrypted_test fr.rs:240-246), Sum/Add for G1Local/G2Local (fr.rs:175-223),
+field::dft/idft (field/mod.rs:508-537; reference tests dft_test/idft_test :606-635),
+the SigmaG1/SigmaG2 inner products of prove (mod.rs:255-272).
+"""
+import numpy as np
+import pytest
+
+import zksnark_rs_amd as zk
+from zksnark_rs_amd import SplitMix64, ints_to_limbs, R_MODULUS, Q_MODULUS
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_fr(rng, n):
+    return ints_to_limbs([rng.fr() for _ in range(n)])
+
+
+def rand_fq(rng, n):
+    return ints_to_limbs([rng.fr() % Q_MODULUS for _ in range(n)])
+
+
+def edge_values(p):
+    return ints_to_limbs([0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 253) % p, (1 << 128) - 1, 1 << 32, (1 << 64) - 1])
+
+
+@pytest.mark.parametrize("field", ["fr", "fq"])
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "inv"])
+def test_field_ops(ctx, orc, field, op):
+    rng = SplitMix64(11)
+    p = R_MODULUS if field == "fr" else Q_MODULUS
+    a = np.concatenate([edge_values(p), rand_fr(rng, 500) if field == "fr" else rand_fq(rng, 500)])
+    b = np.concatenate([edge_values(p)[::-1], rand_fr(rng, 500) if field == "fr" else rand_fq(rng, 500)])
+    if op == "inv":
+        a = a[1:]          # 0 has no inverse
+        b = None
+    g = getattr(ctx, field + "_batch")(op, a, b)
+    rc, o = getattr(orc, field + "_batch")(op, a, b)
+    assert rc == 0
+    assert np.array_equal(g, o)
+
+
+def test_field_errors(ctx):
+    zero = ints_to_limbs([5, 0, 7])
+    with pytest.raises(zk.ZkError) as e:
+        ctx.fr_batch("inv", zero)           # FrLocal::mul_inv panics on zero (fr.rs:69)
+    assert e.value.status == zk._lib.ZK_ERR_DIV_BY_ZERO
+    with pytest.raises(zk.ZkError) as e:
+        ctx.fr_batch("add", ints_to_limbs([R_MODULUS]), ints_to_limbs([1]))
+    assert e.value.status == zk._lib.ZK_ERR_RANGE
+
+
+def g1_points(orc, rng, n):
+    base = np.tile(orc.enc_base_g1(), (n, 1))
+    return orc.g1_mul_batch(base, rand_fr(rng, n))
+
+
+def g2_points(orc, rng, n):
+    base = np.tile(orc.enc_base_g2(), (n, 1))
+    return orc.g2_mul_batch(base, rand_fr(rng, n))
+
+
+def test_point_mul_and_add(ctx, orc):
+    rng = SplitMix64(5)
+    n = 24
+    p1, p2 = g1_points(orc, rng, n), g2_points(orc, rng, n)
+    k = rand_fr(rng, n)
+    k[0] = 0; k[1] = ints_to_limbs([1])[0]; k[2] = ints_to_limbs([R_MODULUS - 1])[0]
+    assert np.array_equal(ctx.g1_mul_batch(p1, k), orc.g1_mul_batch(p1, k))
+    assert np.array_equal(ctx.g2_mul_batch(p2, k), orc.g2_mul_batch(p2, k))
+    # additions incl. P+P, P+(-P), P+inf, inf+inf
+    q1, q2 = g1_points(orc, rng, n), g2_points(orc, rng, n)
+    q1[0] = p1[0]; q2[0] = p2[0]
+    neg = ints_to_limbs([R_MODULUS - 1])
+    q1[1] = orc.g1_mul_batch(p1[1:2], neg)[0]; q2[1] = orc.g2_mul_batch(p2[1:2], neg)[0]
+    q1[2] = 0; q2[2] = 0
+    p1[3] = 0; p2[3] = 0
+    p1[4] = 0; q1[4] = 0; p2[4] = 0; q2[4] = 0
+    assert np.array_equal(ctx.g1_add_batch(p1, q1), orc.g1_add_batch(p1, q1))
+    assert np.array_equal(ctx.g2_add_batch(p2, q2), orc.g2_add_batch(p2, q2))
+
+
+def test_exp_encrypted(ctx, orc):
+    """fr.rs:240-246: a.exp_encrypted_g1(b.encrypt_g1()) == (a*b).encrypt_g1()"""
+    rng = SplitMix64(6)
+    n = 8
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    base1 = np.tile(orc.enc_base_g1(), (n, 1))
+    lhs = ctx.g1_mul_batch(ctx.g1_mul_batch(base1, b), a)
+    rhs = ctx.g1_mul_batch(base1, ctx.fr_batch("mul", a, b))
+    assert np.array_equal(lhs, rhs)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 8])
+def test_ntt_matches_reference_dft(ctx, orc, log_n):
+    """GPU NTT == the reference's naive O(n^2) dft/idft restated over Fr (field/mod.rs:508-537)."""
+    rng = SplitMix64(100 + log_n)
+    a = rand_fr(rng, 1 << log_n)
+    w = orc.root_of_unity(log_n)
+    f = ctx.ntt_fr(a)
+    assert np.array_equal(f, orc.dft_fr(a, w))
+    assert np.array_equal(ctx.ntt_fr(f, inverse=True), a)
+    assert np.array_equal(ctx.ntt_fr(a, inverse=True), orc.dft_fr(a, w, inverse=True))
+
+
+@pytest.mark.parametrize("log_n", [10, 11, 12, 13, 16])
+@pytest.mark.parametrize("coset", [False, True])
+def test_ntt_matches_fast_oracle(ctx, orc, log_n, coset):
+    rng = SplitMix64(200 + log_n)
+    a = rand_fr(rng, 1 << log_n)
+    f = ctx.ntt_fr(a, coset=coset)
+    assert np.array_equal(f, orc.ntt_fr(a, coset=coset))
+    assert np.array_equal(ctx.ntt_fr(f, inverse=True, coset=coset), a)
+
+
+def test_ntt_full_size_properties(ctx):
+    """2^20 (BASELINE size): round trip + linearity + a known transform (delta -> all ones)."""
+    log_n = 20
+    n = 1 << log_n
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    fa = ctx.ntt_fr(a)
+    assert np.array_equal(ctx.ntt_fr(fa, inverse=True), a)
+    b = np.roll(a, 1, axis=0)
+    fb = ctx.ntt_fr(b)
+    assert np.array_equal(ctx.ntt_fr(ctx.fr_batch("add", a, b)), ctx.fr_batch("add", fa, fb))
+    delta = np.zeros((n, 4), np.uint64); delta[0, 0] = 1
+    ones = np.zeros((n, 4), np.uint64); ones[:, 0] = 1
+    assert np.array_equal(ctx.ntt_fr(delta), ones)
+
+
+@pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (2, 3), (17, 4), (100, 0), (300, 7), (1000, 11), (1000, 13)])
+def test_msm_matches_reference_sum(ctx, orc, n, c):
+    """GPU Pippenger == n double-and-add multiplications folded sequentially (mod.rs:255-272)."""
+    rng = SplitMix64(300 + n)
+    p1, p2, k = g1_points(orc, rng, n), g2_points(orc, rng, n), rand_fr(rng, n)
+    if n >= 17:   # zero / one / r-1 scalars, infinity and repeated points
+        k[0] = 0; k[1] = ints_to_limbs([1])[0]; k[2] = ints_to_limbs([R_MODULUS - 1])[0]
+        p1[3] = 0; p2[3] = 0
+        p1[5] = p1[4]; p2[5] = p2[4]; k[5] = k[4]
+        p1[7] = p1[6]; p2[7] = p2[6]; k[7] = ints_to_limbs([(R_MODULUS - int(zk.limbs_to_int(k[6]))) % R_MODULUS])[0]
+    assert np.array_equal(ctx.msm_g1(p1, k, c), orc.msm_g1(p1, k, 0))
+    assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
+
+
+def test_msm_mid_size_vs_pippenger_oracle(ctx, orc):
+    rng = SplitMix64(77)
+    n = 1 << 12
+    base1 = g1_points(orc, rng, 64)
+    base2 = g2_points(orc, rng, 64)
+    p1 = np.tile(base1, (n // 64, 1)); p2 = np.tile(base2, (n // 64, 1))
+    k = rand_fr(rng, n)
+    for c in (0, 8, 16):
+        assert np.array_equal(ctx.msm_g1(p1, k, c), orc.msm_g1(p1, k, 10))
+    assert np.array_equal(ctx.msm_g2(p2, k, 0), orc.msm_g2(p2, k, 10))
+
+
+def test_msm_linearity_large(ctx, orc):
+    """Size-independent property at 2^18 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b)."""
+    rng = SplitMix64(78)
+    n = 1 << 18
+    base1 = g1_points(orc, rng, 256)
+    p1 = np.tile(base1, (n // 256, 1))
+    gen = np.random.default_rng(3)
+    a = gen.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+    b = gen.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); b[:, 3] &= np.uint64((1 << 60) - 1)
+    sa, sb = ctx.msm_g1(p1, a), ctx.msm_g1(p1, b)
+    sab = ctx.msm_g1(p1, ctx.fr_batch("add", a, b))
+    assert np.array_equal(ctx.g1_add_batch(sa.reshape(1, 8), sb.reshape(1, 8))[0], sab)

@@ -1,0 +1,104 @@
+"""ctypes binding of libzkgpu.so (the C ABI in include/zkgpu.h).
+
+There is no CPU fallback: if the HIP extension is missing or no GPU is visible this module
+raises instead of silently computing something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+
+ZK_OK = 0
+ZK_ERR_ARG, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_SIZE, ZK_ERR_DIV_BY_ZERO, ZK_ERR_RANGE, ZK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+PROOF_BYTES = 259
+PARTIAL_BYTES = 768
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class SparseRows(C.Structure):
+    _fields_ = [("ptr", u64p), ("gate", u32p), ("val", u64p)]
+
+
+class QapSparseDesc(C.Structure):
+    _fields_ = [("log_n", C.c_uint), ("m", C.c_size_t), ("input", C.c_size_t),
+                ("u", SparseRows), ("v", SparseRows), ("w", SparseRows)]
+
+
+class CrsDesc(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("input", C.c_size_t),
+                ("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p),
+                ("xi_g1", u64p), ("sum_gamma_g1", u64p), ("sum_delta_g1", u64p), ("xi_t_g1", u64p),
+                ("beta_g2", u64p), ("gamma_g2", u64p), ("delta_g2", u64p), ("xi_g2", u64p)]
+
+
+class CrsOut(C.Structure):
+    _fields_ = [("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p), ("xi_g1", u64p),
+                ("sum_gamma_g1", u64p), ("sum_delta_g1", u64p), ("xi_t_g1", u64p),
+                ("beta_g2", u64p), ("gamma_g2", u64p), ("delta_g2", u64p), ("xi_g2", u64p)]
+
+
+# every symbol include/zkgpu.h declares: (restype, argtypes)
+SIGNATURES = {
+    "zk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_ctx_destroy": (None, [C.c_void_p]),
+    "zk_strerror": (C.c_char_p, [C.c_int]),
+    "zk_last_error": (C.c_char_p, [C.c_void_p]),
+    "zk_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    "zk_get_option": (C.c_long, [C.c_void_p, C.c_char_p]),
+    "zk_ntt_fr": (C.c_int, [C.c_void_p, u64p, C.c_uint, C.c_int, C.c_int]),
+    "zk_msm_g1": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
+    "zk_msm_g2": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
+    "zk_fr_batch": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
+    "zk_fq_batch": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
+    "zk_g1_mul_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
+    "zk_g2_mul_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
+    "zk_g1_add_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
+    "zk_g2_add_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
+    "zk_qap_upload_sparse": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.POINTER(C.c_void_p)]),
+    "zk_qap_upload_dense": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zk_qap_free": (None, [C.c_void_p]),
+    "zk_crs_upload": (C.c_int, [C.c_void_p, C.POINTER(CrsDesc), C.POINTER(C.c_void_p)]),
+    "zk_setup": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]),
+    "zk_crs_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "zk_crs_download": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CrsOut)]),
+    "zk_crs_free": (None, [C.c_void_p]),
+    "zk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, u64p, u8p]),
+    "zk_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
+    "zk_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
+    "zk_profile_reset": (C.c_int, [C.c_void_p]),
+    "zk_profile_count": (C.c_int, [C.c_void_p]),
+    "zk_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libzkgpu.so and types every entry point.  Raises if the extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "zksnark_rs_amd: HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is deliberately no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME libamdhip64.so.7).  Two HIP runtimes in
+    # one process cannot both see the GPU, so when torch is installed let it load first: libzkgpu.so
+    # then binds to the runtime that is already resident (device memory / streams / RCCL interop).
+    if os.environ.get("ZKGPU_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,191 @@
+// capi.hip -- the extern "C" surface declared in include/zkgpu.h.
+// Nothing here computes on the CPU: every entry point either launches HIP kernels or fails
+// with a status code (ZK_ERR_NO_DEVICE when no GPU is visible).
+#include <cstring>
+#include "kernels.hpp"
+#include "pipeline.hpp"
+
+using namespace zk;
+
+extern "C" {
+
+const char* zk_strerror(int status) {
+    switch (status) {
+        case ZK_OK: return "ok";
+        case ZK_ERR_ARG: return "invalid argument";
+        case ZK_ERR_HIP: return "HIP runtime error";
+        case ZK_ERR_NO_DEVICE: return "no HIP device (the product path has no CPU fallback)";
+        case ZK_ERR_SIZE: return "size out of supported range";
+        case ZK_ERR_DIV_BY_ZERO: return "division by zero";
+        case ZK_ERR_RANGE: return "field element out of range";
+        case ZK_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+int zk_ctx_create(int device_ordinal, zk_ctx** out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZK_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= count) return ZK_ERR_ARG;
+    zk_ctx* ctx = new (std::nothrow) zk_ctx();
+    if (!ctx) return ZK_ERR_HIP;
+    ctx->device = device_ordinal;
+    int rc = guarded(ctx, [&] {
+        hipDeviceProp_t prop;
+        ZK_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+        ctx->cu_count = prop.multiProcessorCount;
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ZK_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    });
+    if (rc != ZK_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return ZK_OK;
+}
+
+void zk_ctx_destroy(zk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->ntt_tables.clear();
+    ctx->msm_ws.reset();
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    delete ctx;
+}
+
+const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+static long* option_slot(zk_ctx* ctx, const char* key) {
+    if (!std::strcmp(key, "msm_window_bits")) return &ctx->opt_window_bits;
+    if (!std::strcmp(key, "profile")) return &ctx->opt_profile;
+    if (!std::strcmp(key, "msm_precompute")) return &ctx->opt_precompute;
+    if (!std::strcmp(key, "msm_balance")) return &ctx->opt_balance;
+    return nullptr;
+}
+int zk_set_option(zk_ctx* ctx, const char* key, long value) {
+    if (!ctx || !key) return ZK_ERR_ARG;
+    long* s = option_slot(ctx, key);
+    if (!s) return ZK_ERR_UNSUPPORTED;
+    *s = value;
+    return ZK_OK;
+}
+long zk_get_option(const zk_ctx* ctx, const char* key) {
+    if (!ctx || !key) return -1;
+    long* s = option_slot(const_cast<zk_ctx*>(ctx), key);
+    return s ? *s : -1;
+}
+
+int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { ntt_host(ctx, data, log_n, inverse, coset); ctx->resolve_profile(); });
+}
+int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out[ZK_G1_WORDS]) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { msm_host<Fq>(ctx, points, scalars, n, window_bits, out); ctx->resolve_profile(); });
+}
+int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out[ZK_G2_WORDS]) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { msm_host<Fq2>(ctx, points, scalars, n, window_bits, out); ctx->resolve_profile(); });
+}
+int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { field_batch<Fr>(ctx, op, a, b, out, n); });
+}
+int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { field_batch<Fq>(ctx, op, a, b, out, n); });
+}
+int zk_g1_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { point_mul_batch<Fq>(ctx, points, scalars, out, n); });
+}
+int zk_g2_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { point_mul_batch<Fq2>(ctx, points, scalars, out, n); });
+}
+int zk_g1_add_batch(zk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { point_add_batch<Fq>(ctx, a, b, out, n); });
+}
+int zk_g2_add_batch(zk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { point_add_batch<Fq2>(ctx, a, b, out, n); });
+}
+
+// ---- QAP / CRS / prove: see pipeline.hip ---------------------------------------------------
+int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** out) {
+    if (!ctx || !desc || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = qap_upload_sparse(ctx, *desc); });
+}
+int zk_qap_upload_dense(zk_ctx* ctx, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t,
+                        size_t m, size_t n, size_t input, zk_qap** out) {
+    if (!ctx || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = qap_upload_dense(ctx, u, v, w, t, m, n, input); });
+}
+void zk_qap_free(zk_qap* qap) { qap_free(qap); }
+
+int zk_crs_upload(zk_ctx* ctx, const zk_crs_desc* desc, zk_crs** out) {
+    if (!ctx || !desc || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = crs_upload(ctx, *desc); });
+}
+int zk_setup(zk_ctx* ctx, const zk_qap* qap, const uint64_t trapdoor[20], zk_crs** out) {
+    if (!ctx || !qap || !trapdoor || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = crs_setup(ctx, *qap, trapdoor); });
+}
+int zk_crs_dims(const zk_crs* crs, size_t* n, size_t* m, size_t* input) {
+    if (!crs) return ZK_ERR_ARG;
+    crs_dims(*crs, n, m, input);
+    return ZK_OK;
+}
+int zk_crs_download(zk_ctx* ctx, const zk_crs* crs, const zk_crs_out* out) {
+    if (!ctx || !crs || !out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { crs_download(ctx, *crs, *out); });
+}
+void zk_crs_free(zk_crs* crs) { crs_free(crs); }
+
+int zk_prove(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+             const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!ctx || !crs || !qap || !weights || !r || !s || !proof_out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_host(ctx, *crs, *qap, weights, m, r, s, proof_out); ctx->resolve_profile(); });
+}
+int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                 const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!ctx || !crs || !qap || !d_weights || !r || !s || !proof_out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, proof_out, 0, 1, nullptr); ctx->resolve_profile(); });
+}
+int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                     int rank, int world, void* d_partial_out) {
+    if (!ctx || !crs || !qap || !d_weights || !d_partial_out || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, nullptr, nullptr, nullptr, rank, world, d_partial_out); ctx->resolve_profile(); });
+}
+int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
+                     const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!ctx || !crs || !d_partials || world < 1 || !r || !s || !proof_out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_combine(ctx, *crs, d_partials, world, r, s, proof_out); ctx->resolve_profile(); });
+}
+
+int zk_profile_reset(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { ZK_HIP(hipStreamSynchronize(ctx->stream)); ctx->resolve_profile(); ctx->prof.clear(); });
+}
+int zk_profile_count(const zk_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
+int zk_profile_entry(const zk_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches, double* algo_bytes) {
+    if (!ctx || i < 0 || i >= (int)ctx->prof.size()) return ZK_ERR_ARG;
+    auto it = ctx->prof.begin();
+    std::advance(it, i);
+    if (name) *name = it->first.c_str();
+    if (total_ms) *total_ms = it->second.total_ms;
+    if (launches) *launches = it->second.launches;
+    if (algo_bytes) *algo_bytes = it->second.algo_bytes;
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// common.hpp -- context, error plumbing, device buffers and HIP-event profiling shared by the
+// translation units of libzkgpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/zkgpu.h"
+#include "ec.cuh"
+
+namespace zk {
+
+struct HipError {
+    hipError_t code;
+    std::string where;
+};
+
+#define ZK_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) throw ::zk::HipError{_e, std::string(#expr) + " @ " + __FILE__ + ":" + std::to_string(__LINE__)}; \
+    } while (0)
+
+struct StatusError {
+    int status;
+    std::string msg;
+};
+#define ZK_REQUIRE(cond, status, msg)                          \
+    do {                                                       \
+        if (!(cond)) throw ::zk::StatusError{(status), (msg)}; \
+    } while (0)
+
+// RAII device allocation
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) ZK_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    // grow-only: keeps the allocation when it is already large enough
+    void ensure(size_t count) {
+        if (count > n) alloc(count);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct ProfEntry {
+    double total_ms = 0;
+    uint64_t launches = 0;
+    double algo_bytes = 0;
+};
+struct PendingEvent {
+    std::string name;
+    hipEvent_t e0, e1;
+    double bytes;
+};
+
+struct NttTables;  // ntt.hip
+struct MsmWorkspace;  // msm.hip
+
+}  // namespace zk
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;  // side stream for latency-bound tails
+    std::string last_error;
+    long opt_window_bits = 0;
+    long opt_profile = 0;
+    long opt_precompute = 1;
+    long opt_balance = 1;
+    std::map<std::string, zk::ProfEntry> prof;
+    std::vector<zk::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<unsigned, std::shared_ptr<zk::NttTables>> ntt_tables;
+    std::shared_ptr<zk::MsmWorkspace> msm_ws;
+    int cu_count = 256;
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e;
+        ZK_HIP(hipEventCreate(&e));
+        return e;
+    }
+    // resolves pending event pairs (call after the stream is synchronised)
+    void resolve_profile() {
+        for (auto& pe : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+                auto& e = prof[pe.name];
+                e.total_ms += ms;
+                e.launches += 1;
+                e.algo_bytes += pe.bytes;
+            }
+            event_pool.push_back(pe.e0);
+            event_pool.push_back(pe.e1);
+        }
+        pending.clear();
+    }
+};
+
+namespace zk {
+
+// Brackets a kernel launch with HIP events on the launching stream when profiling is on.
+struct ProfScope {
+    zk_ctx* ctx;
+    hipStream_t st;
+    PendingEvent pe;
+    bool on;
+    ProfScope(zk_ctx* c, const char* name, double algo_bytes, hipStream_t s = nullptr) : ctx(c), st(s ? s : c->stream), on(c->opt_profile != 0) {
+        if (on) {
+            pe.name = name;
+            pe.bytes = algo_bytes;
+            pe.e0 = ctx->get_event();
+            pe.e1 = ctx->get_event();
+            (void)hipEventRecord(pe.e0, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(pe.e1, st);
+            ctx->pending.push_back(pe);
+        }
+    }
+};
+
+static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Runs `fn`, mapping exceptions to zk_status codes; never lets anything cross the C ABI.
+template <class Fn>
+int guarded(zk_ctx* ctx, Fn&& fn) {
+    try {
+        if (ctx) ZK_HIP(hipSetDevice(ctx->device));
+        fn();
+        return ZK_OK;
+    } catch (const HipError& e) {
+        if (ctx) ctx->last_error = std::string(hipGetErrorString(e.code)) + " in " + e.where;
+        return ZK_ERR_HIP;
+    } catch (const StatusError& e) {
+        if (ctx) ctx->last_error = e.msg;
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->last_error = "host allocation failed";
+        return ZK_ERR_HIP;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->last_error = e.what();
+        return ZK_ERR_ARG;
+    } catch (...) {
+        if (ctx) ctx->last_error = "unknown error";
+        return ZK_ERR_ARG;
+    }
+}
+
+}  // namespace zk

@@ -1,0 +1,320 @@
+// crs.hip -- device-resident CRS (SigmaG1/SigmaG2, /root/reference/src/groth16/mod.rs:105-121):
+// upload, download, the bit-reversed copies used by the roots-of-unity pipeline, and
+// groth16::setup (/root/reference/src/groth16/mod.rs:134-197) on the GPU with the trapdoor
+// injected (the reference draws it from thread_rng, mod.rs:139-145).
+#include "pipeline.hpp"
+
+namespace zk {
+
+// ---- upload / download -------------------------------------------------------------------
+template <class A>
+static void up_points(zk_ctx* ctx, DevBuf<A>& d, const uint64_t* src, size_t count, int* d_flag) {
+    d.alloc(std::max<size_t>(count, 1));
+    if (!count) return;
+    ZK_REQUIRE(src, ZK_ERR_ARG, "zk_crs_upload: null point array");
+    ZK_HIP(hipMemcpyAsync(d.p, src, count * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
+    pts_to_mont<A>(ctx, d.p, d.p, count, d_flag);
+}
+
+zk_crs* crs_upload(zk_ctx* ctx, const zk_crs_desc& d) {
+    ZK_REQUIRE(d.n >= 1 && d.m >= 1 && d.input < d.m, ZK_ERR_ARG, "zk_crs_upload: need n >= 1 and input < m");
+    std::unique_ptr<zk_crs> c(new zk_crs());
+    c->ctx = ctx;
+    c->n = d.n;
+    c->m = d.m;
+    c->input = d.input;
+    DevBuf<int> flag(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+    up_points(ctx, c->alpha1, d.alpha_g1, 1, flag.p);
+    up_points(ctx, c->beta1, d.beta_g1, 1, flag.p);
+    up_points(ctx, c->delta1, d.delta_g1, 1, flag.p);
+    up_points(ctx, c->xi1, d.xi_g1, d.n, flag.p);
+    up_points(ctx, c->sum_gamma1, d.sum_gamma_g1, d.input + 1, flag.p);
+    up_points(ctx, c->sum_delta1, d.sum_delta_g1, d.m - d.input - 1, flag.p);
+    up_points(ctx, c->xi_t1, d.xi_t_g1, d.n - 1, flag.p);
+    up_points(ctx, c->beta2, d.beta_g2, 1, flag.p);
+    up_points(ctx, c->gamma2, d.gamma_g2, 1, flag.p);
+    up_points(ctx, c->delta2, d.delta_g2, 1, flag.p);
+    up_points(ctx, c->xi2, d.xi_g2, d.n, flag.p);
+    int h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_crs_upload: coordinate >= q");
+    return c.release();
+}
+
+void crs_dims(const zk_crs& c, size_t* n, size_t* m, size_t* input) {
+    if (n) *n = c.n;
+    if (m) *m = c.m;
+    if (input) *input = c.input;
+}
+
+template <class A>
+static void down_points(zk_ctx* ctx, const DevBuf<A>& d, uint64_t* dst, size_t count) {
+    if (!dst || !count) return;
+    DevBuf<A> tmp(count);
+    pts_from_mont<A>(ctx, d.p, tmp.p, count);
+    ZK_HIP(hipMemcpyAsync(dst, tmp.p, count * sizeof(A), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void crs_download(zk_ctx* ctx, const zk_crs& c, const zk_crs_out& o) {
+    down_points(ctx, c.alpha1, o.alpha_g1, 1);
+    down_points(ctx, c.beta1, o.beta_g1, 1);
+    down_points(ctx, c.delta1, o.delta_g1, 1);
+    down_points(ctx, c.xi1, o.xi_g1, c.n);
+    down_points(ctx, c.sum_gamma1, o.sum_gamma_g1, c.input + 1);
+    down_points(ctx, c.sum_delta1, o.sum_delta_g1, c.m - c.input - 1);
+    down_points(ctx, c.xi_t1, o.xi_t_g1, c.n - 1);
+    down_points(ctx, c.beta2, o.beta_g2, 1);
+    down_points(ctx, c.gamma2, o.gamma_g2, 1);
+    down_points(ctx, c.delta2, o.delta_g2, 1);
+    down_points(ctx, c.xi2, o.xi_g2, c.n);
+}
+
+void crs_free(zk_crs* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    delete c;
+}
+
+// out[brev(i)] = i < count ? in[i] : infinity,  i < 2^log_n
+template <class A>
+__global__ void k_points_brev(const A* __restrict__ in, size_t count, A* __restrict__ out, unsigned log_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << log_n)) return;
+    uint32_t j = log_n ? (__brev((uint32_t)i) >> (32 - log_n)) : 0;
+    out[j] = i < count ? in[i] : A::infinity();
+}
+
+void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n) {
+    if (c.has_br && c.br_log_n == log_n) return;
+    size_t n = (size_t)1 << log_n;
+    ZK_REQUIRE(n == c.n, ZK_ERR_ARG, "CRS degree does not match the QAP domain");
+    c.xi1_br.alloc(n);
+    c.xi_t1_br.alloc(n);
+    c.xi2_br.alloc(n);
+    dim3 g(ceil_div(n, 256)), b(256);
+    hipLaunchKernelGGL(k_points_brev<G1A>, g, b, 0, ctx->stream, c.xi1.p, n, c.xi1_br.p, log_n);
+    hipLaunchKernelGGL(k_points_brev<G1A>, g, b, 0, ctx->stream, c.xi_t1.p, n - 1, c.xi_t1_br.p, log_n);
+    hipLaunchKernelGGL(k_points_brev<G2A>, g, b, 0, ctx->stream, c.xi2.p, n, c.xi2_br.p, log_n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    c.has_br = true;
+    c.br_log_n = log_n;
+}
+
+// ---- setup ---------------------------------------------------------------------------------
+struct SetupConsts {
+    Fr alpha, beta, gamma, delta, x;
+    Fr gamma_inv, delta_inv;
+    Fr tx;        // t(x)
+    Fr tx_dinv;   // t(x) / delta
+    Fr lag_c;     // (x^n - 1) / n   (sparse form)
+    G1A g1;       // 69 * G1::one()   (fr.rs:106-109)
+    G2A g2;       // 96 * G2::one()   (fr.rs:110-113)
+};
+
+struct G2GenWords {
+    uint32_t x0[8], x1[8], y0[8], y1[8];
+};
+static const G2GenWords G2GEN = {
+    {0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu},
+    {0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u},
+    {0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u},
+    {0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u}};
+
+__device__ __forceinline__ Fq fq_from_words(const uint32_t* w) {
+    Fq x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.l[i] = w[i];
+    return Fq::from_canonical(x);
+}
+
+// one lane: trapdoor (canonical) -> Montgomery constants, inverses, t(x), encryption bases
+__global__ void k_setup_consts(const Fr* __restrict__ td, G2GenWords gen, int dense, size_t n, unsigned log_n,
+                               const Fr* __restrict__ t_coeffs, SetupConsts* __restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    SetupConsts c;
+    c.alpha = Fr::from_canonical(td[0]);
+    c.beta = Fr::from_canonical(td[1]);
+    c.gamma = Fr::from_canonical(td[2]);
+    c.delta = Fr::from_canonical(td[3]);
+    c.x = Fr::from_canonical(td[4]);
+    c.gamma_inv = c.gamma.inv();
+    c.delta_inv = c.delta.inv();
+    if (dense) {
+        Fr acc = Fr::zero();  // Horner, Polynomial::evaluate (field/mod.rs:338-343)
+        for (size_t k = n + 1; k-- > 0;) acc = acc * c.x + t_coeffs[k];
+        c.tx = acc;
+        c.lag_c = Fr::zero();
+    } else {
+        Fr xn = c.x;
+        for (unsigned k = 0; k < log_n; ++k) xn = xn.sqr();
+        c.tx = xn - Fr::one();
+        Fr nn = Fr::zero();
+        nn.l[0] = (uint32_t)n;
+        c.lag_c = c.tx * Fr::from_canonical(nn).inv();
+    }
+    c.tx_dinv = c.tx * c.delta_inv;
+    G1J one1{Fq::from_u32(1), Fq::from_u32(2), Fq::one()};
+    c.g1 = jac_to_affine(jac_mul_small(one1, 69));
+    G2J one2{Fq2{fq_from_words(gen.x0), fq_from_words(gen.x1)}, Fq2{fq_from_words(gen.y0), fq_from_words(gen.y1)}, Fq2::one()};
+    c.g2 = jac_to_affine(jac_mul_small(one2, 96));
+    *out = c;
+}
+
+__device__ __forceinline__ Fr pow_u32(Fr base, uint32_t e) {
+    Fr acc = Fr::one();
+    for (int i = 31 - __clz(e | 1); i >= 0; --i) {
+        acc = acc.sqr();
+        if ((e >> i) & 1) acc = acc * base;
+    }
+    return acc;
+}
+
+// xi_s[i] = x^i ; xit_s[i] = x^i * t(x)/delta
+__global__ void k_setup_powers(const SetupConsts* __restrict__ cs, Fr* __restrict__ xi_s, Fr* __restrict__ xit_s, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr p = pow_u32(cs->x, (uint32_t)i);
+    xi_s[i] = p;
+    if (i + 1 < n) xit_s[i] = p * cs->tx_dinv;
+}
+
+// L[j] = (x^n - 1)/n * w^j / (x - w^j);  if x == w^j then L[j] = 1 (and lag_c == 0 zeroes the rest)
+__global__ void k_lagrange_at(const SetupConsts* __restrict__ cs, Fr w, Fr* __restrict__ L, size_t n) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Fr wj = pow_u32(w, (uint32_t)j);
+    Fr den = cs->x - wj;
+    L[j] = den.is_zero() ? Fr::one() : cs->lag_c * wj * den.inv();
+}
+
+// comb[i] = (beta*u_i(x) + alpha*v_i(x) + w_i(x)) / (i <= l ? gamma : delta)   (mod.rs:147-164)
+__global__ void k_setup_comb_sparse(const SetupConsts* __restrict__ cs, const Fr* __restrict__ L,
+                                    const uint32_t* up, const uint32_t* ug, const Fr* uv,
+                                    const uint32_t* vp, const uint32_t* vg, const Fr* vv,
+                                    const uint32_t* wp, const uint32_t* wg, const Fr* wv,
+                                    size_t m, size_t input, Fr* __restrict__ comb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr ux = Fr::zero(), vx = Fr::zero(), wx = Fr::zero();
+    for (uint32_t k = up[i]; k < up[i + 1]; ++k) ux = ux + uv[k] * L[ug[k]];
+    for (uint32_t k = vp[i]; k < vp[i + 1]; ++k) vx = vx + vv[k] * L[vg[k]];
+    for (uint32_t k = wp[i]; k < wp[i + 1]; ++k) wx = wx + wv[k] * L[wg[k]];
+    Fr c = cs->beta * ux + cs->alpha * vx + wx;
+    comb[i] = c * (i <= input ? cs->gamma_inv : cs->delta_inv);
+}
+__global__ void k_setup_comb_dense(const SetupConsts* __restrict__ cs, const Fr* __restrict__ U, const Fr* __restrict__ V,
+                                   const Fr* __restrict__ W, size_t m, size_t n, size_t input, Fr* __restrict__ comb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr x = cs->x, ux = Fr::zero(), vx = Fr::zero(), wx = Fr::zero();
+    for (size_t k = n; k-- > 0;) {
+        ux = ux * x + U[i * n + k];
+        vx = vx * x + V[i * n + k];
+        wx = wx * x + W[i * n + k];
+    }
+    Fr c = cs->beta * ux + cs->alpha * vx + wx;
+    comb[i] = c * (i <= input ? cs->gamma_inv : cs->delta_inv);
+}
+
+// out[i] = scalars[i] * base  (encrypt_g1 / encrypt_g2, fr.rs:106-113), one lane per scalar
+template <class F>
+__global__ __launch_bounds__(64) void k_fixed_base_mul(const Aff<F>* __restrict__ base, const Fr* __restrict__ scalars, Aff<F>* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr k = scalars[i].to_canonical();
+    Aff<F> b = *base;
+    Jac<F> acc = Jac<F>::infinity();
+    bool started = false;
+    for (int bit = 255; bit >= 0; --bit) {
+        if (started) acc = jac_dbl_ni(acc);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1) {
+            acc = jac_madd_ni(acc, b);
+            started = true;
+        }
+    }
+    out[i] = jac_to_affine(acc);
+}
+template <class F>
+static void fixed_base_mul(zk_ctx* ctx, const Aff<F>* base, const Fr* scalars, Aff<F>* out, size_t n, const char* name) {
+    if (!n) return;
+    ProfScope ps(ctx, name, (32.0 + sizeof(Aff<F>)) * n);
+    hipLaunchKernelGGL(k_fixed_base_mul<F>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, base, scalars, out, n);
+    ZK_HIP(hipGetLastError());
+}
+
+zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
+    for (int k = 0; k < 5; ++k) {
+        const uint64_t* e = trapdoor + 4 * k;
+        // Random for FrLocal never yields 0 (fr.rs:90-99); gamma/delta == 0 would panic in `/` (fr.rs:54)
+        ZK_REQUIRE(e[0] | e[1] | e[2] | e[3], ZK_ERR_DIV_BY_ZERO, "zk_setup: trapdoor elements must be non-zero");
+    }
+    const size_t n = q.n, m = q.m, l = q.input;
+    std::unique_ptr<zk_crs> c(new zk_crs());
+    c->ctx = ctx;
+    c->n = n;
+    c->m = m;
+    c->input = l;
+    hipStream_t st = ctx->stream;
+    DevBuf<Fr> td(5);
+    DevBuf<int> flag(1);
+    DevBuf<SetupConsts> cs(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    ZK_HIP(hipMemcpyAsync(td.p, trapdoor, 5 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    {
+        DevBuf<Fr> tmp(5);
+        fr_to_mont(ctx, td.p, tmp.p, 5, flag.p);  // range check only
+        int h = 0;
+        ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_setup: trapdoor element >= r");
+    }
+    hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, st, td.p, G2GEN, q.dense ? 1 : 0, n, q.log_n, q.dt.p, cs.p);
+    ZK_HIP(hipGetLastError());
+
+    DevBuf<Fr> xi_s(n), xit_s(std::max<size_t>(n, 1)), comb(m);
+    hipLaunchKernelGGL(k_setup_powers, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, xi_s.p, xit_s.p, n);
+    if (q.dense) {
+        hipLaunchKernelGGL(k_setup_comb_dense, dim3(ceil_div(m, 64)), dim3(64), 0, st, cs.p, q.du.p, q.dv.p, q.dw.p, m, n, l, comb.p);
+    } else {
+        DevBuf<Fr> L(n);
+        hipLaunchKernelGGL(k_lagrange_at, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, host_root_of_unity(q.log_n), L.p, n);
+        hipLaunchKernelGGL(k_setup_comb_sparse, dim3(ceil_div(m, 256)), dim3(256), 0, st, cs.p, L.p,
+                           q.u_wire.ptr.p, q.u_wire.idx.p, q.u_wire.val.p, q.v_wire.ptr.p, q.v_wire.idx.p, q.v_wire.val.p,
+                           q.w_wire.ptr.p, q.w_wire.idx.p, q.w_wire.val.p, m, l, comb.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));  // L is freed at scope exit
+    }
+    ZK_HIP(hipGetLastError());
+
+    const G1A* g1 = &cs.p->g1;
+    const G2A* g2 = &cs.p->g2;
+    c->xi1.alloc(n);
+    c->xi2.alloc(n);
+    c->xi_t1.alloc(std::max<size_t>(n - 1, 1));
+    c->sum_gamma1.alloc(l + 1);
+    c->sum_delta1.alloc(std::max<size_t>(m - l - 1, 1));
+    c->alpha1.alloc(1); c->beta1.alloc(1); c->delta1.alloc(1);
+    c->beta2.alloc(1); c->gamma2.alloc(1); c->delta2.alloc(1);
+    fixed_base_mul<Fq>(ctx, g1, xi_s.p, c->xi1.p, n, "setup_fixed_base_g1");
+    fixed_base_mul<Fq>(ctx, g1, xit_s.p, c->xi_t1.p, n - 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq>(ctx, g1, comb.p, c->sum_gamma1.p, l + 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq>(ctx, g1, comb.p + l + 1, c->sum_delta1.p, m - l - 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq2>(ctx, g2, xi_s.p, c->xi2.p, n, "setup_fixed_base_g2");
+    // alpha, beta, gamma, delta sit first in SetupConsts (Montgomery)
+    const Fr* tdm = &cs.p->alpha;
+    fixed_base_mul<Fq>(ctx, g1, tdm + 0, c->alpha1.p, 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq>(ctx, g1, tdm + 1, c->beta1.p, 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq>(ctx, g1, tdm + 3, c->delta1.p, 1, "setup_fixed_base_g1");
+    fixed_base_mul<Fq2>(ctx, g2, tdm + 1, c->beta2.p, 1, "setup_fixed_base_g2");
+    fixed_base_mul<Fq2>(ctx, g2, tdm + 2, c->gamma2.p, 1, "setup_fixed_base_g2");
+    fixed_base_mul<Fq2>(ctx, g2, tdm + 3, c->delta2.p, 1, "setup_fixed_base_g2");
+    ZK_HIP(hipStreamSynchronize(st));
+    ctx->resolve_profile();
+    return c.release();
+}
+
+}  // namespace zk

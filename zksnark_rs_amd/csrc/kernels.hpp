@@ -1,0 +1,63 @@
+// kernels.hpp -- internal interfaces between the translation units of libzkgpu.so.
+#pragma once
+#include "common.hpp"
+
+namespace zk {
+
+// ---- field_kernels.hip ----
+template <class F> void field_batch(zk_ctx*, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+void fr_to_mont(zk_ctx*, const Fr* in, Fr* out, size_t n, int* d_flag);
+void fr_from_mont(zk_ctx*, const Fr* in, Fr* out, size_t n);
+template <class A> void pts_to_mont(zk_ctx*, const A* in, A* out, size_t n, int* d_flag);
+template <class A> void pts_from_mont(zk_ctx*, const A* in, A* out, size_t n);
+template <class F> void point_mul_batch(zk_ctx*, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
+template <class F> void point_add_batch(zk_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+// ---- ntt.hip ----
+// Host-side field constants (computed with the same ff.cuh code on the host)
+Fr host_root_of_unity(unsigned log_n);   // w = 5^((r-1)/2^log_n), Montgomery form
+Fr host_fr_from_u64(uint64_t v);
+Fr host_fr_pow(Fr base, uint64_t e);
+
+constexpr unsigned NTT_MAX_LOCAL_LOG = 11;   // 2048-element LDS tiles (64 KiB)
+constexpr unsigned NTT_MAX_LOG = 22;
+
+struct NttTables {
+    unsigned log_n = 0;
+    DevBuf<Fr> tw_fwd, tw_inv;       // w_2048^k and w_2048^-k, k < 1024 (local butterflies)
+    DevBuf<Fr> mid_fwd, mid_inv;     // inter-pass twiddles, n entries each (log_n > 11)
+    DevBuf<Fr> coset_fwd_brev;       // g^brev(pos)                     (prove pipeline, DIT input order)
+    DevBuf<Fr> coset_inv_brev_half;  // g^-brev(pos) / 2                (prove pipeline, h combine)
+    Fr n_inv;                        // 1/n
+};
+std::shared_ptr<NttTables> ntt_get_tables(zk_ctx*, unsigned log_n);
+void ntt_ensure_coset_tables(zk_ctx*, NttTables&);
+
+// natural order in -> bit-reversed order out.  inverse: use w^-1; scale_n_inv: multiply by 1/n.
+void ntt_dif(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv);
+// bit-reversed order in -> natural order out.  d_pre (optional): element-wise multiplier applied
+// to the input (in its bit-reversed order) as it is loaded.
+void ntt_dit(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, const Fr* d_pre);
+void bitrev_permute(zk_ctx*, const Fr* d_in, Fr* d_out, unsigned log_n);
+// out[i] = a[i] * b[i]
+void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);
+// out[i] = base^i * scale (natural order powers)
+void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
+void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
+
+// ---- msm.hip ----
+struct MsmPlan {
+    int c = 0;           // window bits
+    int windows = 0;     // floor(254/c)+1
+    int first_window = 0, window_step = 1;  // window subset owned by this rank: first, first+step, ...
+};
+int msm_auto_window(size_t n);
+// Sum_i scalars[i]*points[i].  points: affine Montgomery; scalars: CANONICAL Fr limbs.
+// Result (Jacobian, Montgomery) is written to d_out.  Only windows w = first + k*step are
+// accumulated; the missing windows contribute nothing (multi-GPU partial sums).
+template <class F>
+void msm_run(zk_ctx*, const Aff<F>* d_points, const Fr* d_scalars, size_t n, const MsmPlan& plan, Jac<F>* d_out, const char* tag);
+template <class F>
+void msm_host(zk_ctx*, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine);
+
+}  // namespace zk

@@ -1,0 +1,68 @@
+// pipeline.hpp -- device-resident QAP / CRS handles and the prove / setup pipelines.
+#pragma once
+#include "kernels.hpp"
+
+namespace zk {
+
+// CSR with Fr values (Montgomery) on the device
+struct DevCsr {
+    DevBuf<uint32_t> ptr;   // rows+1
+    DevBuf<uint32_t> idx;   // nnz column indices
+    DevBuf<Fr> val;         // nnz
+    size_t rows = 0, nnz = 0;
+};
+
+}  // namespace zk
+
+struct zk_qap {
+    zk_ctx* ctx = nullptr;
+    bool dense = false;
+    size_t n = 0, m = 0, input = 0;
+    unsigned log_n = 0;
+    // sparse form (roots w^j): by gate (prove: evaluation vectors) and by wire (setup: u_i(x))
+    zk::DevCsr u_gate, v_gate;
+    zk::DevCsr u_wire, v_wire, w_wire;
+    // dense form: m x n coefficient matrices and t (n+1), Montgomery
+    zk::DevBuf<zk::Fr> du, dv, dw, dt;
+    size_t t_degree = 0;      // actual degree of t (dense)
+    zk::DevBuf<zk::Fr> t_cinv; // 1 / leading coefficient of t (dense)
+    bool t_is_zero = false;
+    // scratch reused across proofs
+    zk::DevBuf<zk::Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, h_can, wc, prod_a, prod_b;
+};
+
+struct zk_crs {
+    zk_ctx* ctx = nullptr;
+    size_t n = 0, m = 0, input = 0;
+    zk::DevBuf<zk::G1A> alpha1, beta1, delta1;          // 1 each
+    zk::DevBuf<zk::G1A> xi1, sum_gamma1, sum_delta1, xi_t1;
+    zk::DevBuf<zk::G2A> beta2, gamma2, delta2, xi2;
+    // bit-reversed copies for the roots-of-unity pipeline (built on first use); xi_t1_br has n
+    // entries, the last one (coefficient n-1, never used by the reference) is infinity
+    zk::DevBuf<zk::G1A> xi1_br, xi_t1_br;
+    zk::DevBuf<zk::G2A> xi2_br;
+    unsigned br_log_n = 0;
+    bool has_br = false;
+};
+
+namespace zk {
+
+zk_qap* qap_upload_sparse(zk_ctx*, const zk_qap_sparse_desc&);
+zk_qap* qap_upload_dense(zk_ctx*, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input);
+void qap_free(zk_qap*);
+
+zk_crs* crs_upload(zk_ctx*, const zk_crs_desc&);
+zk_crs* crs_setup(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20]);
+void crs_dims(const zk_crs&, size_t* n, size_t* m, size_t* input);
+void crs_download(zk_ctx*, const zk_crs&, const zk_crs_out&);
+void crs_free(zk_crs*);
+void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
+
+void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
+// rank/world select the owned Pippenger windows.  With d_partial_out == nullptr the proof is
+// finished locally (world must be 1); otherwise the five partial sums are written there.
+void prove_dev(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
+               uint8_t* proof_out, int rank, int world, void* d_partial_out);
+void prove_combine(zk_ctx*, const zk_crs&, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
+
+}  // namespace zk
