@@ -38,6 +38,12 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         ctx->cu_count = prop.multiProcessorCount;
         ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ZK_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
+            ZK_HIP(hipStreamCreateWithFlags(&ctx->msm_stream[i], hipStreamNonBlocking));
+            ZK_HIP(hipEventCreateWithFlags(&ctx->msm_done[i], hipEventDisableTiming));
+        }
+        ZK_HIP(hipEventCreateWithFlags(&ctx->fork_evt, hipEventDisableTiming));
+        msm_set_lds_attributes();
     });
     if (rc != ZK_OK) { delete ctx; return rc; }
     *out = ctx;
@@ -49,7 +55,12 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->ntt_tables.clear();
-    ctx->msm_ws.reset();
+    for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
+        ctx->msm_ws[i].reset();
+        if (ctx->msm_stream[i]) { (void)hipStreamSynchronize(ctx->msm_stream[i]); (void)hipStreamDestroy(ctx->msm_stream[i]); }
+        if (ctx->msm_done[i]) (void)hipEventDestroy(ctx->msm_done[i]);
+    }
+    if (ctx->fork_evt) (void)hipEventDestroy(ctx->fork_evt);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

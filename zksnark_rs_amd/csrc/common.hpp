@@ -77,7 +77,7 @@ struct PendingEvent {
 };
 
 struct NttTables;  // ntt.hip
-struct MsmWorkspace;  // msm.hip
+struct MsmWorkspace;  // kernels.hpp
 
 }  // namespace zk
 
@@ -94,7 +94,11 @@ struct zk_ctx {
     std::vector<zk::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<unsigned, std::shared_ptr<zk::NttTables>> ntt_tables;
-    std::shared_ptr<zk::MsmWorkspace> msm_ws;
+    static constexpr int MSM_STREAMS = 5;
+    std::shared_ptr<zk::MsmWorkspace> msm_ws[MSM_STREAMS];
+    hipStream_t msm_stream[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t msm_done[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_evt = nullptr;
     int cu_count = 256;
 
     hipEvent_t get_event() {

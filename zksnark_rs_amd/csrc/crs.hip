@@ -104,6 +104,25 @@ void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n) {
     c.br_log_n = log_n;
 }
 
+void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
+    if (c.tables_kind == (brev ? 1 : 0) && c.tables_c == ctx->opt_window_bits) return;
+    if (brev) crs_ensure_brev(ctx, c, log_n);
+    auto pick = [&](size_t count) { return ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(count); };
+    const size_t n = c.n, nl = c.m - c.input - 1;
+    // xi_t has n-1 points; the bit-reversed copy is padded with infinity to n entries
+    msm_build_table<Fq>(ctx, brev ? c.xi1_br.p : c.xi1.p, n, pick(n), c.t_xi1);
+    msm_build_table<Fq>(ctx, brev ? c.xi_t1_br.p : c.xi_t1.p, brev ? n : n - 1, pick(n), c.t_xi_t1);
+    msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
+    msm_build_table<Fq2>(ctx, brev ? c.xi2_br.p : c.xi2.p, n, pick(n), c.t_xi2);
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (brev) {   // the tables now hold the permuted points
+        c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();
+        c.has_br = false;
+    }
+    c.tables_kind = brev ? 1 : 0;
+    c.tables_c = ctx->opt_window_bits;
+}
+
 // ---- setup ---------------------------------------------------------------------------------
 struct SetupConsts {
     Fr alpha, beta, gamma, delta, x;

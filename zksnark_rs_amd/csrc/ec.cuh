@@ -58,7 +58,7 @@ ZK_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
     F U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
     F S1 = p.Y * q.Z * Z2Z2, S2 = q.Y * p.Z * Z1Z1;
     if (U1 == U2) {
-        if (S1 == S2) return jac_dbl_ni(p);   // rare: keep the doubling out of line
+        if (S1 == S2) return jac_dbl_ni(p);
         return Jac<F>::infinity();
     }
     F H = U2 - U1;

@@ -6,7 +6,7 @@
 // one element per lane, 32 B per element in HBM so a lane moves an element with two
 // global_load_dwordx4.
 //
-// Values are kept fully reduced in [0, p) and in Montgomery form (R = 2^256) on the device.
+// Values are kept fully reduced in [0, p) and in Montgomery form (R = 2^261) on the device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,16 +18,19 @@ namespace zk {
 struct FrParams {
     // r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     static constexpr uint32_t P[8]  = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t R1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
-    static constexpr uint32_t INV = 0xefffffffu;  // -p^-1 mod 2^32
+    // Montgomery radix R = 2^261 = (2^29)^9, see Fp::operator*
+    static constexpr uint32_t R1[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};
+    static constexpr uint32_t R2[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u, 0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};
+    static constexpr uint32_t P29[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV29 = 0x0fffffffu;  // -p^-1 mod 2^29
 };
 struct FqParams {
     // q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
     static constexpr uint32_t P[8]  = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t R1[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
-    static constexpr uint32_t INV = 0xe4866389u;
+    static constexpr uint32_t R1[8] = {0x157ccc21u, 0x4e8384ebu, 0x0ce148c3u, 0xfb90a602u, 0x819caa36u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};
+    static constexpr uint32_t R2[8] = {0x659bac10u, 0xe1a2a074u, 0x5406005au, 0x63985586u, 0x2d3e2632u, 0xff54c580u, 0x34ea65a6u, 0x2a11a68cu};
+    static constexpr uint32_t P29[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV29 = 0x04866389u;
 };
 
 template <class PR>
@@ -116,43 +119,89 @@ struct alignas(16) Fp {
     ZK_HD Fp operator-() const { return zero() - *this; }
     ZK_HD Fp dbl() const { return *this + *this; }
 
-    // CIOS Montgomery product a*b*R^-1 mod p; 8x8 limb products as 64-bit multiply-adds
-    // (v_mad_u64_u32 on gfx950).
-    ZK_HD Fp operator*(const Fp& b) const {
-        uint32_t t[10];
+    // ---- Montgomery multiplication, radix 2^29 product scanning -----------------------------
+    // On gfx950 v_mad_u64_u32 (32x32+64 -> 64) issues at the same rate as a 64-bit add or an
+    // add-with-carry (tools/ubench_valu.hip), so the cost of a 254-bit multiply is the NUMBER of
+    // VALU instructions, not the number of multiplies.  With 9 limbs of 29 bits a whole column of
+    // the schoolbook product plus the Montgomery correction (18 products < 2^58) fits one 64-bit
+    // accumulator: every limb product is exactly one v_mad_u64_u32 accumulating in place, with no
+    // carry handling inside a column -- 162 multiply-adds + ~60 shifts/masks instead of the
+    // 136 + ~430 of the 32-bit CIOS form (1.5x-1.9x faster, tools/ubench_field.hip).
+    static constexpr uint32_t M29 = 0x1fffffffu;
+    ZK_HD static void to29(const uint32_t* x, uint32_t* o) {   // o[k] = bits [29k, 29k+29)
 #pragma unroll
-        for (int i = 0; i < 10; ++i) t[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint64_t c = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                c = (uint64_t)l[j] * b.l[i] + t[j] + c;
-                t[j] = (uint32_t)c;
-                c >>= 32;
-            }
-            c += t[8];
-            t[8] = (uint32_t)c;
-            t[9] = (uint32_t)(c >> 32);
-            uint32_t m = t[0] * PR::INV;
-            c = (uint64_t)m * PR::P[0] + t[0];
-            c >>= 32;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) {
-                c = (uint64_t)m * PR::P[j] + t[j] + c;
-                t[j - 1] = (uint32_t)c;
-                c >>= 32;
-            }
-            c += t[8];
-            t[7] = (uint32_t)c;
-            t[8] = t[9] + (uint32_t)(c >> 32);
+        for (int k = 0; k < 9; ++k) {
+            const int bit = 29 * k, w = bit >> 5, s = bit & 31;
+            uint32_t lo = x[w] >> s;
+            if (s > 3 && w + 1 < 8) lo |= x[w + 1] << (32 - s);
+            o[k] = lo & M29;
         }
-        Fp r;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r.l[i] = t[i];
-        return reduce_once(r, t[8]);
     }
-    ZK_HD Fp sqr() const { return *this * *this; }
+    ZK_HD static void from29(const uint32_t* a, uint32_t* x) {   // limbs < 2^29 -> 8 x 32
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int bit = 32 * w, k = bit / 29, s = bit - 29 * k;
+            uint32_t v = a[k] >> s;
+            const int have = 29 - s;
+            if (have < 32 && k + 1 < 9) v |= a[k + 1] << have;
+            if (have + 29 < 32 && k + 2 < 9) v |= a[k + 2] << (have + 29);
+            x[w] = v;
+        }
+    }
+    // r = a*b*2^-261 mod p (r < 2p), a, b, r as 9 x 29-bit limbs.  SQR: a == b, symmetric terms
+    // are formed once with a doubled limb (45 instead of 81 products).
+    template <bool SQR>
+    ZK_HD static void mont29(const uint32_t* a, const uint32_t* b, uint32_t* r) {
+        uint32_t m[9], a2[9];
+        if (SQR) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
+        }
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+            if (SQR) {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) {
+                    const int j = k - i;
+                    if (i < j) acc += (uint64_t)a2[i] * a[j];
+                    else if (i == j) acc += (uint64_t)a[i] * a[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) acc += (uint64_t)a[i] * b[k - i];
+            }
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i < k || k >= 9) acc += (uint64_t)m[i] * PR::P29[k - i];
+            if (k < 9) {
+                m[k] = ((uint32_t)acc * PR::INV29) & M29;
+                acc += (uint64_t)m[k] * PR::P29[0];
+            } else {
+                r[k - 9] = (uint32_t)acc & M29;
+            }
+            acc >>= 29;
+        }
+        r[8] = (uint32_t)acc;
+    }
+    ZK_HD Fp operator*(const Fp& b) const {
+        uint32_t x[9], y[9], r[9];
+        to29(l, x);
+        to29(b.l, y);
+        mont29<false>(x, y, r);
+        Fp o;
+        from29(r, o.l);
+        return reduce_once(o, 0);
+    }
+    ZK_HD Fp sqr() const {
+        uint32_t x[9], r[9];
+        to29(l, x);
+        mont29<true>(x, x, r);
+        Fp o;
+        from29(r, o.l);
+        return reduce_once(o, 0);
+    }
 
     // canonical integer <-> Montgomery
     ZK_HD static Fp from_canonical(const Fp& x) { return x * r2(); }

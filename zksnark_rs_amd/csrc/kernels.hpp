@@ -46,17 +46,29 @@ void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
 void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
 
 // ---- msm.hip ----
-struct MsmPlan {
-    int c = 0;           // window bits
-    int windows = 0;     // floor(254/c)+1
-    int first_window = 0, window_step = 1;  // window subset owned by this rank: first, first+step, ...
+constexpr int MSM_MAX_C = 16;   // 2^(c-1) LDS counters per sorting workgroup (128 KiB at c = 16)
+
+// T[w][i] = 2^(c w) P_i, w < windows, i < n (affine, Montgomery)
+template <class F>
+struct MsmTable {
+    DevBuf<Aff<F>> table;
+    size_t n = 0;
+    int c = 0, windows = 0;
+};
+struct MsmWorkspace {
+    DevBuf<uint32_t> hist, total, start, sorted;
+    DevBuf<uint8_t> partial, bucket_sums, seg_sums;
 };
 int msm_auto_window(size_t n);
-// Sum_i scalars[i]*points[i].  points: affine Montgomery; scalars: CANONICAL Fr limbs.
-// Result (Jacobian, Montgomery) is written to d_out.  Only windows w = first + k*step are
-// accumulated; the missing windows contribute nothing (multi-GPU partial sums).
+void msm_set_lds_attributes();
 template <class F>
-void msm_run(zk_ctx*, const Aff<F>* d_points, const Fr* d_scalars, size_t n, const MsmPlan& plan, Jac<F>* d_out, const char* tag);
+void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& out);
+// sum_{i < n_used} scalars[i] * P_i over the table's bases; scalars are CANONICAL Fr limbs.
+// Only windows w = rank (mod world) are accumulated (multi-GPU partial sums).  Everything is
+// enqueued on `st`; the result (Jacobian, Montgomery) lands in d_out.
+template <class F>
+void msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
+             int rank, int world, Jac<F>* d_out);
 template <class F>
 void msm_host(zk_ctx*, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine);
 

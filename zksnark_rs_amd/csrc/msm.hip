@@ -1,52 +1,81 @@
-// msm.hip -- Pippenger bucket multi-scalar multiplication in G1 and G2 for gfx950.
+// msm.hip -- fixed-base Pippenger multi-scalar multiplication in G1 and G2 for gfx950.
 //
 // Replaces the SigmaG1/SigmaG2 inner products of groth16::prove
 // (/root/reference/src/groth16/mod.rs:255-272,279-290): the reference performs n independent
 // 256-bit double-and-add scalar multiplications (exp_encrypted_g1/g2,
 // /root/reference/src/groth16/fr.rs:114-119) and folds them sequentially (Sum for G1Local/G2Local,
 // fr.rs:191-198,217-223).  The sum is a group element, so any evaluation order gives the same
-// affine point; here it is evaluated with signed c-bit windows and buckets:
+// affine point.
 //
-//   digits   : one lane per scalar recodes it into W = floor(254/c)+1 signed digits and
-//              histograms |digit| per window (global atomics on 2^(c-1) counters per window)
-//   scan     : one workgroup per window, exclusive prefix sum -> bucket offsets
-//   scatter  : counting sort of (point index, sign) by bucket
-//   accumulate: one lane per (window, bucket): mixed Jacobian+affine additions of that bucket's
-//              points (64 B / 128 B gathers, the CRS is L2/Infinity-Cache resident at 2^20)
-//   reduce   : per window sum_b b*bucket[b] by segmented running sums + a block tree reduction
-//   horner   : sum_w 2^(c w) S_w
-//
-// Windows are independent, which is what the multi-GPU path shards (MsmPlan::first_window/step).
+// MI355X-first design.  The bases are CRS points, fixed across proofs, and the GPU has 288 GB of
+// HBM, so every base P_i is stored W times as T[w][i] = 2^(c w) P_i (W = floor(254/c)+1 signed
+// c-bit windows).  All windows then share ONE set of 2^(c-1) buckets:
+//     sum_i k_i P_i = sum_b b * ( sum_{(w,i): |digit_w(k_i)| = b} sign * T[w][i] )
+// which removes the per-window bucket reductions and the serial 254-doubling Horner tail of the
+// textbook algorithm.  Per MSM:
+//   hist      one workgroup per scalar chunk: signed-digit recoding + histogram of all owned
+//             windows in LDS (2^(c-1) counters = 128 KiB at c = 16), one row per chunk to HBM
+//   offsets   per bucket exclusive prefix over chunks, then a scan over buckets
+//   scatter   same chunks: counting sort of (w*n + i, sign) by bucket, positions from LDS atomics
+//   accumulate T lanes per bucket walk the bucket's list (strided, so the index list is read
+//             coalesced) doing mixed Jacobian+affine additions of gathered 64 B / 128 B points
+//   reduce    merge the T partials per bucket, segmented running sums for sum_b b*S_b, block
+//             tree reduction -> one point
+// Windows are independent: rank g of a multi-GPU job owns windows w = g (mod world) and needs
+// only those slices of T (MsmPlan::first_window / window_step).
 #include "kernels.hpp"
 
 namespace zk {
 
-struct MsmWorkspace {
-    DevBuf<uint32_t> digits, sorted, counts, offsets, cursor;
-    DevBuf<uint8_t> buckets, partials, window_sums;
-};
-
 int msm_auto_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg - 4;
+    int c = lg;
     if (c < 3) c = 3;
-    if (c > 16) c = 16;
+    if (c > MSM_MAX_C) c = MSM_MAX_C;
     return c;
 }
 
-constexpr int MSM_SEG = 8;  // buckets per lane in the running-sum reduction
+constexpr int MSM_SEG = 8;       // buckets per lane in the running-sum reduction
+constexpr int SORT_THREADS = 1024;
 
-// ---- digits + histogram ------------------------------------------------------------------
-// digits[wl * n + i] = (|d| << 1) | (d < 0) for owned window index wl
-__global__ void k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int windows, int first, int step,
-                             uint32_t* __restrict__ digits, uint32_t* __restrict__ counts, int buckets) {
+// ---- table precompute: T[w][i] = 2^(c w) P_i ------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_precompute(const Aff<F>* __restrict__ pts, size_t n, int c, int windows, Aff<F>* __restrict__ table) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr k = scalars[i];
+    Aff<F> p = pts[i];
+    table[i] = p;
+    Jac<F> j = Jac<F>::from_affine(p);
+    for (int w = 1; w < windows; ++w) {
+        for (int k = 0; k < c; ++k) j = jac_dbl_ni(j);
+        table[(size_t)w * n + i] = jac_to_affine(j);
+    }
+}
+
+template <class F>
+void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& t) {
+    ZK_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZK_ERR_ARG, "msm: window_bits must be in [2, 16]");
+    t.c = c;
+    t.windows = 254 / c + 1;
+    t.n = n;
+    ZK_REQUIRE((size_t)t.windows * std::max<size_t>(n, 1) < ((size_t)1 << 31), ZK_ERR_SIZE, "msm: too many points for this window size");
+    t.table.alloc(std::max<size_t>((size_t)t.windows * n, 1));
+    if (!n) return;
+    ProfScope ps(ctx, sizeof(F) > sizeof(Fq) ? "msm_precompute_g2" : "msm_precompute_g1", (double)sizeof(Aff<F>) * n * (t.windows + 1));
+    hipLaunchKernelGGL(k_msm_precompute<F>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, d_points, n, c, t.windows, t.table.p);
+    ZK_HIP(hipGetLastError());
+}
+template void msm_build_table<Fq>(zk_ctx*, const G1A*, size_t, int, MsmTable<Fq>&);
+template void msm_build_table<Fq2>(zk_ctx*, const G2A*, size_t, int, MsmTable<Fq2>&);
+
+// ---- signed-digit recoding -------------------------------------------------------------------
+// Calls f(w, mag, neg) for every owned window with a non-zero digit.
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, int first, int step, Fn&& f) {
     uint32_t carry = 0;
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
-    int wl = 0, next_owned = first;
+    int next_owned = first;
     for (int w = 0; w < windows; ++w) {
         int pos = w * c, word = pos >> 5, off = pos & 31;
         uint32_t raw = 0;
@@ -60,200 +89,222 @@ __global__ void k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, in
         uint32_t mag = neg ? (1u << c) - raw : raw;
         carry = neg;
         if (w == next_owned) {
-            digits[(size_t)wl * n + i] = (mag << 1) | (neg & (mag != 0));
-            if (mag) atomicAdd(&counts[(size_t)wl * (buckets + 1) + mag], 1u);
-            ++wl;
+            if (mag) f(w, mag, neg);
             next_owned += step;
         }
     }
 }
 
-// ---- exclusive scan of counts[w][0..buckets] -> offsets, cursor ---------------------------
-__global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                    uint32_t* __restrict__ cursor, int buckets) {
+// hist[chunk][b] = number of digits of magnitude b+1 among the chunk's scalars
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
+                                                           int first, int step, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int buckets = 1 << (c - 1);
+    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = 0;
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
+    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        Fr k = scalars[i];
+        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { atomicAdd(&lds[mag - 1], 1u); });
+    }
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * buckets;
+    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) row[b] = lds[b];
+}
+
+// per bucket: hist[chunk][b] -> exclusive prefix over chunks; total[b]
+__global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int buckets, uint32_t* __restrict__ total) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= buckets) return;
+    uint32_t run = 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        uint32_t v = hist[(size_t)ch * buckets + b];
+        hist[(size_t)ch * buckets + b] = run;
+        run += v;
+    }
+    total[b] = run;
+}
+
+// exclusive scan of total[0..buckets) -> start[0..buckets]; one workgroup
+__global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ total, uint32_t* __restrict__ start, int buckets) {
     __shared__ uint32_t part[1024];
-    const uint32_t* cnt = counts + (size_t)blockIdx.x * (buckets + 1);
-    uint32_t* off = offsets + (size_t)blockIdx.x * (buckets + 1);
-    uint32_t* cur = cursor + (size_t)blockIdx.x * (buckets + 1);
-    int total = buckets + 1;
-    int per = (total + 1023) / 1024;
-    int lo = threadIdx.x * per, hi = min(lo + per, total);
+    int per = (buckets + 1023) / 1024;
+    int lo = threadIdx.x * per, hi = min(lo + per, buckets);
     uint32_t s = 0;
-    for (int b = lo; b < hi; ++b) s += cnt[b];
+    for (int b = lo; b < hi; ++b) s += total[b];
     part[threadIdx.x] = s;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
     for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        uint32_t v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
         __syncthreads();
         part[threadIdx.x] += v;
         __syncthreads();
     }
     uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (int b = lo; b < hi; ++b) {
-        off[b] = run;
-        cur[b] = run;
-        run += cnt[b];
+        start[b] = run;
+        run += total[b];
+    }
+    if (threadIdx.x == 1023) start[buckets] = part[1023];
+}
+
+// sorted[pos] = ((w*n + i) << 1) | neg, grouped by bucket
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
+                                                              int first, int step, const uint32_t* __restrict__ prefix,
+                                                              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int buckets = 1 << (c - 1);
+    const uint32_t* row = prefix + (size_t)blockIdx.x * buckets;
+    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = start[b] + row[b];
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
+    for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        Fr k = scalars[i];
+        for_each_digit(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
+            uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
+            sorted[pos] = ((uint32_t)((size_t)w * stride + i) << 1) | neg;
+        });
     }
 }
 
-__global__ void k_msm_scatter(const uint32_t* __restrict__ digits, size_t n, int owned, int buckets,
-                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int wl = 0; wl < owned; ++wl) {
-        uint32_t code = digits[(size_t)wl * n + i];
-        uint32_t mag = code >> 1;
-        if (mag) {
-            uint32_t pos = atomicAdd(&cursor[(size_t)wl * (buckets + 1) + mag], 1u);
-            sorted[(size_t)wl * n + pos] = ((uint32_t)i << 1) | (code & 1);
-        }
-    }
-}
-
-// ---- bucket accumulation -----------------------------------------------------------------
+// ---- bucket accumulation: `lanes` lanes per bucket ---------------------------------------------
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_accumulate(const Aff<F>* __restrict__ points, size_t n, const uint32_t* __restrict__ sorted,
-                                 const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                 int buckets, int owned, Jac<F>* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
+                                                       const uint32_t* __restrict__ start, int buckets, int log_lanes, Jac<F>* __restrict__ partial) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (size_t)owned * buckets) return;
-    int wl = (int)(tid / buckets), b = (int)(tid % buckets) + 1;
-    size_t ci = (size_t)wl * (buckets + 1) + b;
-    uint32_t start = offsets[ci], cnt = counts[ci];
-    const uint32_t* list = sorted + (size_t)wl * n + start;
+    if (tid >= ((size_t)buckets << log_lanes)) return;
+    int b = (int)(tid >> log_lanes), t = (int)(tid & ((1u << log_lanes) - 1));
+    uint32_t lo = start[b], hi = start[b + 1];
     Jac<F> acc = Jac<F>::infinity();
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t e = list[k];
-        Aff<F> p = points[e >> 1];
+    for (uint32_t k = lo + t; k < hi; k += 1u << log_lanes) {
+        uint32_t e = sorted[k];
+        Aff<F> p = table[e >> 1];
         if (e & 1) p.y = -p.y;
         acc = jac_madd(acc, p);
     }
-    out[tid] = acc;
+    partial[tid] = acc;
 }
 
-// ---- per-window reduction sum_b b * bucket[b] ---------------------------------------------
+// S_b = sum_t partial[b][t]
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restrict__ bkt, int buckets, int segs, int owned, Jac<F>* __restrict__ partials) {
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (size_t)owned * segs) return;
-    int wl = (int)(tid / segs), t = (int)(tid % segs);
+__global__ __launch_bounds__(64) void k_msm_merge(const Jac<F>* __restrict__ partial, int buckets, int log_lanes, Jac<F>* __restrict__ bucket_sums) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= buckets) return;
+    const Jac<F>* src = partial + ((size_t)b << log_lanes);
+    Jac<F> acc = src[0];
+    for (int t = 1; t < (1 << log_lanes); ++t) acc = jac_add_ni(acc, src[t]);
+    bucket_sums[b] = acc;
+}
+
+// segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} b * S_b
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restrict__ bkt, int buckets, int segs, Jac<F>* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= segs) return;
     int lo = t * MSM_SEG + 1, hi = min(buckets, lo + MSM_SEG - 1);
-    const Jac<F>* wb = bkt + (size_t)wl * buckets - 1;  // wb[b], b in 1..buckets
+    const Jac<F>* wb = bkt - 1;  // wb[b], b in 1..buckets
     Jac<F> running = Jac<F>::infinity(), acc = Jac<F>::infinity();
     for (int b = hi; b >= lo; --b) {
         running = jac_add_ni(running, wb[b]);
         acc = jac_add_ni(acc, running);
     }
     if (lo > 1) acc = jac_add_ni(acc, jac_mul_small(running, (uint32_t)(lo - 1)));
-    partials[tid] = acc;
+    out[t] = acc;
 }
 
-// sums `count` points per group into one (one workgroup of 256 lanes per group)
+// sums `count` points into one (one workgroup of 256 lanes)
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
-    const Jac<F>* src = in + (size_t)blockIdx.x * count;
     Jac<F> acc = Jac<F>::infinity();
-    for (int k = threadIdx.x; k < count; k += 256) acc = jac_add_ni(acc, src[k]);
+    for (int k = threadIdx.x; k < count; k += 256) acc = jac_add_ni(acc, in[k]);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) sh[threadIdx.x] = jac_add_ni(sh[threadIdx.x], sh[threadIdx.x + d]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
-}
-
-// result = sum_k 2^(c * (first + k*step)) * S_k  (one lane; latency-bound tail)
-template <class F>
-__global__ void k_msm_horner(const Jac<F>* __restrict__ sums, int c, int windows, int first, int step, int owned, Jac<F>* __restrict__ out) {
-    if (threadIdx.x || blockIdx.x) return;
-    Jac<F> acc = Jac<F>::infinity();
-    int wl = owned - 1;
-    for (int w = windows - 1; w >= 0; --w) {
-        for (int k = 0; k < c; ++k) acc = jac_dbl_ni(acc);
-        if (wl >= 0 && w == first + wl * step) {
-            acc = jac_add_ni(acc, sums[wl]);
-            --wl;
-        }
-    }
-    out[0] = acc;
+    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 template <class F>
-void msm_run(zk_ctx* ctx, const Aff<F>* d_points, const Fr* d_scalars, size_t n, const MsmPlan& plan, Jac<F>* d_out, const char* tag) {
-    ZK_REQUIRE(plan.c >= 2 && plan.c <= 20, ZK_ERR_ARG, "msm: window_bits must be in [2, 20]");
-    ZK_REQUIRE(n < ((size_t)1 << 31), ZK_ERR_SIZE, "msm: too many points");
-    if (!ctx->msm_ws) ctx->msm_ws = std::make_shared<MsmWorkspace>();
-    MsmWorkspace& ws = *ctx->msm_ws;
-    const int c = plan.c, windows = plan.windows, buckets = 1 << (c - 1);
+void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
+             int rank, int world, Jac<F>* d_out) {
+    const bool g2 = sizeof(F) > sizeof(Fq);
+    const int c = tab.c, windows = tab.windows, buckets = 1 << (c - 1);
+    const size_t n = tab.n;
+    ZK_REQUIRE(n_used <= n, ZK_ERR_ARG, "msm: more scalars than table points");
     int owned = 0;
-    for (int w = plan.first_window; w < windows; w += plan.window_step) ++owned;
-    hipStream_t st = ctx->stream;
-    if (n == 0 || owned == 0) {
-        Jac<F> inf = Jac<F>::infinity();
+    for (int w = rank; w < windows; w += world) ++owned;
+    if (n_used == 0 || owned == 0) {
+        static const Jac<F> inf = Jac<F>::infinity();
         ZK_HIP(hipMemcpyAsync(d_out, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
-        ZK_HIP(hipStreamSynchronize(st));
         return;
     }
-    size_t cnt_words = (size_t)owned * (buckets + 1);
-    ws.digits.ensure((size_t)owned * n);
-    ws.sorted.ensure((size_t)owned * n);
-    ws.counts.ensure(cnt_words);
-    ws.offsets.ensure(cnt_words);
-    ws.cursor.ensure(cnt_words);
-    int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
-    ws.buckets.ensure((size_t)owned * buckets * sizeof(Jac<F>));
-    ws.partials.ensure((size_t)owned * segs * sizeof(Jac<F>));
-    ws.window_sums.ensure((size_t)owned * sizeof(Jac<F>));
-    Jac<F>* d_buckets = reinterpret_cast<Jac<F>*>(ws.buckets.p);
-    Jac<F>* d_partials = reinterpret_cast<Jac<F>*>(ws.partials.p);
-    Jac<F>* d_wsums = reinterpret_cast<Jac<F>*>(ws.window_sums.p);
-    const bool g2 = sizeof(F) > sizeof(Fq);
+    // chunking of the scalar array for the LDS counting sort
+    int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
+    if (chunks < 1) chunks = 1;
+    size_t chunk_len = (n_used + chunks - 1) / chunks;
+    chunks = (int)((n_used + chunk_len - 1) / chunk_len);
+    // lanes per bucket: aim at ~32 entries per lane
+    size_t entries = (size_t)owned * n_used;
+    int log_lanes = 0;
+    while (log_lanes < 6 && (entries >> (log_lanes + 1)) / buckets >= 24) ++log_lanes;
+    const int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
+
+    ws.hist.ensure((size_t)chunks * buckets);
+    ws.total.ensure(buckets);
+    ws.start.ensure(buckets + 1);
+    ws.sorted.ensure(entries);
+    ws.partial.ensure(((size_t)buckets << log_lanes) * sizeof(Jac<F>));
+    ws.bucket_sums.ensure((size_t)buckets * sizeof(Jac<F>));
+    ws.seg_sums.ensure((size_t)segs * sizeof(Jac<F>));
+    Jac<F>* d_partial = reinterpret_cast<Jac<F>*>(ws.partial.p);
+    Jac<F>* d_bsum = reinterpret_cast<Jac<F>*>(ws.bucket_sums.p);
+    Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
+    const size_t lds_bytes = (size_t)buckets * 4;
     const double pt_bytes = (double)sizeof(Aff<F>);
 
-    ZK_HIP(hipMemsetAsync(ws.counts.p, 0, cnt_words * sizeof(uint32_t), st));
     {
-        ProfScope ps(ctx, "msm_digits", 32.0 * n + 4.0 * owned * n);
-        hipLaunchKernelGGL(k_msm_digits, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, n, c, windows, plan.first_window,
-                           plan.window_step, ws.digits.p, ws.counts.p, buckets);
+        ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * buckets, st);
+        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
     }
     {
-        ProfScope ps(ctx, "msm_scan", 12.0 * cnt_words);
-        hipLaunchKernelGGL(k_msm_scan, dim3(owned), dim3(1024), 0, st, ws.counts.p, ws.offsets.p, ws.cursor.p, buckets);
+        ProfScope ps(ctx, "msm_offsets", 8.0 * chunks * buckets, st);
+        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(buckets, 256)), dim3(256), 0, st, ws.hist.p, chunks, buckets, ws.total.p);
+        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.start.p, buckets);
     }
     {
-        ProfScope ps(ctx, "msm_scatter", 8.0 * owned * n);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws.digits.p, n, owned, buckets, ws.cursor.p, ws.sorted.p);
+        ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 4.0 * entries + 4.0 * chunks * buckets, st);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+                           ws.hist.p, ws.start.p, ws.sorted.p);
     }
     {
-        // algorithmic bytes: every (window, point) pair reads its index and the affine point once,
-        // every bucket is written once
-        ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * owned * n + (double)sizeof(Jac<F>) * owned * buckets);
-        size_t threads = (size_t)owned * buckets;
-        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(threads, 64)), dim3(64), 0, st, d_points, n, ws.sorted.p, ws.offsets.p,
-                           ws.counts.p, buckets, owned, d_buckets);
+        // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
+        // every lane writes one Jacobian partial
+        size_t threads = (size_t)buckets << log_lanes;
+        ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(Jac<F>) * threads, st);
+        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(threads, 64)), dim3(64), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, log_lanes, d_partial);
     }
     {
-        ProfScope ps(ctx, g2 ? "msm_bucket_reduce_g2" : "msm_bucket_reduce_g1", (double)sizeof(Jac<F>) * owned * (buckets + segs));
-        size_t threads = (size_t)owned * segs;
-        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(threads, 64)), dim3(64), 0, st, d_buckets, buckets, segs, owned, d_partials);
-    }
-    {
-        ProfScope ps(ctx, g2 ? "msm_sum_points_g2" : "msm_sum_points_g1", (double)sizeof(Jac<F>) * owned * segs);
-        hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(owned), dim3(256), 256 * sizeof(Jac<F>), st, d_partials, segs, d_wsums);
-    }
-    {
-        ProfScope ps(ctx, g2 ? "msm_horner_g2" : "msm_horner_g1", (double)sizeof(Jac<F>) * (owned + 1));
-        hipLaunchKernelGGL(k_msm_horner<F>, dim3(1), dim3(64), 0, st, d_wsums, c, windows, plan.first_window, plan.window_step, owned, d_out);
+        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(Jac<F>) * (((size_t)buckets << log_lanes) + 2.0 * buckets + 2.0 * segs), st);
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, d_partial, buckets, log_lanes, d_bsum);
+        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
+        hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
     }
     ZK_HIP(hipGetLastError());
-    (void)tag;
 }
-template void msm_run<Fq>(zk_ctx*, const G1A*, const Fr*, size_t, const MsmPlan&, G1J*, const char*);
-template void msm_run<Fq2>(zk_ctx*, const G2A*, const Fr*, size_t, const MsmPlan&, G2J*, const char*);
+template void msm_run<Fq>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<Fq>&, const Fr*, size_t, int, int, G1J*);
+template void msm_run<Fq2>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<Fq2>&, const Fr*, size_t, int, int, G2J*);
+
+void msm_set_lds_attributes() {
+    static bool done = false;
+    if (done) return;
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (MSM_MAX_C - 1)));
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (MSM_MAX_C - 1)));
+    done = true;
+}
 
 template <class F>
 __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) {
@@ -261,11 +312,13 @@ __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) 
     if (i < n) out[i] = pt_to_canonical(jac_to_affine(in[i]));
 }
 
+// zk_msm_g1 / zk_msm_g2: arbitrary (non-CRS) points, so the window table is built on the fly
 template <class F>
 void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine) {
     ZK_REQUIRE(out_affine && (n == 0 || (points && scalars)), ZK_ERR_ARG, "zk_msm: null pointer");
+    msm_set_lds_attributes();
     DevBuf<Aff<F>> dp(n), daff(1);
-    DevBuf<Fr> ds(n);
+    DevBuf<Fr> ds(n), tmp(n);
     DevBuf<Jac<F>> dres(1);
     DevBuf<int> flag(1);
     hipStream_t st = ctx->stream;
@@ -274,16 +327,13 @@ void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
         ZK_HIP(hipMemcpyAsync(dp.p, points, n * sizeof(Aff<F>), hipMemcpyHostToDevice, st));
         ZK_HIP(hipMemcpyAsync(ds.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
         pts_to_mont<Aff<F>>(ctx, dp.p, dp.p, n, flag.p);
-        // scalars stay canonical; range check by a Montgomery round trip into scratch is not needed:
-        // digits are extracted from the integer value, and values >= r are rejected here
-        DevBuf<Fr> tmp(n);
-        fr_to_mont(ctx, ds.p, tmp.p, n, flag.p);
-        ZK_HIP(hipStreamSynchronize(st));
+        fr_to_mont(ctx, ds.p, tmp.p, n, flag.p);   // range check of the scalars (digits use the canonical integers)
     }
-    MsmPlan plan;
-    plan.c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(n));
-    plan.windows = 254 / plan.c + 1;
-    msm_run<F>(ctx, dp.p, ds.p, n, plan, dres.p, "msm_host");
+    int c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(n));
+    MsmTable<F> tab;
+    msm_build_table<F>(ctx, dp.p, n, c, tab);
+    if (!ctx->msm_ws[0]) ctx->msm_ws[0] = std::make_shared<MsmWorkspace>();
+    msm_run<F>(ctx, *ctx->msm_ws[0], st, tab, ds.p, n, 0, 1, dres.p);
     hipLaunchKernelGGL(k_jac_to_affine_canonical<F>, dim3(1), dim3(64), 0, st, dres.p, daff.p, 1);
     ZK_HIP(hipGetLastError());
     int hflag = 0;

@@ -43,6 +43,12 @@ struct zk_crs {
     zk::DevBuf<zk::G2A> xi2_br;
     unsigned br_log_n = 0;
     bool has_br = false;
+    // fixed-base window tables T[w][i] = 2^(c w) P_i for the four base sets prove() uses
+    // (built on first use for the order -- natural or bit-reversed -- the QAP kind needs)
+    zk::MsmTable<zk::Fq> t_xi1, t_xi_t1, t_sum_delta1;
+    zk::MsmTable<zk::Fq2> t_xi2;
+    int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed
+    long tables_c = -1;      // the msm_window_bits option the tables were built for
 };
 
 namespace zk {
@@ -57,6 +63,7 @@ void crs_dims(const zk_crs&, size_t* n, size_t* m, size_t* input);
 void crs_download(zk_ctx*, const zk_crs&, const zk_crs_out&);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
+void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n);
 
 void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
 // rank/world select the owned Pippenger windows.  With d_partial_out == nullptr the proof is

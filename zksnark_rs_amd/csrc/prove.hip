@@ -176,11 +176,9 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     }
 
     const Fr *uc_can, *vc_can, *h_can;
-    const G1A *xi1, *xi_t1;
-    const G2A* xi2;
     size_t n_h;   // number of h coefficients paired with xi_t
     if (!q.dense) {
-        crs_ensure_brev(ctx, crs, q.log_n);
+        crs_ensure_tables(ctx, crs, true, q.log_n);
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
@@ -202,10 +200,10 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
         uc_can = q.uc_can.p; vc_can = q.vc_can.p; h_can = q.h_can.p;
-        xi1 = crs.xi1_br.p; xi2 = crs.xi2_br.p; xi_t1 = crs.xi_t1_br.p;
-        n_h = n;   // entry brev(n-1) = n-1 of xi_t1_br is infinity
+        n_h = n;   // entry brev(n-1) = n-1 of the bit-reversed xi_t table is infinity
     } else {
         ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
+        crs_ensure_tables(ctx, crs, false, 0);
         unsigned lc = 1;
         while (((size_t)1 << lc) < 2 * n) ++lc;
         size_t nc = (size_t)1 << lc;
@@ -232,26 +230,27 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
         uc_can = q.uc_can.p; vc_can = q.vc_can.p; h_can = q.h_can.p;
-        xi1 = crs.xi1.p; xi2 = crs.xi2.p; xi_t1 = crs.xi_t1.p;
     }
 
-    MsmPlan plan;
-    auto make_plan = [&](size_t count) {
-        MsmPlan p;
-        p.c = ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(count);
-        p.windows = 254 / p.c + 1;
-        p.first_window = rank;
-        p.window_step = world;
-        return p;
-    };
+    // the five inner products run on their own streams: the latency-bound reduction tail of one
+    // overlaps the accumulation of the others
     DevBuf<MsmResults> d_ms(1);
     MsmResults* ms = d_ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    msm_run<Fq>(ctx, xi1, uc_can, n, make_plan(n), &ms->a, "A");
-    msm_run<Fq>(ctx, xi1, vc_can, n, make_plan(n), &ms->b1, "B1");
-    msm_run<Fq2>(ctx, xi2, vc_can, n, make_plan(n), &ms->b2, "B2");
-    msm_run<Fq>(ctx, xi_t1, h_can, n_h, make_plan(n_h), &ms->h, "H");
-    msm_run<Fq>(ctx, crs.sum_delta1.p, d_weights + l + 1, n_l, make_plan(n_l), &ms->l, "L");
+    ZK_HIP(hipEventRecord(ctx->fork_evt, st));
+    auto launch = [&](int k, auto& table, const Fr* scalars, size_t count, auto* out) {
+        hipStream_t ms_st = ctx->msm_stream[k];
+        if (!ctx->msm_ws[k]) ctx->msm_ws[k] = std::make_shared<MsmWorkspace>();
+        ZK_HIP(hipStreamWaitEvent(ms_st, ctx->fork_evt, 0));
+        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out);
+        ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
+        ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
+    };
+    launch(0, crs.t_xi2, vc_can, n, &ms->b2);                       // B in G2 first: longest tail
+    launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);    // L: sum a_i * sum_delta_i
+    launch(2, crs.t_xi1, uc_can, n, &ms->a);                        // A
+    launch(3, crs.t_xi1, vc_can, n, &ms->b1);                       // B in G1
+    launch(4, crs.t_xi_t1, h_can, n_h, &ms->h);                     // H: sum h_i * xi_t_i
 
     int hflag = 0;
     ZK_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -266,7 +265,6 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     ctx->event_pool.push_back(pre_evt);
     finish(ctx, crs, ms, r, s, d_pre.p, true, proof_out);
     ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "prove: witness element >= r");
-    (void)plan;
 }
 
 void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
