@@ -37,9 +37,13 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         ZK_HIP(hipGetDeviceProperties(&prop, device_ordinal));
         ctx->cu_count = prop.multiProcessorCount;
         ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        // A and B1 (streams 2, 3) and the side stream that consumes them run at high priority so the
+        // dynamic-base multiplications s*A, r*B1 start early and hide behind the other inner products
+        int prio_least = 0, prio_greatest = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_greatest));
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
-            ZK_HIP(hipStreamCreateWithFlags(&ctx->msm_stream[i], hipStreamNonBlocking));
+            ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, (i == 2 || i == 3) ? prio_greatest : prio_least));
             ZK_HIP(hipEventCreateWithFlags(&ctx->msm_done[i], hipEventDisableTiming));
         }
         ZK_HIP(hipEventCreateWithFlags(&ctx->fork_evt, hipEventDisableTiming));

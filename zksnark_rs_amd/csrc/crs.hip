@@ -123,6 +123,40 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
     c.tables_c = ctx->opt_window_bits;
 }
 
+// FT[w][d] = d * 16^w * P, w < 64, d < 16 (one lane per window; built once per CRS)
+template <class F>
+__global__ void k_fixed_table(const Aff<F>* __restrict__ point, Aff<F>* __restrict__ table) {
+    int w = threadIdx.x;
+    if (w >= 64) return;
+    Jac<F> base = Jac<F>::from_affine(*point);
+    for (int k = 0; k < 4 * w; ++k) base = jac_dbl_ni(base);
+    Jac<F> acc = Jac<F>::infinity();
+    for (int d = 0; d < 16; ++d) {
+        table[w * 16 + d] = jac_to_affine(acc);
+        acc = jac_add_ni(acc, base);
+    }
+}
+
+void crs_ensure_fixed_tables(zk_ctx* ctx, zk_crs& c) {
+    if (c.has_ft) return;
+    auto build1 = [&](const DevBuf<G1A>& p, DevBuf<G1A>& t) {
+        t.alloc(1024);
+        hipLaunchKernelGGL(k_fixed_table<Fq>, dim3(1), dim3(64), 0, ctx->stream, p.p, t.p);
+    };
+    auto build2 = [&](const DevBuf<G2A>& p, DevBuf<G2A>& t) {
+        t.alloc(1024);
+        hipLaunchKernelGGL(k_fixed_table<Fq2>, dim3(1), dim3(64), 0, ctx->stream, p.p, t.p);
+    };
+    build1(c.alpha1, c.ft_alpha1);
+    build1(c.beta1, c.ft_beta1);
+    build1(c.delta1, c.ft_delta1);
+    build2(c.beta2, c.ft_beta2);
+    build2(c.delta2, c.ft_delta2);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    c.has_ft = true;
+}
+
 // ---- setup ---------------------------------------------------------------------------------
 struct SetupConsts {
     Fr alpha, beta, gamma, delta, x;

@@ -12,6 +12,14 @@
 #include <stdint.h>
 
 #define ZK_HD __host__ __device__ __forceinline__
+// Keeps the instruction scheduler from interleaving independent field multiplications: each one
+// is ~230 VALU instructions with plenty of internal ILP, and interleaving several only inflates
+// the live register set of the curve formulas (occupancy 1-2 waves/SIMD, spills in G2).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_SCHED_FENCE)
+#define ZK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ZK_SCHED_FENCE() ((void)0)
+#endif
 
 namespace zk {
 
@@ -157,51 +165,71 @@ struct alignas(16) Fp {
 #pragma unroll
             for (int i = 0; i < 9; ++i) a2[i] = a[i] << 1;
         }
-        uint64_t acc = 0;
+        // Independent accumulator chains per column (products of a*b split in two, m*p in a
+        // third): a single running sum makes every v_mad_u64_u32 wait for the previous one, which is
+        // latency-bound at the 2-4 waves/SIMD the curve kernels reach.
+        uint64_t carry = 0;
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
             const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+            uint64_t acc0 = carry, acc1 = 0, acc2 = 0;
             if (SQR) {
 #pragma unroll
                 for (int i = lo; i <= hi; ++i) {
                     const int j = k - i;
-                    if (i < j) acc += (uint64_t)a2[i] * a[j];
-                    else if (i == j) acc += (uint64_t)a[i] * a[i];
+                    if (i < j) { if (i & 1) acc1 += (uint64_t)a2[i] * a[j]; else acc0 += (uint64_t)a2[i] * a[j]; }
+                    else if (i == j) acc1 += (uint64_t)a[i] * a[i];
                 }
             } else {
 #pragma unroll
-                for (int i = lo; i <= hi; ++i) acc += (uint64_t)a[i] * b[k - i];
+                for (int i = lo; i <= hi; ++i) { if (i & 1) acc1 += (uint64_t)a[i] * b[k - i]; else acc0 += (uint64_t)a[i] * b[k - i]; }
             }
 #pragma unroll
             for (int i = lo; i <= hi; ++i)
-                if (i < k || k >= 9) acc += (uint64_t)m[i] * PR::P29[k - i];
+                if (i < k || k >= 9) acc2 += (uint64_t)m[i] * PR::P29[k - i];
+            uint64_t acc = acc0 + acc1 + acc2;
             if (k < 9) {
                 m[k] = ((uint32_t)acc * PR::INV29) & M29;
                 acc += (uint64_t)m[k] * PR::P29[0];
             } else {
                 r[k - 9] = (uint32_t)acc & M29;
             }
-            acc >>= 29;
+            carry = acc >> 29;
         }
+        uint64_t acc = carry;
         r[8] = (uint32_t)acc;
     }
-    ZK_HD Fp operator*(const Fp& b) const {
+    ZK_HD static Fp mul_inline(const Fp& a, const Fp& b) {
         uint32_t x[9], y[9], r[9];
-        to29(l, x);
+        to29(a.l, x);
         to29(b.l, y);
         mont29<false>(x, y, r);
         Fp o;
         from29(r, o.l);
-        return reduce_once(o, 0);
+        o = reduce_once(o, 0);
+        ZK_SCHED_FENCE();
+        return o;
     }
-    ZK_HD Fp sqr() const {
+    ZK_HD static Fp sqr_inline(const Fp& a) {
         uint32_t x[9], r[9];
-        to29(l, x);
+        to29(a.l, x);
         mont29<true>(x, x, r);
         Fp o;
         from29(r, o.l);
-        return reduce_once(o, 0);
+        o = reduce_once(o, 0);
+        ZK_SCHED_FENCE();
+        return o;
     }
+#if defined(ZK_MUL_OUTLINE) && defined(__HIP_DEVICE_COMPILE__)
+    // one out-of-line body per translation unit: keeps the G2 loops inside the instruction cache
+    __device__ __attribute__((noinline)) static Fp mul_outline(Fp a, Fp b) { return mul_inline(a, b); }
+    __device__ __attribute__((noinline)) static Fp sqr_outline(Fp a) { return sqr_inline(a); }
+    ZK_HD Fp operator*(const Fp& b) const { return mul_outline(*this, b); }
+    ZK_HD Fp sqr() const { return sqr_outline(*this); }
+#else
+    ZK_HD Fp operator*(const Fp& b) const { return mul_inline(*this, b); }
+    ZK_HD Fp sqr() const { return sqr_inline(*this); }
+#endif
 
     // canonical integer <-> Montgomery
     ZK_HD static Fp from_canonical(const Fp& x) { return x * r2(); }

@@ -23,10 +23,12 @@
 //             tree reduction -> one point
 // Windows are independent: rank g of a multi-GPU job owns windows w = g (mod world) and needs
 // only those slices of T (MsmPlan::first_window / window_step).
+#pragma once
 #include "kernels.hpp"
 
 namespace zk {
 
+#ifdef ZK_MSM_COMMON
 int msm_auto_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
@@ -35,6 +37,8 @@ int msm_auto_window(size_t n) {
     if (c > MSM_MAX_C) c = MSM_MAX_C;
     return c;
 }
+
+#endif  // ZK_MSM_COMMON
 
 constexpr int MSM_SEG = 8;       // buckets per lane in the running-sum reduction
 constexpr int SORT_THREADS = 1024;
@@ -66,8 +70,7 @@ void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTa
     hipLaunchKernelGGL(k_msm_precompute<F>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, d_points, n, c, t.windows, t.table.p);
     ZK_HIP(hipGetLastError());
 }
-template void msm_build_table<Fq>(zk_ctx*, const G1A*, size_t, int, MsmTable<Fq>&);
-template void msm_build_table<Fq2>(zk_ctx*, const G2A*, size_t, int, MsmTable<Fq2>&);
+template void msm_build_table<ZK_MSM_FIELD>(zk_ctx*, const Aff<ZK_MSM_FIELD>*, size_t, int, MsmTable<ZK_MSM_FIELD>&);
 
 // ---- signed-digit recoding -------------------------------------------------------------------
 // Calls f(w, mag, neg) for every owned window with a non-zero digit.
@@ -96,6 +99,7 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, 
 }
 
 // hist[chunk][b] = number of digits of magnitude b+1 among the chunk's scalars
+#ifdef ZK_MSM_COMMON
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
                                                            int first, int step, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -167,17 +171,30 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
     }
 }
 
+#else
+__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+__global__ void k_msm_chunk_prefix(uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
+__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, const uint32_t*, uint32_t*);
+#endif  // ZK_MSM_COMMON
+
 // ---- bucket accumulation: `lanes` lanes per bucket ---------------------------------------------
+// waves per SIMD the accumulate kernel is compiled for.  G1 fits 3 waves (136 VGPRs).  The G2 body
+// (Jacobian accumulator + affine point over Fq2 = 80 live limbs before any temporary) does not fit
+// 256 registers; forcing 2 waves only adds scratch traffic and measured slower (bench r1).
+template <class F> struct AccWaves { static constexpr int value = 3; };
+template <> struct AccWaves<Fq2> { static constexpr int value = 1; };
+
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
+__global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
                                                        const uint32_t* __restrict__ start, int buckets, int log_lanes, Jac<F>* __restrict__ partial) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= ((size_t)buckets << log_lanes)) return;
     int b = (int)(tid >> log_lanes), t = (int)(tid & ((1u << log_lanes) - 1));
-    uint32_t lo = start[b], hi = start[b + 1];
+    const uint32_t hi = start[b + 1], stride = 1u << log_lanes;
     Jac<F> acc = Jac<F>::infinity();
-    for (uint32_t k = lo + t; k < hi; k += 1u << log_lanes) {
-        uint32_t e = sorted[k];
+    for (uint32_t k = start[b] + t; k < hi; k += stride) {
+        const uint32_t e = sorted[k];
         Aff<F> p = table[e >> 1];
         if (e & 1) p.y = -p.y;
         acc = jac_madd(acc, p);
@@ -295,9 +312,9 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     ZK_HIP(hipGetLastError());
 }
-template void msm_run<Fq>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<Fq>&, const Fr*, size_t, int, int, G1J*);
-template void msm_run<Fq2>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<Fq2>&, const Fr*, size_t, int, int, G2J*);
+template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*);
 
+#ifdef ZK_MSM_COMMON
 void msm_set_lds_attributes() {
     static bool done = false;
     if (done) return;
@@ -305,6 +322,8 @@ void msm_set_lds_attributes() {
     ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (MSM_MAX_C - 1)));
     done = true;
 }
+
+#endif  // ZK_MSM_COMMON
 
 template <class F>
 __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) {
@@ -342,7 +361,6 @@ void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
     ZK_HIP(hipStreamSynchronize(st));
     ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "zk_msm: coordinate or scalar >= modulus");
 }
-template void msm_host<Fq>(zk_ctx*, const uint64_t*, const uint64_t*, size_t, int, uint64_t*);
-template void msm_host<Fq2>(zk_ctx*, const uint64_t*, const uint64_t*, size_t, int, uint64_t*);
+template void msm_host<ZK_MSM_FIELD>(zk_ctx*, const uint64_t*, const uint64_t*, size_t, int, uint64_t*);
 
 }  // namespace zk

@@ -48,6 +48,11 @@ struct zk_crs {
     zk::MsmTable<zk::Fq> t_xi1, t_xi_t1, t_sum_delta1;
     zk::MsmTable<zk::Fq2> t_xi2;
     int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed
+    // 4-bit fixed-base tables FT[w][d] = d * 16^w * P (64 x 16 entries) for the single CRS points
+    // that prove() multiplies by r, s and r*s
+    zk::DevBuf<zk::G1A> ft_alpha1, ft_beta1, ft_delta1;
+    zk::DevBuf<zk::G2A> ft_beta2, ft_delta2;
+    bool has_ft = false;
     long tables_c = -1;      // the msm_window_bits option the tables were built for
 };
 
@@ -64,6 +69,7 @@ void crs_download(zk_ctx*, const zk_crs&, const zk_crs_out&);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
 void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n);
+void crs_ensure_fixed_tables(zk_ctx*, zk_crs&);
 
 void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
 // rank/world select the owned Pippenger windows.  With d_partial_out == nullptr the proof is

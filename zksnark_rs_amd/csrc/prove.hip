@@ -29,21 +29,70 @@ static_assert(sizeof(MsmResults) == 4 * 96 + 192, "partial layout");
 static_assert(sizeof(MsmResults) <= ZK_PARTIAL_BYTES, "ZK_PARTIAL_BYTES too small");
 
 struct AssemblePre {
-    G1J r_delta, s_delta, rs_delta;   // r*delta1, s*delta1, (r*s)*delta1
-    G2J s_delta2;                     // s*delta2
+    G1J r_delta;      // r * delta1
+    G1J fixed_c;      // s * alpha1 + r * beta1 + (r s) * delta1
+    G2J s_delta2;     // s * delta2
+};
+struct AssembleDyn {
+    G1J s_a, r_b1;    // s * A_msm, r * B1_msm
 };
 
-// independent of the MSMs: runs on the side stream while they execute
-__global__ __launch_bounds__(256) void k_assemble_pre(const G1A* __restrict__ delta1, const G2A* __restrict__ delta2, Fr r, Fr s, AssemblePre* __restrict__ out) {
-    int wave = threadIdx.x >> 6;
-    if (threadIdx.x & 63) return;
-    if (wave == 0) out->r_delta = jac_mul_words(G1J::from_affine(*delta1), r.l);
-    if (wave == 1) out->s_delta2 = jac_mul_words(G2J::from_affine(*delta2), s.l);
-    if (wave == 2) out->s_delta = jac_mul_words(G1J::from_affine(*delta1), s.l);
-    if (wave == 3) {
-        Fr rs = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
-        out->rs_delta = jac_mul_words(G1J::from_affine(*delta1), rs.l);
+__device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
+
+// k * P from the 4-bit fixed-base table FT[w][d] = d * 16^w * P: lane w contributes FT[w][digit_w];
+// the 64 contributions are summed by a tree over LDS (6 additions deep instead of 254 doublings).
+template <class F>
+__device__ void fixed_base_mul_wave(const Aff<F>* __restrict__ ft, const Fr& k, Jac<F>* sh, int lane, Jac<F>* out) {
+    sh[lane] = Jac<F>::from_affine(ft[lane * 16 + nibble(k, lane)]);
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (lane < d) sh[lane] = jac_add_ni(sh[lane], sh[lane + d]);
+        __syncthreads();
     }
+    if (lane == 0) *out = sh[0];
+}
+
+// Everything that depends only on (r, s) and single CRS points; runs on the side stream while the
+// five inner products execute.  One wave per fixed-base multiplication.
+__global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
+                                                      const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
+                                                      Fr r, Fr s, AssemblePre* __restrict__ out) {
+    __shared__ G1J sh1[4][64];
+    __shared__ G2J sh2[64];
+    __shared__ G1J res[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Fr rs = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
+    // every wave reaches the same number of __syncthreads (7) inside fixed_base_mul_wave
+    if (wave == 0) fixed_base_mul_wave<Fq>(ft_delta1, r, sh1[0], lane, &res[0]);          // r delta
+    else if (wave == 1) fixed_base_mul_wave<Fq>(ft_alpha1, s, sh1[1], lane, &res[1]);     // s alpha
+    else if (wave == 2) fixed_base_mul_wave<Fq>(ft_beta1, r, sh1[2], lane, &res[2]);      // r beta
+    else if (wave == 3) fixed_base_mul_wave<Fq>(ft_delta1, rs, sh1[3], lane, &res[3]);    // rs delta
+    else fixed_base_mul_wave<Fq2>(ft_delta2, s, sh2, lane, &out->s_delta2);               // s delta2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->r_delta = res[0];
+        out->fixed_c = jac_add_ni(jac_add_ni(res[1], res[2]), res[3]);
+    }
+}
+
+// 4-bit windowed k * P for a point only known at run time (one lane)
+__device__ G1J dyn_mul_g1(const G1J& p, const Fr& k) {
+    G1J tab[16];
+    tab[0] = G1J::infinity();
+    tab[1] = p;
+    for (int d = 2; d < 16; ++d) tab[d] = jac_add_ni(tab[d - 1], p);
+    G1J acc = G1J::infinity();
+    for (int w = 63; w >= 0; --w) {
+        for (int k4 = 0; k4 < 4; ++k4) acc = jac_dbl_ni(acc);
+        acc = jac_add_ni(acc, tab[nibble(k, w)]);
+    }
+    return acc;
+}
+// s * A_msm and r * B1_msm: launched as soon as those two inner products are done, hidden behind
+// the remaining ones
+__global__ __launch_bounds__(128) void k_assemble_dyn(const MsmResults* __restrict__ ms, Fr r, Fr s, AssembleDyn* __restrict__ out) {
+    if (threadIdx.x == 0) out->s_a = dyn_mul_g1(ms->a, s);
+    if (threadIdx.x == 64) out->r_b1 = dyn_mul_g1(ms->b1, r);
 }
 
 __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
@@ -76,32 +125,16 @@ __device__ void encode_g2(const G2J& p, uint8_t* out) {
     put_be32(a.y.c0, out + 97);
 }
 
-// a = A + alpha + r delta ; b = B2 + beta2 + s delta2 ;
-// c = H + L + s a + r (beta + B1 + s delta) - (r s) delta            (mod.rs:274-293)
-__global__ __launch_bounds__(256) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
-                                                  const G1A* __restrict__ alpha1, const G1A* __restrict__ beta1, const G2A* __restrict__ beta2,
-                                                  Fr r, Fr s, uint8_t* __restrict__ proof) {
-    __shared__ G1J sa, rb;
-    int wave = threadIdx.x >> 6;
-    bool lead = (threadIdx.x & 63) == 0;
-    if (lead && wave == 0) {
-        G1J a = jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta);
-        encode_g1(a, proof);
-        sa = jac_mul_words(a, s.l);
-    }
-    if (lead && wave == 1) {
-        G1J t = jac_add_ni(jac_madd_ni(ms->b1, *beta1), pre->s_delta);
-        rb = jac_mul_words(t, r.l);
-    }
-    if (lead && wave == 2) {
-        G2J b = jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2);
-        encode_g2(b, proof + 65);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        G1J c = jac_add_ni(jac_add_ni(jac_add_ni(ms->h, ms->l), jac_add_ni(sa, rb)), pre->rs_delta.neg());
-        encode_g1(c, proof + 65 + 129);
-    }
+// (mod.rs:274-293)  a = A + alpha + r delta ;  b = B2 + beta2 + s delta2 ;
+// c = H + L + s a + r (beta + B1 + s delta) - (r s) delta
+//   = H + L + s A + r B1 + [s alpha + r beta + (r s) delta]
+__global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const AssembleDyn* __restrict__ dyn,
+                                                  const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x & 63) return;
+    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
+    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(jac_add_ni(ms->h, ms->l), jac_add_ni(dyn->s_a, dyn->r_b1)), pre->fixed_c), proof + 65 + 129);
 }
 
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
@@ -129,22 +162,29 @@ static Fr fr_from_words64(const uint64_t w[4]) {
     return x;
 }
 
-static void finish(zk_ctx* ctx, const zk_crs& crs, const MsmResults* d_ms, const uint64_t r[4], const uint64_t s[4],
-                   AssemblePre* d_pre, bool pre_done, uint8_t* proof_out) {
-    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
-    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+struct AssembleScratch {
+    AssemblePre pre;
+    AssembleDyn dyn;
+};
+
+static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
+    hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
+    ZK_HIP(hipGetLastError());
+}
+static void launch_dyn(zk_ctx* ctx, hipStream_t st, const MsmResults* d_ms, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
+    ProfScope ps(ctx, "assemble_dyn", 0, st);
+    hipLaunchKernelGGL(k_assemble_dyn, dim3(1), dim3(128), 0, st, d_ms, rc, sc, &d_as->dyn);
+    ZK_HIP(hipGetLastError());
+}
+// final additions + affine normalisation + canonical encoding, then copy the 259 bytes out
+static void finish(zk_ctx* ctx, const zk_crs& crs, const MsmResults* d_ms, AssembleScratch* d_as, uint8_t* d_proof, uint8_t* proof_out) {
     hipStream_t st = ctx->stream;
-    if (!pre_done) {
-        ProfScope ps(ctx, "assemble_pre", 0);
-        hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(256), 0, st, crs.delta1.p, crs.delta2.p, rc, sc, d_pre);
-    }
-    DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
     {
         ProfScope ps(ctx, "assemble", 0);
-        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(256), 0, st, d_ms, d_pre, crs.alpha1.p, crs.beta1.p, crs.beta2.p, rc, sc, d_proof.p);
+        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms, &d_as->pre, &d_as->dyn, crs.alpha1.p, crs.beta2.p, d_proof);
     }
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(proof_out, d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(proof_out, d_proof, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
 }
 
@@ -163,15 +203,18 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     q.a_mont.ensure(std::max<size_t>(a_len, 1));
     fr_to_mont(ctx, d_weights, q.a_mont.p, a_len, flag.p);
 
-    // the r/s-only scalar multiplications overlap with everything below on the side stream
-    DevBuf<AssemblePre> d_pre(1);
+    // the r/s-only fixed-base multiplications overlap with everything below on the side stream
+    DevBuf<AssembleScratch> d_as(1);
+    DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
+    Fr rc = Fr::zero(), sc = Fr::zero();
     hipEvent_t pre_evt = nullptr;
     if (!d_partial_out) {
-        Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
+        rc = fr_from_words64(r);
+        sc = fr_from_words64(s);
         ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+        crs_ensure_fixed_tables(ctx, crs);
         pre_evt = ctx->get_event();
-        hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(256), 0, ctx->side, crs.delta1.p, crs.delta2.p, rc, sc, d_pre.p);
-        ZK_HIP(hipGetLastError());
+        launch_pre(ctx, crs, ctx->side, rc, sc, d_as.p);
         ZK_HIP(hipEventRecord(pre_evt, ctx->side));
     }
 
@@ -246,10 +289,18 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
         ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
     };
-    launch(0, crs.t_xi2, vc_can, n, &ms->b2);                       // B in G2 first: longest tail
-    launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);    // L: sum a_i * sum_delta_i
     launch(2, crs.t_xi1, uc_can, n, &ms->a);                        // A
     launch(3, crs.t_xi1, vc_can, n, &ms->b1);                       // B in G1
+    if (!d_partial_out) {
+        // s*A and r*B1 need only these two results: start them now (side stream), behind the
+        // remaining three inner products
+        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[2], 0));
+        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[3], 0));
+        launch_dyn(ctx, ctx->side, ms, rc, sc, d_as.p);
+        ZK_HIP(hipEventRecord(pre_evt, ctx->side));
+    }
+    launch(0, crs.t_xi2, vc_can, n, &ms->b2);                       // B in G2 (longest reduction tail)
+    launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);    // L: sum a_i * sum_delta_i
     launch(4, crs.t_xi_t1, h_can, n_h, &ms->h);                     // H: sum h_i * xi_t_i
 
     int hflag = 0;
@@ -263,7 +314,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     }
     ZK_HIP(hipStreamWaitEvent(st, pre_evt, 0));
     ctx->event_pool.push_back(pre_evt);
-    finish(ctx, crs, ms, r, s, d_pre.p, true, proof_out);
+    finish(ctx, crs, ms, d_as.p, d_proof.p, proof_out);
     ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "prove: witness element >= r");
 }
 
@@ -273,12 +324,19 @@ void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_
     prove_dev(ctx, crs, qap, dw.p, m, r, s, proof_out, 0, 1, nullptr);
 }
 
-void prove_combine(zk_ctx* ctx, const zk_crs& crs, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
+void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
+    zk_crs& crs = const_cast<zk_crs&>(crs_c);
+    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
+    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+    crs_ensure_fixed_tables(ctx, crs);
     DevBuf<MsmResults> d_ms(1);
-    DevBuf<AssemblePre> d_pre(1);
+    DevBuf<AssembleScratch> d_as(1);
+    DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
+    launch_pre(ctx, crs, ctx->stream, rc, sc, d_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, ctx->stream, (const uint8_t*)d_partials, world, d_ms.p);
     ZK_HIP(hipGetLastError());
-    finish(ctx, crs, d_ms.p, r, s, d_pre.p, false, proof_out);
+    launch_dyn(ctx, ctx->stream, d_ms.p, rc, sc, d_as.p);
+    finish(ctx, crs, d_ms.p, d_as.p, d_proof.p, proof_out);
 }
 
 }  // namespace zk
