@@ -1,0 +1,106 @@
+"""-m "not gpu": the N > 1 path (partial sums -> all-gather of byte blobs -> combine) exercised
+with world_size 2 over the gloo backend on CPU.  The per-rank compute is a stand-in built on the
+CPU oracle (each rank sums the terms i = rank mod world of the five inner products); what is under
+test is the protocol in zksnark_rs_amd/distributed.py that bench.py runs over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import pyref
+    from zksnark_rs_amd import PARTIAL_BYTES, SplitMix64
+    from zksnark_rs_amd.distributed import prove_sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # tiny chain circuit, faithful QAP / CRS from the Python twin (same seed on every rank)
+    n = 4
+    rng = SplitMix64(31)
+    roots = [pow(pyref.omega(2), j, pyref.R) for j in range(n)]
+    qap = pyref.qap_from_root_rep(pyref.FR, pyref.chain_root_rep(n, roots))
+    wts = pyref.chain_weights(n, rng.fr(), [rng.fr() for _ in range(n)])
+    td = [rng.fr() for _ in range(5)]
+    r, s = rng.fr(), rng.fr()
+    s1, s2 = pyref.setup_with_trapdoor(qap, td)
+    want = pyref.enc_proof(*pyref.prove_with_rs(qap, s1, s2, wts, r, s))
+    F = pyref.FR
+
+    def wsum(polys):
+        return pyref.poly_sum(F, [pyref.poly_scale(F, p, a) for p, a in zip(polys, wts)])
+    U, V, W = wsum(qap["u"]), wsum(qap["v"]), wsum(qap["w"])
+    h, _ = pyref.poly_divmod(F, pyref.poly_sub(F, pyref.poly_mul(F, U, V), W), qap["t"])
+    l = qap["input"]
+
+    def enc_pt(P, g2=False):
+        if g2:
+            return pyref.enc_g2(P)
+        return pyref.enc_g1(P)
+
+    def dec_g1(b):
+        return None if b[0] == 0 else (int.from_bytes(b[1:33], "big"), int.from_bytes(b[33:65], "big"))
+
+    def dec_g2(b):
+        if b[0] == 0:
+            return None
+        v = [int.from_bytes(b[1 + 32 * k:33 + 32 * k], "big") for k in range(4)]
+        return ((v[1], v[0]), (v[3], v[2]))
+
+    class CpuProver:
+        """blob = enc(A) | enc(B1) | enc(H) | enc(L) | enc(B2), zero padded to PARTIAL_BYTES"""
+        def new_buffer(self, nbytes):
+            return torch.zeros(nbytes, dtype=torch.uint8)
+
+        def partial(self, rank, world, out):
+            sl = lambda v: v[rank::world]
+            a = pyref.msm_g1(sl(s1["xi"]), sl(U)); b1 = pyref.msm_g1(sl(s1["xi"]), sl(V))
+            hh = pyref.msm_g1(sl(s1["xi_t"]), sl(h)); ll = pyref.msm_g1(sl(s1["sum_delta"]), sl(wts[l + 1:]))
+            b2 = pyref.msm_g2(sl(s2["xi"]), sl(V))
+            blob = enc_pt(a) + enc_pt(b1) + enc_pt(hh) + enc_pt(ll) + enc_pt(b2, True)
+            blob += bytes(PARTIAL_BYTES - len(blob))
+            out.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+
+        def combine(self, gathered, world, r, s):
+            raw = bytes(gathered.numpy().tobytes())
+            acc = [None] * 5
+            for g in range(world):
+                b = raw[g * PARTIAL_BYTES:(g + 1) * PARTIAL_BYTES]
+                for k in range(4):
+                    acc[k] = pyref.g1_add(acc[k], dec_g1(b[65 * k:65 * k + 65]))
+                acc[4] = pyref.g2_add(acc[4], dec_g2(b[260:389]))
+            a_g1, b_g1, c_h, c_l, b_g2 = acc
+            a = pyref.g1_add(pyref.g1_add(a_g1, s1["alpha"]), pyref.g1_mul(s1["delta"], r))
+            b = pyref.g2_add(pyref.g2_add(b_g2, s2["beta"]), pyref.g2_mul(s2["delta"], s))
+            c = pyref.g1_add(c_h, c_l)
+            c = pyref.g1_add(c, pyref.g1_mul(a, s))
+            c = pyref.g1_add(c, pyref.g1_mul(pyref.g1_add(pyref.g1_add(s1["beta"], b_g1), pyref.g1_mul(s1["delta"], s)), r))
+            c = pyref.g1_add(c, pyref.g1_neg(pyref.g1_mul(s1["delta"], F.mul(r, s))))
+            return pyref.enc_proof(a, b, c)
+
+    got = prove_sharded(CpuProver(), dist, rank, world, r, s)
+    q.put((rank, got == want))
+    dist.destroy_process_group()
+
+
+def test_sharded_prove_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]

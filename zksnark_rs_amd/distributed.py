@@ -1,0 +1,42 @@
+"""Multi-GPU prove: MSM windows sharded over ranks, one all-gather of 768-byte partial sums.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Every rank holds the CRS
+and the QAP, recomputes the cheap NTT stage, accumulates only the Pippenger windows
+w = rank (mod world) of the five inner products (zk_prove_partial), all-gathers the partial sums
+as raw bytes (RCCL cannot reduce group elements) and finishes locally (zk_prove_combine).
+SURVEY.md 8e.  The same function drives the CPU `gloo` test with a stand-in backend.
+"""
+from . import PARTIAL_BYTES
+
+
+class GpuProver:
+    """partial()/combine() on one device through the C ABI; buffers are torch CUDA tensors."""
+
+    def __init__(self, ctx, crs, qap, d_weights, m):
+        import torch
+        self.torch = torch
+        self.ctx, self.crs, self.qap, self.d_weights, self.m = ctx, crs, qap, d_weights, m
+
+    def new_buffer(self, nbytes):
+        return self.torch.zeros(nbytes, dtype=self.torch.uint8, device="cuda")
+
+    def partial(self, rank, world, out):
+        self.ctx.prove_partial(self.crs, self.qap, self.d_weights.data_ptr(), self.m, rank, world, out.data_ptr())
+
+    def combine(self, gathered, world, r, s):
+        self.torch.cuda.synchronize()
+        return self.ctx.prove_combine(self.crs, gathered.data_ptr(), world, r, s)
+
+
+def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
+    """One proof with the inner products sharded over `world` ranks.  Returns the 259 proof bytes
+    (identical on every rank)."""
+    if buffers is None:
+        buffers = (prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES))
+    part, gathered = buffers
+    prover.partial(rank, world, part)
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, part)
+    else:
+        gathered.copy_(part)
+    return prover.combine(gathered, world, r, s)
