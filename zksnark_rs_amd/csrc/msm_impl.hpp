@@ -183,7 +183,7 @@ __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, 
 // (Jacobian accumulator + affine point over Fq2 = 80 live limbs before any temporary) does not fit
 // 256 registers; forcing 2 waves only adds scratch traffic and measured slower (bench r1).
 template <class F> struct AccWaves { static constexpr int value = 3; };
-template <> struct AccWaves<Fq2> { static constexpr int value = 1; };
+template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
 template <class F>
 __global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const
         const uint32_t e = sorted[k];
         Aff<F> p = table[e >> 1];
         if (e & 1) p.y = -p.y;
-        acc = jac_madd(acc, p);
+        acc = jac_madd_nocall(acc, p);
     }
     partial[tid] = acc;
 }
