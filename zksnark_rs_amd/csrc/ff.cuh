@@ -39,6 +39,9 @@ struct FqParams {
     static constexpr uint32_t R2[8] = {0x659bac10u, 0xe1a2a074u, 0x5406005au, 0x63985586u, 0x2d3e2632u, 0xff54c580u, 0x34ea65a6u, 0x2a11a68cu};
     static constexpr uint32_t P29[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr uint32_t INV29 = 0x04866389u;
+    // k*q for k = -2..2 and 8,4,2,1 in "normal form" (limbs 0..7 in [0, 2^29), signed top limb): lazy29.cuh
+    static constexpr int32_t KP29[5][9] = {{252052850, 502742674, 119191905, 441825886, 351554831, 441024126, 514997629, 55030679, -6342813}, {126026425, 519806793, 59595952, 489348399, 175777415, 488947519, 525934270, 295950795, -3171407}, {0, 0, 0, 0, 0, 0, 0, 0, 0}, {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}, {284818062, 34128237, 417679006, 95045025, 185316080, 95846785, 21873282, 481840232, 6342812}};
+    static constexpr int32_t POSP29[4][9] = {{65530424, 136512950, 60103288, 380180103, 204393408, 383387141, 87493128, 316748192, 25371251}, {32765212, 68256475, 298487100, 190090051, 370632160, 191693570, 43746564, 426809552, 12685625}, {284818062, 34128237, 417679006, 95045025, 185316080, 95846785, 21873282, 481840232, 6342812}, {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}};
 };
 
 template <class PR>

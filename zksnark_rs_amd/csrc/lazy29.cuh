@@ -1,0 +1,238 @@
+// lazy29.cuh -- register-resident field arithmetic for the MSM accumulation loop.
+//
+// The bucket accumulation (k_msm_accumulate) is >85 % of a proof and is bound by VALU
+// instruction count.  Outside that loop field elements are 8 x 32-bit, fully reduced (ff.cuh):
+// every multiply converts to 9 x 29-bit limbs and back (~60 instructions) and every add/sub is a
+// carry chain + conditional correction (~50 instructions).  Inside the loop the accumulator and
+// all temporaries stay in the multiplier's own radix instead:
+//
+//   FpR : 9 signed 32-bit limbs, value = sum v[i] 2^(29 i), a residue mod p (NOT reduced).
+//         "normal form" (N): v[0..7] in [0, 2^29), v[8] small and signed; |value| < 8p.
+//   add / sub are 9 independent v_add/v_sub (no carries, no reduction); a difference of two normal
+//   forms has |limb| < 2^29 and can be multiplied directly; sums / longer combinations are brought
+//   back to normal form with `norm` (carry propagation, 24 light instructions).
+//   mul / sqr are the same product-scanning Montgomery as ff.cuh on SIGNED 64-bit accumulators
+//   (v_mad_i64_i32): inputs with |limb| <= 2^30 on ONE side and < 2^29 on the other keep every
+//   column sum below 2^63; the output is in normal form with value in (-p/4, 1.3 p) whatever
+//   the (bounded) inputs were -- Montgomery reduction with R = 2^261 >> p contracts.
+//
+// The caller (msm_impl.hpp) loads points from the 8 x 32 tables, keeps the Jacobian accumulator in
+// FpR for the whole bucket and stores the fully reduced 8 x 32 form at the end, so the change is
+// invisible outside the kernel.  Bounds are argued at each use in madd_lazy below.
+#pragma once
+#include "ec.cuh"
+
+namespace zk {
+
+template <class PR>
+struct FpR {
+    int32_t v[9];
+    static constexpr int32_t M29 = 0x1fffffff;
+
+    ZK_HD static FpR load(const Fp<PR>& x) {   // canonical residue [0, p) -> normal form
+        uint32_t t[9];
+        Fp<PR>::to29(x.l, t);
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] = (int32_t)t[i];
+        return r;
+    }
+    // limb-wise, no carries: results are NOT in normal form
+    ZK_HD FpR operator+(const FpR& b) const {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] = v[i] + b.v[i];
+        return r;
+    }
+    ZK_HD FpR operator-(const FpR& b) const {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] = v[i] - b.v[i];
+        return r;
+    }
+    ZK_HD FpR neg() const {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.v[i] = -v[i];
+        return r;
+    }
+    // carry propagation -> normal form (value unchanged)
+    ZK_HD FpR norm() const {
+        FpR r;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int32_t t = v[i] + c;
+            r.v[i] = t & M29;
+            c = t >> 29;   // arithmetic
+        }
+        r.v[8] = v[8] + c;
+        return r;
+    }
+    // a*b*2^-261 mod p in normal form.  Requires |a limbs| <= 2^30, |b limbs| < 2^29 (or vice versa).
+    template <bool SQR>
+    ZK_HD static FpR mont(const FpR& a, const FpR& b) {
+        int32_t m[9], a2[9];
+        if (SQR) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a2[i] = a.v[i] * 2;
+        }
+        FpR r;
+        int64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+            int64_t acc0 = carry, acc1 = 0, acc2 = 0;
+            if (SQR) {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) {
+                    const int j = k - i;
+                    if (i < j) { if (i & 1) acc1 += (int64_t)a2[i] * a.v[j]; else acc0 += (int64_t)a2[i] * a.v[j]; }
+                    else if (i == j) acc1 += (int64_t)a.v[i] * a.v[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) { if (i & 1) acc1 += (int64_t)a.v[i] * b.v[k - i]; else acc0 += (int64_t)a.v[i] * b.v[k - i]; }
+            }
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i < k || k >= 9) acc2 += (int64_t)m[i] * (int32_t)PR::P29[k - i];
+            int64_t acc = acc0 + acc1 + acc2;
+            if (k < 9) {
+                m[k] = (int32_t)(((uint32_t)acc * PR::INV29) & (uint32_t)M29);
+                acc += (int64_t)m[k] * (int32_t)PR::P29[0];
+            } else {
+                r.v[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)M29);
+            }
+            carry = acc >> 29;   // arithmetic; exact for k < 9 (low 29 bits are zero)
+        }
+        r.v[8] = (int32_t)carry;
+        ZK_SCHED_FENCE();
+        return r;
+    }
+    ZK_HD FpR operator*(const FpR& b) const { return mont<false>(*this, b); }
+    ZK_HD FpR sqr() const { return mont<true>(*this, *this); }
+
+    // x == 0 (mod p)?  For x in normal form with |value| < 3p, i.e. any Montgomery output or the
+    // double of one: the normal form of an integer is unique, so compare with k*p, k = -2..2.
+    // Limb 0 filters (a false positive needs a 2^-29 coincidence) before the full comparison.
+    ZK_HD bool is_zero_mod_p() const {
+        bool maybe = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) maybe |= v[0] == PR::KP29[k][0];
+        if (!maybe) return false;
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) d |= v[i] ^ PR::KP29[k][i];
+            hit |= d == 0;
+        }
+        return hit;
+    }
+    // fully reduced 8 x 32 form; accepts any value with |value| < 8p and limbs within int32 range
+    ZK_HD Fp<PR> store_exact() const {
+        FpR t;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.v[i] = v[i] + PR::POSP29[0][i];   // + 8p: value in (0, 16p)
+        t = t.norm();
+        // conditional subtraction of 8p, 4p, 2p, p with borrow propagation in radix 2^29
+#pragma unroll
+        for (int sh = 0; sh < 4; ++sh) {
+            int32_t d[9], br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int32_t x = t.v[i] - PR::POSP29[sh][i] + br;
+                d[i] = x & M29;
+                br = x >> 29;
+            }
+            d[8] = t.v[8] - PR::POSP29[sh][8] + br;
+            const bool ge = d[8] >= 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t.v[i] = ge ? d[i] : t.v[i];
+        }
+        uint32_t u[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u[i] = (uint32_t)t.v[i];
+        Fp<PR> o;
+        Fp<PR>::from29(u, o.l);
+        return o;
+    }
+};
+
+// Fq2 = Fq[i]/(i^2+1) over the lazy form; components of stored values are kept in normal form
+template <class PR>
+struct Fp2R {
+    FpR<PR> c0, c1;
+    ZK_HD static Fp2R load(const Fq2& x) { return Fp2R{FpR<PR>::load(x.c0), FpR<PR>::load(x.c1)}; }
+    ZK_HD Fp2R operator+(const Fp2R& o) const { return Fp2R{c0 + o.c0, c1 + o.c1}; }
+    ZK_HD Fp2R operator-(const Fp2R& o) const { return Fp2R{c0 - o.c0, c1 - o.c1}; }
+    ZK_HD Fp2R neg() const { return Fp2R{c0.neg(), c1.neg()}; }
+    ZK_HD Fp2R norm() const { return Fp2R{c0.norm(), c1.norm()}; }
+    // operands: components with |limb| < 2^29 (normal forms or differences of two normal forms)
+    ZK_HD Fp2R operator*(const Fp2R& o) const {
+        FpR<PR> aa = c0 * o.c0, bb = c1 * o.c1;
+        FpR<PR> s = (c0 + c1).norm() * (o.c0 + o.c1);   // one side normalised: (N) x (|limb| < 2^30)
+        return Fp2R{(aa - bb).norm(), (s - aa - bb).norm()};
+    }
+    ZK_HD Fp2R sqr() const {
+        FpR<PR> ab = c0 * c1;
+        FpR<PR> d = (c0 + c1).norm() * (c0 - c1);       // (N) x (|limb| < 2^30)
+        return Fp2R{d, (ab + ab).norm()};
+    }
+    ZK_HD bool is_zero_mod_p() const { return c0.is_zero_mod_p() && c1.is_zero_mod_p(); }
+    ZK_HD Fq2 store_exact() const { return Fq2{c0.store_exact(), c1.store_exact()}; }
+};
+
+template <class F> struct LazyOf;
+template <> struct LazyOf<Fq> { typedef FpR<FqParams> type; };
+template <> struct LazyOf<Fq2> { typedef Fp2R<FqParams> type; };
+
+// Jacobian accumulator in lazy form; `inf` replaces the Z == 0 test
+template <class F>
+struct JacR {
+    typename LazyOf<F>::type X, Y, Z;
+    bool inf;
+};
+
+// acc += (qx, qy), mixed Jacobian + affine addition without the constant factors of madd-2007-bl
+// (the result differs from it by the projective scaling lambda = 2):
+//   Z1Z1 = Z1^2, U2 = x2 Z1Z1, S2 = y2 Z1 Z1Z1, H = U2 - X1, R = S2 - Y1,
+//   HH = H^2, HHH = H HH, W = X1 HH,
+//   X3 = R^2 - HHH - 2W,  Y3 = R (W - X3) - Y1 HHH,  Z3 = Z1 H                     (8M + 3S)
+// Bounds: X1, Y1, Z1, x2, y2 in normal form; every product is in normal form; H, R are
+// differences of two normal forms (|limb| < 2^29) and are multiplied directly, as is W - X3; X3
+// (4 terms) and Y3 (it feeds R = S2 - Y1, which is squared) are normalised.
+// Returns false when the caller must take the slow path (P == Q: doubling).
+template <class F>
+ZK_HD bool madd_lazy(JacR<F>& p, const typename LazyOf<F>::type& qx, const typename LazyOf<F>::type& qy) {
+    typedef typename LazyOf<F>::type L;
+    if (p.inf) {
+        p.X = qx; p.Y = qy; p.inf = false;
+        // Z = 1 in Montgomery form
+        p.Z = L::load(F::one());
+        return true;
+    }
+    L Z1Z1 = p.Z.sqr();
+    L U2 = qx * Z1Z1;
+    L S2 = (qy * p.Z) * Z1Z1;
+    L H = U2 - p.X;
+    L R = S2 - p.Y;
+    L HH = H.sqr();
+    if (HH.is_zero_mod_p()) {               // H == 0 (mod p): same x coordinate
+        if (R.sqr().is_zero_mod_p()) return false;   // same point: doubling, slow path
+        p.inf = true;                        // P + (-P)
+        return true;
+    }
+    L HHH = H * HH;
+    L W = p.X * HH;
+    L X3 = (R.sqr() - HHH - (W + W)).norm();
+    L Y3 = (R * (W - X3) - p.Y * HHH).norm();   // W - X3: difference of two normal forms, multiplied directly
+    p.Z = p.Z * H;
+    p.X = X3;
+    p.Y = Y3;
+    return true;
+}
+
+}  // namespace zk

@@ -25,6 +25,7 @@
 // only those slices of T (MsmPlan::first_window / window_step).
 #pragma once
 #include "kernels.hpp"
+#include "lazy29.cuh"
 
 namespace zk {
 
@@ -192,14 +193,25 @@ __global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const
     if (tid >= ((size_t)buckets << log_lanes)) return;
     int b = (int)(tid >> log_lanes), t = (int)(tid & ((1u << log_lanes) - 1));
     const uint32_t hi = start[b + 1], stride = 1u << log_lanes;
-    Jac<F> acc = Jac<F>::infinity();
+    typedef typename LazyOf<F>::type L;
+    // accumulator and temporaries live in the multiplier's radix (lazy29.cuh) for the whole bucket
+    JacR<F> acc;
+    acc.inf = true;
+    acc.X = acc.Y = acc.Z = L::load(F::zero());
     for (uint32_t k = start[b] + t; k < hi; k += stride) {
         const uint32_t e = sorted[k];
-        Aff<F> p = table[e >> 1];
-        if (e & 1) p.y = -p.y;
-        acc = jac_madd_nocall(acc, p);
+        const Aff<F> p = table[e >> 1];
+        if (p.is_inf()) continue;
+        L qx = L::load(p.x), qy = L::load(p.y);
+        if (e & 1) qy = qy.neg();
+        if (!madd_lazy<F>(acc, qx, qy)) {
+            // same point twice in one bucket: doubling through the generic formulas (rare)
+            Jac<F> j = jac_dbl(Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()});
+            acc.X = L::load(j.X); acc.Y = L::load(j.Y); acc.Z = L::load(j.Z);
+            acc.inf = j.is_inf();
+        }
     }
-    partial[tid] = acc;
+    partial[tid] = acc.inf ? Jac<F>::infinity() : Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()};
 }
 
 // S_b = sum_t partial[b][t]
