@@ -218,19 +218,48 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ZK_HIP(hipEventRecord(pre_evt, ctx->side));
     }
 
-    const Fr *uc_can, *vc_can, *h_can;
-    size_t n_h;   // number of h coefficients paired with xi_t
+    // The five inner products run on their own streams; each is forked from the main stream as
+    // soon as its scalars exist (L needs only the witness, A only sum a_i u_i, ...), so the NTT stage
+    // and the latency-bound reduction tails hide behind bucket accumulation.  Joined before assembly.
+    DevBuf<MsmResults> d_ms(1);
+    MsmResults* ms = d_ms.p;
+    const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
+    auto launch = [&](int k, auto& table, const Fr* scalars, size_t count, auto* out) {
+        hipStream_t ms_st = ctx->msm_stream[k];
+        if (!ctx->msm_ws[k]) ctx->msm_ws[k] = std::make_shared<MsmWorkspace>();
+        ZK_HIP(hipEventRecord(ctx->fork_evt, st));
+        ZK_HIP(hipStreamWaitEvent(ms_st, ctx->fork_evt, 0));
+        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out);
+        ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
+    };
+    auto launch_dyn_after_a_b1 = [&]() {
+        if (d_partial_out) return;
+        // s*A and r*B1 need only these two results: start them now (side stream, high priority),
+        // behind the remaining inner products
+        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[2], 0));
+        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[3], 0));
+        launch_dyn(ctx, ctx->side, ms, rc, sc, d_as.p);
+        ZK_HIP(hipEventRecord(pre_evt, ctx->side));
+    };
+
     if (!q.dense) {
         crs_ensure_tables(ctx, crs, true, q.log_n);
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
         q.uc_can.ensure(n); q.vc_can.ensure(n); q.h_can.ensure(n);
+        launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);     // L: sum a_i * sum_delta_i (witness only)
         spmv(ctx, q.u_gate, q.a_mont.p, a_len, q.ue.p);
         spmv(ctx, q.v_gate, q.a_mont.p, a_len, q.ve.p);
         fr_pointwise_mul(ctx, q.ue.p, q.ve.p, q.x0.p, n);                 // U.V on <w>
         ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients (bit-reversed order)
+        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
+        launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);                      // A
         ntt_dif(ctx, q.ve.p, q.log_n, true, true);
+        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
+        launch(3, crs.t_xi1, q.vc_can.p, n, &ms->b1);                     // B in G1
+        launch_dyn_after_a_b1();
+        launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);                     // B in G2
         ZK_HIP(hipMemcpyAsync(q.ug.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ZK_HIP(hipMemcpyAsync(q.vg.p, q.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ntt_dit(ctx, q.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
@@ -240,10 +269,8 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ntt_dif(ctx, q.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
         Fr half = host_fr_from_u64(2).inv();
         h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.h_can.p, n);
-        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
-        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        uc_can = q.uc_can.p; vc_can = q.vc_can.p; h_can = q.h_can.p;
-        n_h = n;   // entry brev(n-1) = n-1 of the bit-reversed xi_t table is infinity
+        // entry brev(n-1) = n-1 of the bit-reversed xi_t table is infinity
+        launch(4, crs.t_xi_t1, q.h_can.p, n, &ms->h);                     // H: sum h_i * xi_t_i
     } else {
         ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
         crs_ensure_tables(ctx, crs, false, 0);
@@ -252,9 +279,16 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         size_t nc = (size_t)1 << lc;
         q.ue.ensure(n); q.ve.ensure(n); q.wc.ensure(n); q.prod_a.ensure(nc); q.prod_b.ensure(nc);
         q.uc_can.ensure(n); q.vc_can.ensure(n); q.h_can.ensure(nc);
+        launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
         dense_matvec(ctx, q.du.p, q.a_mont.p, a_len, n, q.ue.p);
         dense_matvec(ctx, q.dv.p, q.a_mont.p, a_len, n, q.ve.p);
         dense_matvec(ctx, q.dw.p, q.a_mont.p, a_len, n, q.wc.p);
+        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
+        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
+        launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);
+        launch(3, crs.t_xi1, q.vc_can.p, n, &ms->b1);
+        launch_dyn_after_a_b1();
+        launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);
         ZK_HIP(hipMemsetAsync(q.prod_a.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemcpyAsync(q.prod_a.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -268,40 +302,10 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
         if (len_r > d) poly_divide(ctx, q.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, q.prod_b.p);
-        n_h = n - 1;
-        fr_from_mont(ctx, q.prod_b.p, q.h_can.p, n_h);
-        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
-        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        uc_can = q.uc_can.p; vc_can = q.vc_can.p; h_can = q.h_can.p;
+        fr_from_mont(ctx, q.prod_b.p, q.h_can.p, n - 1);
+        launch(4, crs.t_xi_t1, q.h_can.p, n - 1, &ms->h);
     }
-
-    // the five inner products run on their own streams: the latency-bound reduction tail of one
-    // overlaps the accumulation of the others
-    DevBuf<MsmResults> d_ms(1);
-    MsmResults* ms = d_ms.p;
-    const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    ZK_HIP(hipEventRecord(ctx->fork_evt, st));
-    auto launch = [&](int k, auto& table, const Fr* scalars, size_t count, auto* out) {
-        hipStream_t ms_st = ctx->msm_stream[k];
-        if (!ctx->msm_ws[k]) ctx->msm_ws[k] = std::make_shared<MsmWorkspace>();
-        ZK_HIP(hipStreamWaitEvent(ms_st, ctx->fork_evt, 0));
-        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out);
-        ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
-        ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
-    };
-    launch(2, crs.t_xi1, uc_can, n, &ms->a);                        // A
-    launch(3, crs.t_xi1, vc_can, n, &ms->b1);                       // B in G1
-    if (!d_partial_out) {
-        // s*A and r*B1 need only these two results: start them now (side stream), behind the
-        // remaining three inner products
-        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[2], 0));
-        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[3], 0));
-        launch_dyn(ctx, ctx->side, ms, rc, sc, d_as.p);
-        ZK_HIP(hipEventRecord(pre_evt, ctx->side));
-    }
-    launch(0, crs.t_xi2, vc_can, n, &ms->b2);                       // B in G2 (longest reduction tail)
-    launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);    // L: sum a_i * sum_delta_i
-    launch(4, crs.t_xi_t1, h_can, n_h, &ms->h);                     // H: sum h_i * xi_t_i
+    for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
 
     int hflag = 0;
     ZK_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
