@@ -121,6 +121,32 @@ int zk_qap_upload_dense(zk_ctx* ctx, const uint64_t* u, const uint64_t* v, const
                         size_t m, size_t n, size_t input, zk_qap** out);
 void zk_qap_free(zk_qap* qap);
 
+/* Dimensions of a device QAP, and its dense coefficient matrices back on the host (dense form only;
+ * any pointer may be NULL = skip).  Layout as zk_qap_upload_dense. */
+int zk_qap_dims(const zk_qap* qap, size_t* n, size_t* m, size_t* input, int* dense);
+int zk_qap_download_dense(zk_ctx* ctx, const zk_qap* qap, uint64_t* u, uint64_t* v, uint64_t* w, uint64_t* t);
+
+/* ------------------------------------------------------------------------------------------
+ * .zk front end (the input side of the path; host code, as in the reference)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct zk_circuit zk_circuit;   /* DummyRep<FrLocal> (circuit/dummy_rep.rs:6-13) + the parsed program */
+/* ASTParser::try_parse (circuit/mod.rs:224-527; tokenizer/AST: circuit/ast.rs).  On a parse error
+ * returns ZK_ERR_ARG and writes the ParseErr text ("SyntaxErr(line, ..)" / "StructureErr(gate, ..)")
+ * to err.  Wire 0 is the constant 1, then the `verify` variables, then first appearance; gate k
+ * (1-based) sits at root k (circuit/mod.rs:517). */
+int zk_circuit_parse(const char* code, zk_circuit** out, char* err, size_t err_len);
+void zk_circuit_free(zk_circuit* c);
+int zk_circuit_dims(const zk_circuit* c, size_t* m, size_t* n, size_t* input, size_t* n_in);
+/* Root representation rows (RootRepresentation::u/v/w, circuit/mod.rs:201-214): which = 0 u, 1 v, 2 w;
+ * ptr[m+1], gate[nnz] (0-based gate index = root - 1), val[nnz*4].  NULL arrays are skipped. */
+int zk_circuit_rows(const zk_circuit* c, int which, uint64_t* ptr, uint32_t* gate, uint64_t* val, size_t* nnz);
+/* circuit::weights (circuit/mod.rs:529-637): inputs in `in` order -> [1] ++ wire values (m x 4 words) */
+int zk_circuit_weights(const zk_circuit* c, const uint64_t* inputs, size_t n_in, uint64_t* weights_out, size_t m);
+const char* zk_circuit_last_error(const zk_circuit* c);
+/* QAP<CoefficientPoly<FrLocal>>::from(root_rep) (fr.rs:140-173; Lagrange interpolation
+ * coefficient_poly.rs:159-200) on the GPU for the circuit's roots 1..n -> dense device QAP. */
+int zk_circuit_qap(zk_ctx* ctx, const zk_circuit* c, zk_qap** out);
+
 /* ------------------------------------------------------------------------------------------
  * CRS  (SigmaG1 / SigmaG2, groth16/mod.rs:105-121)
  * ---------------------------------------------------------------------------------------- */

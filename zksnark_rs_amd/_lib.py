@@ -61,6 +61,15 @@ SIGNATURES = {
     "zk_qap_upload_sparse": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.POINTER(C.c_void_p)]),
     "zk_qap_upload_dense": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_free": (None, [C.c_void_p]),
+    "zk_qap_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "zk_qap_download_dense": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p]),
+    "zk_circuit_parse": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "zk_circuit_free": (None, [C.c_void_p]),
+    "zk_circuit_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "zk_circuit_rows": (C.c_int, [C.c_void_p, C.c_int, u64p, u32p, u64p, C.POINTER(C.c_size_t)]),
+    "zk_circuit_weights": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]),
+    "zk_circuit_last_error": (C.c_char_p, [C.c_void_p]),
+    "zk_circuit_qap": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_crs_upload": (C.c_int, [C.c_void_p, C.POINTER(CrsDesc), C.POINTER(C.c_void_p)]),
     "zk_setup": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]),
     "zk_crs_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -198,18 +198,30 @@ __global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const
     JacR<F> acc;
     acc.inf = true;
     acc.X = acc.Y = acc.Z = L::load(F::zero());
-    for (uint32_t k = start[b] + t; k < hi; k += stride) {
-        const uint32_t e = sorted[k];
-        const Aff<F> p = table[e >> 1];
-        if (p.is_inf()) continue;
-        L qx = L::load(p.x), qy = L::load(p.y);
-        if (e & 1) qy = qy.neg();
-        if (!madd_lazy<F>(acc, qx, qy)) {
-            // same point twice in one bucket: doubling through the generic formulas (rare)
-            Jac<F> j = jac_dbl(Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()});
-            acc.X = L::load(j.X); acc.Y = L::load(j.Y); acc.Z = L::load(j.Z);
-            acc.inf = j.is_inf();
+    // software pipeline: the next point's gather (a random line of a multi-GiB table) and the
+    // index after it are in flight while the current addition executes
+    uint32_t k = start[b] + t;
+    uint32_t e = k < hi ? sorted[k] : 0;
+    uint32_t e_next = k + stride < hi ? sorted[k + stride] : 0;
+    Aff<F> p = k < hi ? table[e >> 1] : Aff<F>::infinity();
+    while (k < hi) {
+        const uint32_t kn = k + stride;
+        const Aff<F> p_next = kn < hi ? table[e_next >> 1] : Aff<F>::infinity();
+        const uint32_t e_next2 = kn + stride < hi ? sorted[kn + stride] : 0;
+        if (!p.is_inf()) {
+            L qx = L::load(p.x), qy = L::load(p.y);
+            if (e & 1) qy = qy.neg();
+            if (!madd_lazy<F>(acc, qx, qy)) {
+                // same point twice in one bucket: doubling through the generic formulas (rare)
+                Jac<F> j = jac_dbl(Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()});
+                acc.X = L::load(j.X); acc.Y = L::load(j.Y); acc.Z = L::load(j.Z);
+                acc.inf = j.is_inf();
+            }
         }
+        p = p_next;
+        e = e_next;
+        e_next = e_next2;
+        k = kn;
     }
     partial[tid] = acc.inf ? Jac<F>::infinity() : Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()};
 }
