@@ -195,6 +195,18 @@ int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int
                      const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
 
 /* ------------------------------------------------------------------------------------------
+ * verify  (groth16::verify, groth16/mod.rs:299-320) -- host code, as in the reference
+ * ---------------------------------------------------------------------------------------- */
+/* *ok = 1 iff e(alpha,beta) e(sum_i x_i sum_gamma_i, gamma) e(C,delta) == e(A,B) with x = (1, inputs...).
+ * inputs: n_inputs Fr values (the `verify` wires, without the leading 1).  A malformed or off-curve
+ * proof gives *ok = 0. */
+int zk_verify(zk_ctx* ctx, const zk_crs* crs, const uint64_t* inputs, size_t n_inputs, const uint8_t proof[ZK_PROOF_BYTES], int* ok);
+/* EllipticEncryptable::pairing (fr.rs:120-122): the optimal ate pairing e(P, Q) as 12 Fq coefficients
+ * (48 words) in the order c0.a0.c0, c0.a0.c1, c0.a1.c0, ..., c1.a2.c1 of the tower
+ * Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (9+i)).  Host only; needs no context. */
+int zk_pairing(const uint64_t g1[ZK_G1_WORDS], const uint64_t g2[ZK_G2_WORDS], uint64_t out[48]);
+
+/* ------------------------------------------------------------------------------------------
  * Profiling: HIP-event timing of the library's own kernels on the stream they run on.
  * ---------------------------------------------------------------------------------------- */
 int zk_profile_reset(zk_ctx* ctx);

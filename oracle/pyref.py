@@ -428,3 +428,118 @@ def chain_weights(n, x, avals):
             wts[2 * n + 1] = ak
             wts[2] = F.add(prev, ak)
     return wts
+
+
+# ----------------------------------------------------------------------------
+# Optimal ate pairing on BN254 (what bn::pairing computes, fr.rs:120-122) -- big-int twin used to
+# pin the product's host pairing (zk_pairing / zk_verify).  Tower: Fq2 = Fq[i]/(i^2+1),
+# Fq6 = Fq2[v]/(v^3 - xi), xi = 9 + i, Fq12 = Fq6[w]/(w^2 - v).  D-type twist
+# psi(x', y') = (x' w^2, y' w^3).  Affine line functions; final exponentiation by plain
+# square-and-multiply with (q^12 - 1)/r.
+# ----------------------------------------------------------------------------
+BN_U = 4965661367192848881
+ATE_LOOP = 6 * BN_U + 2
+XI = (9, 1)
+FINAL_EXP = (Q ** 12 - 1) // R
+
+def fq2_sqr(a): return fq2_mul(a, a)
+def fq2_mul_xi(a): return ((9 * a[0] - a[1]) % Q, (9 * a[1] + a[0]) % Q)
+def fq2_conj(a): return (a[0], (-a[1]) % Q)
+def fq2_pow(a, e):
+    r_ = (1, 0)
+    while e:
+        if e & 1: r_ = fq2_mul(r_, a)
+        a = fq2_mul(a, a); e >>= 1
+    return r_
+FQ2_ZERO, FQ2_ONE = (0, 0), (1, 0)
+
+def fq6_add(a, b): return tuple(fq2_add(x, y) for x, y in zip(a, b))
+def fq6_sub(a, b): return tuple(fq2_sub(x, y) for x, y in zip(a, b))
+def fq6_neg(a): return tuple(fq2_neg(x) for x in a)
+def fq6_mul(a, b):
+    a0, a1, a2 = a; b0, b1, b2 = b
+    c0 = fq2_add(fq2_mul(a0, b0), fq2_mul_xi(fq2_add(fq2_mul(a1, b2), fq2_mul(a2, b1))))
+    c1 = fq2_add(fq2_add(fq2_mul(a0, b1), fq2_mul(a1, b0)), fq2_mul_xi(fq2_mul(a2, b2)))
+    c2 = fq2_add(fq2_add(fq2_mul(a0, b2), fq2_mul(a1, b1)), fq2_mul(a2, b0))
+    return (c0, c1, c2)
+def fq6_mul_v(a): return (fq2_mul_xi(a[2]), a[0], a[1])
+def fq6_inv(a):
+    a0, a1, a2 = a
+    t0 = fq2_sub(fq2_sqr(a0), fq2_mul_xi(fq2_mul(a1, a2)))
+    t1 = fq2_sub(fq2_mul_xi(fq2_sqr(a2)), fq2_mul(a0, a1))
+    t2 = fq2_sub(fq2_sqr(a1), fq2_mul(a0, a2))
+    d = fq2_add(fq2_mul(a0, t0), fq2_mul_xi(fq2_add(fq2_mul(a2, t1), fq2_mul(a1, t2))))
+    di = fq2_inv(d)
+    return (fq2_mul(t0, di), fq2_mul(t1, di), fq2_mul(t2, di))
+FQ6_ZERO = (FQ2_ZERO, FQ2_ZERO, FQ2_ZERO)
+FQ6_ONE = (FQ2_ONE, FQ2_ZERO, FQ2_ZERO)
+
+def fq12_mul(a, b):
+    a0, a1 = a; b0, b1 = b
+    t0, t1 = fq6_mul(a0, b0), fq6_mul(a1, b1)
+    return (fq6_add(t0, fq6_mul_v(t1)), fq6_add(fq6_mul(a0, b1), fq6_mul(a1, b0)))
+def fq12_inv(a):
+    a0, a1 = a
+    d = fq6_inv(fq6_sub(fq6_mul(a0, a0), fq6_mul_v(fq6_mul(a1, a1))))
+    return (fq6_mul(a0, d), fq6_neg(fq6_mul(a1, d)))
+FQ12_ONE = (FQ6_ONE, FQ6_ZERO)
+def fq12_pow(a, e):
+    r_ = FQ12_ONE
+    for bit in bin(e)[2:]:
+        r_ = fq12_mul(r_, r_)
+        if bit == "1": r_ = fq12_mul(r_, a)
+    return r_
+
+def _line(T, Q2, P):
+    """Line through T and Q2 (tangent when equal) on the twist, evaluated at P in G1, and T + Q2."""
+    (xt, yt), (xq, yq) = T, Q2
+    if T == Q2:
+        lam = fq2_mul(fq2_mul((3, 0), fq2_sqr(xt)), fq2_inv(fq2_add(yt, yt)))
+    else:
+        lam = fq2_mul(fq2_sub(yq, yt), fq2_inv(fq2_sub(xq, xt)))
+    x3 = fq2_sub(fq2_sub(fq2_sqr(lam), xt), xq)
+    y3 = fq2_sub(fq2_mul(lam, fq2_sub(xt, x3)), yt)
+    xp, yp = P
+    # l = yP - lam xP w + (lam xT - yT) w^3 ;  w^3 = v w
+    c0 = ((yp % Q, 0), FQ2_ZERO, FQ2_ZERO)
+    c1 = (fq2_neg(fq2_mul(lam, (xp % Q, 0))), fq2_sub(fq2_mul(lam, xt), yt), FQ2_ZERO)
+    return (c0, c1), (x3, y3)
+
+GAMMA_X = fq2_pow(XI, (Q - 1) // 3)        # Frobenius on the twist: x' -> conj(x') * xi^((q-1)/3)
+GAMMA_Y = fq2_pow(XI, (Q - 1) // 2)        #                         y' -> conj(y') * xi^((q-1)/2)
+def twist_frobenius(Pt):
+    return (fq2_mul(fq2_conj(Pt[0]), GAMMA_X), fq2_mul(fq2_conj(Pt[1]), GAMMA_Y))
+
+def miller_loop(P, Qt):
+    if P is None or Qt is None:
+        return FQ12_ONE
+    f, T = FQ12_ONE, Qt
+    for bit in bin(ATE_LOOP)[3:]:
+        l, T = _line(T, T, P)
+        f = fq12_mul(fq12_mul(f, f), l)
+        if bit == "1":
+            l, T = _line(T, Qt, P)
+            f = fq12_mul(f, l)
+    Q1 = twist_frobenius(Qt)
+    Q2n = g2_neg(twist_frobenius(Q1))
+    l, T = _line(T, Q1, P)
+    f = fq12_mul(f, l)
+    l, T = _line(T, Q2n, P)
+    f = fq12_mul(f, l)
+    return f
+
+def final_exponentiation(f): return fq12_pow(f, FINAL_EXP)
+def pairing(P, Qt): return final_exponentiation(miller_loop(P, Qt))
+
+def verify_bn(s1, s2, inputs, proof):
+    """groth16::verify (mod.rs:299-320): e(alpha,beta) e(sum_term,gamma) e(C,delta) == e(A,B)."""
+    a, b, c = proof
+    sum_term = None
+    for g, x in zip(s1["sum_gamma"], [1] + list(inputs)):
+        sum_term = g1_add(sum_term, g1_mul(g, x))
+    lhs = fq12_mul(fq12_mul(pairing(s1["alpha"], s2["beta"]), pairing(sum_term, s2["gamma"])), pairing(c, s2["delta"]))
+    return lhs == pairing(a, b)
+
+def fq12_flat(f):
+    """12 Fq coefficients in the order c0.a0.c0, c0.a0.c1, c0.a1.c0, ... c1.a2.c1 (the ABI order of zk_pairing)."""
+    return [x for six in f for two in six for x in two]

@@ -1,0 +1,108 @@
+"""groth16::verify and the pairing (host code in the reference and here).
+
+CPU: zk_pairing against the big-int twin (oracle/pyref.py) coefficient for coefficient, plus
+bilinearity / non-degeneracy.  GPU: verify accepts honest proofs made by the GPU prover and rejects
+wrong public inputs -- the reference's own end-to-end tests (lib.rs:156-190, fr.rs:248-416)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import zksnark_rs_amd as zk
+from zksnark_rs_amd import ints_to_limbs, SplitMix64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+ZK_DIR = os.path.join(ROOT, "tests", "golden", "zk")
+
+
+def g1_words(P):
+    return np.zeros(8, np.uint64) if P is None else ints_to_limbs([P[0], P[1]]).reshape(8)
+
+
+def g2_words(P):
+    return np.zeros(16, np.uint64) if P is None else ints_to_limbs([P[0][0], P[0][1], P[1][0], P[1][1]]).reshape(16)
+
+
+def test_pairing_matches_bigint_twin():
+    import pyref
+    for a, b in ((1, 1), (69, 96), (123456789, 987654321)):
+        P, Qt = pyref.g1_mul(pyref.G1_GEN, a), pyref.g2_mul(pyref.G2_GEN, b)
+        assert zk.pairing(g1_words(P), g2_words(Qt)) == pyref.fq12_flat(pyref.pairing(P, Qt))
+
+
+def test_pairing_bilinear_and_degenerate():
+    import pyref
+    one = [1] + [0] * 11
+    assert zk.pairing(g1_words(None), g2_words(pyref.G2_GEN)) == one
+    assert zk.pairing(g1_words(pyref.G1_GEN), g2_words(None)) == one
+    e = zk.pairing(g1_words(pyref.G1_GEN), g2_words(pyref.G2_GEN))
+    assert e != one
+    a = 0xdeadbeefcafe
+    assert zk.pairing(g1_words(pyref.g1_mul(pyref.G1_GEN, a)), g2_words(pyref.G2_GEN)) == \
+        zk.pairing(g1_words(pyref.G1_GEN), g2_words(pyref.g2_mul(pyref.G2_GEN, a)))
+    with pytest.raises(zk.ZkError):
+        zk.pairing(ints_to_limbs([1, 3]).reshape(8), g2_words(pyref.G2_GEN))      # (1,3) is not on the curve
+
+
+@pytest.mark.gpu
+def test_simple_circuit_test(ctx):
+    """lib.rs:156-190: simple.zk, a=3 b=2 c=4 -> verify(b=2, x=34) true, verify(b=2, x=25) false."""
+    from zksnark_rs_amd.circuit import Circuit
+    c = Circuit(open(os.path.join(ZK_DIR, "simple.zk")).read())
+    weights = c.weights([3, 2, 4])
+    qap = c.qap(ctx)
+    rng = SplitMix64(77)
+    for _ in range(2):
+        crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+        proof = ctx.prove(crs, qap, weights, rng.fr(), rng.fr())
+        assert ctx.verify(crs, [2, 34], proof)
+        assert not ctx.verify(crs, [2, 25], proof)
+    bad = bytearray(proof); bad[40] ^= 1
+    assert not ctx.verify(crs, [2, 34], bytes(bad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["lispesque_quad.zk", "lispesque_cubic.zk", "deg_15.zk"])
+def test_bn_encrypt_programs_verify(ctx, prog):
+    """fr.rs:273-416 (bn_encrypt_quad/cubic/deg_15_test): random inputs, verify(&weights[1..3])."""
+    from zksnark_rs_amd.circuit import Circuit
+    c = Circuit(open(os.path.join(ZK_DIR, prog)).read())
+    rng = SplitMix64(len(prog))
+    weights = c.weights([rng.fr() for _ in range(c.n_in)])
+    qap = c.qap(ctx)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    proof = ctx.prove(crs, qap, weights, rng.fr(), rng.fr())
+    assert ctx.verify(crs, weights[1:3], proof)
+    wrong = weights[1:3].copy(); wrong[1, 0] ^= np.uint64(1)
+    assert not ctx.verify(crs, wrong, proof)
+
+
+@pytest.mark.gpu
+def test_verify_large_sparse_proof(ctx):
+    """2^12-gate chain circuit through the sparse pipeline: the proof verifies; an unsatisfying witness does not."""
+    from zksnark_rs_amd.circuits import chain_rows, chain_weights
+    log_n = 12
+    rng = SplitMix64(4242)
+    m, l, u, v, w = chain_rows(log_n)
+    weights = chain_weights(log_n, rng.fr(), [rng.fr() for _ in range(1 << log_n)])
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    r, s = rng.fr(), rng.fr()
+    assert ctx.verify(crs, weights[1:3], ctx.prove(crs, qap, weights, r, s))
+    bad = weights.copy(); bad[5, 0] ^= np.uint64(1)
+    assert not ctx.verify(crs, bad[1:3], ctx.prove(crs, qap, bad, r, s))
+
+
+@pytest.mark.gpu
+def test_reference_doc_example(ctx):
+    """The crate's doc example (lib.rs:80-114) through the reference-named API."""
+    from zksnark_rs_amd import groth16
+    code = open(os.path.join(ZK_DIR, "simple.zk")).read()
+    qap = groth16.QAP.from_zk(ctx, code)
+    w = groth16.weights(code, [3, 2, 4])
+    sigmag1, sigmag2 = groth16.setup(qap)
+    proof = groth16.prove(qap, (sigmag1, sigmag2), w)
+    assert groth16.verify((sigmag1, sigmag2), [2, 34], proof)
+    assert not groth16.verify((sigmag1, sigmag2), [2, 25], proof)

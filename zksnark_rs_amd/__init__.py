@@ -23,7 +23,7 @@ R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575
 Q_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
 __all__ = ["Context", "ZkError", "fr_to_limbs", "limbs_to_int", "ints_to_limbs", "limbs_to_ints",
-           "PROOF_BYTES", "PARTIAL_BYTES", "R_MODULUS", "Q_MODULUS", "SplitMix64"]
+           "PROOF_BYTES", "PARTIAL_BYTES", "R_MODULUS", "Q_MODULUS", "SplitMix64", "pairing"]
 
 
 class ZkError(RuntimeError):
@@ -88,6 +88,18 @@ def _u64(a):
 def _u32(a):
     a = np.ascontiguousarray(a, dtype=np.uint32)
     return a, a.ctypes.data_as(_lib.u32p)
+
+
+def pairing(g1, g2):
+    """EllipticEncryptable::pairing (fr.rs:120-122) on the host: (8,) and (16,) limb arrays -> 12 Fq ints."""
+    lib = _lib.load()
+    a, ap = _u64(np.asarray(g1).reshape(8))
+    b, bp = _u64(np.asarray(g2).reshape(16))
+    out = np.zeros(48, dtype=np.uint64)
+    rc = lib.zk_pairing(ap, bp, out.ctypes.data_as(_lib.u64p))
+    if rc != 0:
+        raise ZkError(rc)
+    return limbs_to_ints(out)
 
 
 class _Handle:
@@ -308,6 +320,15 @@ class Context:
         out = np.zeros(PROOF_BYTES, dtype=np.uint8)
         self._check(self.lib.zk_prove_combine(self.ptr, crs.ptr, C.c_void_p(d_partials_ptr), world, rp, sp, out.ctypes.data_as(_lib.u8p)))
         return out.tobytes()
+
+    # ---- verify ----
+    def verify(self, crs, inputs, proof):
+        """groth16::verify (mod.rs:299-320): inputs = the `verify` wires (ints or (k,4) limbs), proof = 259 bytes."""
+        a = ints_to_limbs(list(inputs)) if not isinstance(inputs, np.ndarray) else np.ascontiguousarray(inputs, dtype=np.uint64).reshape(-1, 4)
+        pb = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
+        ok = C.c_int(0)
+        self._check(self.lib.zk_verify(self.ptr, crs.ptr, a.ctypes.data_as(_lib.u64p), a.shape[0], pb.ctypes.data_as(_lib.u8p), C.byref(ok)))
+        return bool(ok.value)
 
     # ---- profiling ----
     def profile_reset(self):

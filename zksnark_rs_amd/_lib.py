@@ -79,6 +79,8 @@ SIGNATURES = {
     "zk_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
     "zk_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
+    "zk_verify": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u8p, C.POINTER(C.c_int)]),
+    "zk_pairing": (C.c_int, [u64p, u64p, u64p]),
     "zk_profile_reset": (C.c_int, [C.c_void_p]),
     "zk_profile_count": (C.c_int, [C.c_void_p]),
     "zk_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
