@@ -185,12 +185,13 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
                  const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
 
 /* Multi-GPU: every rank holds the CRS and recomputes the NTT stage; rank g owns
- * Pippenger windows w = g (mod world) of each of the five inner products and writes its
- * partial sums (Jacobian, device Montgomery limbs) to d_partial_out (ZK_PARTIAL_BYTES).  The
- * caller all-gathers the blobs (RCCL, as bytes) and any rank finishes with zk_prove_combine. */
-#define ZK_PARTIAL_BYTES 768   /* 4 G1 Jacobian (96 B) + 1 G2 Jacobian (192 B) + padding to 768 */
+ * Pippenger windows w = g (mod world) of each inner product and writes its partial sums
+ * (Jacobian, device Montgomery limbs) to d_partial_out (ZK_PARTIAL_BYTES).  The caller all-gathers
+ * the blobs (RCCL, as bytes) and any rank finishes with zk_prove_combine.  (r, s) are needed here
+ * because B in G1 enters the proof only as r*B1 and is folded into the H product as scalars r*v_i. */
+#define ZK_PARTIAL_BYTES 768   /* 4 G1 Jacobian slots (96 B) + 1 G2 Jacobian (192 B), padded to 768 */
 int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
-                     int rank, int world, void* d_partial_out);
+                     const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out);
 int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
                      const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
 

@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
         def new_buffer(self, nbytes):
             return torch.zeros(nbytes, dtype=torch.uint8)
 
-        def partial(self, rank, world, out):
+        def partial(self, rank, world, r, s, out):
             sl = lambda v: v[rank::world]
             a = pyref.msm_g1(sl(s1["xi"]), sl(U)); b1 = pyref.msm_g1(sl(s1["xi"]), sl(V))
             hh = pyref.msm_g1(sl(s1["xi_t"]), sl(h)); ll = pyref.msm_g1(sl(s1["sum_delta"]), sl(wts[l + 1:]))

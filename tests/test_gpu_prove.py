@@ -112,7 +112,7 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     for world in (1, 2, 4, 8):
         buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
         for rank in range(world):
-            ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+            ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
         torch.cuda.synchronize()
         assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want
     assert ctx.prove_dev(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]) == want

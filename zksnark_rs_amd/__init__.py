@@ -311,8 +311,10 @@ class Context:
         self._check(self.lib.zk_prove_dev(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, out.ctypes.data_as(_lib.u8p)))
         return out.tobytes()
 
-    def prove_partial(self, crs, qap, d_weights_ptr, m, rank, world, d_partial_ptr):
-        self._check(self.lib.zk_prove_partial(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rank, world, C.c_void_p(d_partial_ptr)))
+    def prove_partial(self, crs, qap, d_weights_ptr, m, r, s, rank, world, d_partial_ptr):
+        r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)
+        s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
+        self._check(self.lib.zk_prove_partial(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, rank, world, C.c_void_p(d_partial_ptr)))
 
     def prove_combine(self, crs, d_partials_ptr, world, r, s):
         r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)

@@ -177,9 +177,9 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
     return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, proof_out, 0, 1, nullptr); ctx->resolve_profile(); });
 }
 int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
-                     int rank, int world, void* d_partial_out) {
-    if (!ctx || !crs || !qap || !d_weights || !d_partial_out || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
-    return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, nullptr, nullptr, nullptr, rank, world, d_partial_out); ctx->resolve_profile(); });
+                     const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out) {
+    if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, nullptr, rank, world, d_partial_out); ctx->resolve_profile(); });
 }
 int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
                      const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]) {

@@ -111,7 +111,14 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
     const size_t n = c.n, nl = c.m - c.input - 1;
     // xi_t has n-1 points; the bit-reversed copy is padded with infinity to n entries
     msm_build_table<Fq>(ctx, brev ? c.xi1_br.p : c.xi1.p, n, pick(n), c.t_xi1);
-    msm_build_table<Fq>(ctx, brev ? c.xi_t1_br.p : c.xi_t1.p, brev ? n : n - 1, pick(n), c.t_xi_t1);
+    {   // bases of the merged product H + r*B1: xi_t | xi
+        const size_t nt = brev ? n : n - 1;
+        DevBuf<G1A> cat(nt + n);
+        if (nt) ZK_HIP(hipMemcpyAsync(cat.p, brev ? c.xi_t1_br.p : c.xi_t1.p, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(cat.p + nt, brev ? c.xi1_br.p : c.xi1.p, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        msm_build_table<Fq>(ctx, cat.p, nt + n, pick(nt + n), c.t_hb1);
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
     msm_build_table<Fq2>(ctx, brev ? c.xi2_br.p : c.xi2.p, n, pick(n), c.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));

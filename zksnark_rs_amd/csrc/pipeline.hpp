@@ -28,7 +28,7 @@ struct zk_qap {
     zk::DevBuf<zk::Fr> t_cinv; // 1 / leading coefficient of t (dense)
     bool t_is_zero = false;
     // scratch reused across proofs
-    zk::DevBuf<zk::Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, h_can, wc, prod_a, prod_b;
+    zk::DevBuf<zk::Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b;
 };
 
 struct zk_crs {
@@ -45,7 +45,7 @@ struct zk_crs {
     bool has_br = false;
     // fixed-base window tables T[w][i] = 2^(c w) P_i for the four base sets prove() uses
     // (built on first use for the order -- natural or bit-reversed -- the QAP kind needs)
-    zk::MsmTable<zk::Fq> t_xi1, t_xi_t1, t_sum_delta1;
+    zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;   // t_hb1: bases xi_t | xi (H and r*B1 in one product)
     zk::MsmTable<zk::Fq2> t_xi2;
     int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed
     // 4-bit fixed-base tables FT[w][d] = d * 16^w * P (64 x 16 entries) for the single CRS points

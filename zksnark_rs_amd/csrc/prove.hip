@@ -22,7 +22,10 @@ namespace zk {
 void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n);
 
 struct MsmResults {
-    G1J a, b1, h, l;
+    G1J a;      // sum u_i [x^i]_1
+    G1J hb;     // sum h_i [x^i t/delta]_1 + sum (r v_i) [x^i]_1   (H and r*B1 share one MSM: both only occur in c)
+    G1J l;      // sum a_i sum_delta_i
+    G1J spare;
     G2J b2;
 };
 static_assert(sizeof(MsmResults) == 4 * 96 + 192, "partial layout");
@@ -34,7 +37,7 @@ struct AssemblePre {
     G2J s_delta2;     // s * delta2
 };
 struct AssembleDyn {
-    G1J s_a, r_b1;    // s * A_msm, r * B1_msm
+    G1J s_a;          // s * A_msm (the only dynamic-base multiplication left)
 };
 
 __device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
@@ -88,11 +91,10 @@ __device__ G1J dyn_mul_g1(const G1J& p, const Fr& k) {
     }
     return acc;
 }
-// s * A_msm and r * B1_msm: launched as soon as those two inner products are done, hidden behind
-// the remaining ones
+// s * A_msm: launched as soon as A is done, hidden behind the remaining inner products
 __global__ __launch_bounds__(128) void k_assemble_dyn(const MsmResults* __restrict__ ms, Fr r, Fr s, AssembleDyn* __restrict__ out) {
     if (threadIdx.x == 0) out->s_a = dyn_mul_g1(ms->a, s);
-    if (threadIdx.x == 64) out->r_b1 = dyn_mul_g1(ms->b1, r);
+    (void)r;
 }
 
 __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
@@ -127,14 +129,15 @@ __device__ void encode_g2(const G2J& p, uint8_t* out) {
 
 // (mod.rs:274-293)  a = A + alpha + r delta ;  b = B2 + beta2 + s delta2 ;
 // c = H + L + s a + r (beta + B1 + s delta) - (r s) delta
-//   = H + L + s A + r B1 + [s alpha + r beta + (r s) delta]
+//   = [H + r B1] + L + s A + [s alpha + r beta + (r s) delta]
+// where H + r B1 comes out of ONE inner product (scalars h_i and r v_i over the bases xi_t | xi)
 __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const AssembleDyn* __restrict__ dyn,
                                                   const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x & 63) return;
     if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
     if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(jac_add_ni(ms->h, ms->l), jac_add_ni(dyn->s_a, dyn->r_b1)), pre->fixed_c), proof + 65 + 129);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(jac_add_ni(ms->hb, ms->l), dyn->s_a), pre->fixed_c), proof + 65 + 129);
 }
 
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
@@ -144,10 +147,10 @@ __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, 
         G1J acc = G1J::infinity();
         for (int g = 0; g < world; ++g) {
             const MsmResults* p = reinterpret_cast<const MsmResults*>(partials + (size_t)g * ZK_PARTIAL_BYTES);
-            const G1J* src = which == 0 ? &p->a : which == 1 ? &p->b1 : which == 2 ? &p->h : &p->l;
+            const G1J* src = which == 0 ? &p->a : which == 1 ? &p->hb : which == 2 ? &p->l : &p->spare;
             acc = jac_add_ni(acc, *src);
         }
-        G1J* dst = which == 0 ? &out->a : which == 1 ? &out->b1 : which == 2 ? &out->h : &out->l;
+        G1J* dst = which == 0 ? &out->a : which == 1 ? &out->hb : which == 2 ? &out->l : &out->spare;
         *dst = acc;
     } else {
         G2J acc = G2J::infinity();
@@ -206,12 +209,11 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     // the r/s-only fixed-base multiplications overlap with everything below on the side stream
     DevBuf<AssembleScratch> d_as(1);
     DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
-    Fr rc = Fr::zero(), sc = Fr::zero();
+    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
+    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+    const Fr r_mont = Fr::from_canonical(rc);
     hipEvent_t pre_evt = nullptr;
     if (!d_partial_out) {
-        rc = fr_from_words64(r);
-        sc = fr_from_words64(s);
-        ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
         crs_ensure_fixed_tables(ctx, crs);
         pre_evt = ctx->get_event();
         launch_pre(ctx, crs, ctx->side, rc, sc, d_as.p);
@@ -232,12 +234,10 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out);
         ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
     };
-    auto launch_dyn_after_a_b1 = [&]() {
+    auto launch_dyn_after_a = [&]() {
         if (d_partial_out) return;
-        // s*A and r*B1 need only these two results: start them now (side stream, high priority),
-        // behind the remaining inner products
+        // s*A needs only A: start it now (side stream, high priority), behind the remaining inner products
         ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[2], 0));
-        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[3], 0));
         launch_dyn(ctx, ctx->side, ms, rc, sc, d_as.p);
         ZK_HIP(hipEventRecord(pre_evt, ctx->side));
     };
@@ -247,7 +247,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
-        q.uc_can.ensure(n); q.vc_can.ensure(n); q.h_can.ensure(n);
+        q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
         launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);     // L: sum a_i * sum_delta_i (witness only)
         spmv(ctx, q.u_gate, q.a_mont.p, a_len, q.ue.p);
         spmv(ctx, q.v_gate, q.a_mont.p, a_len, q.ve.p);
@@ -255,11 +255,11 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients (bit-reversed order)
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);                      // A
+        launch_dyn_after_a();
         ntt_dif(ctx, q.ve.p, q.log_n, true, true);
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(3, crs.t_xi1, q.vc_can.p, n, &ms->b1);                     // B in G1
-        launch_dyn_after_a_b1();
         launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);                     // B in G2
+        fr_scale_to_canonical(ctx, q.ve.p, r_mont, q.hb_can.p + n, n);    // r * v_i: B in G1 folded into the H product
         ZK_HIP(hipMemcpyAsync(q.ug.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ZK_HIP(hipMemcpyAsync(q.vg.p, q.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ntt_dit(ctx, q.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
@@ -268,9 +268,9 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ntt_dif(ctx, q.x0.p, q.log_n, true, true);                        // lo + hi
         ntt_dif(ctx, q.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
         Fr half = host_fr_from_u64(2).inv();
-        h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.h_can.p, n);
-        // entry brev(n-1) = n-1 of the bit-reversed xi_t table is infinity
-        launch(4, crs.t_xi_t1, q.h_can.p, n, &ms->h);                     // H: sum h_i * xi_t_i
+        h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.hb_can.p, n);
+        // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
+        launch(4, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);                 // H + r B1
     } else {
         ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
         crs_ensure_tables(ctx, crs, false, 0);
@@ -278,7 +278,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         while (((size_t)1 << lc) < 2 * n) ++lc;
         size_t nc = (size_t)1 << lc;
         q.ue.ensure(n); q.ve.ensure(n); q.wc.ensure(n); q.prod_a.ensure(nc); q.prod_b.ensure(nc);
-        q.uc_can.ensure(n); q.vc_can.ensure(n); q.h_can.ensure(nc);
+        q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
         launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
         dense_matvec(ctx, q.du.p, q.a_mont.p, a_len, n, q.ue.p);
         dense_matvec(ctx, q.dv.p, q.a_mont.p, a_len, n, q.ve.p);
@@ -286,9 +286,9 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
         launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);
-        launch(3, crs.t_xi1, q.vc_can.p, n, &ms->b1);
-        launch_dyn_after_a_b1();
+        launch_dyn_after_a();
         launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);
+        fr_scale_to_canonical(ctx, q.ve.p, r_mont, q.hb_can.p + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
         ZK_HIP(hipMemsetAsync(q.prod_a.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemcpyAsync(q.prod_a.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -302,8 +302,8 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
         if (len_r > d) poly_divide(ctx, q.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, q.prod_b.p);
-        fr_from_mont(ctx, q.prod_b.p, q.h_can.p, n - 1);
-        launch(4, crs.t_xi_t1, q.h_can.p, n - 1, &ms->h);
+        fr_from_mont(ctx, q.prod_b.p, q.hb_can.p, n - 1);
+        launch(4, crs.t_hb1, q.hb_can.p, 2 * n - 1, &ms->hb);
     }
     for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
 

@@ -187,6 +187,18 @@ void h_combine(zk_ctx* ctx, const Fr* x, const Fr* y, const Fr* tab, Fr half, Fr
     ZK_HIP(hipGetLastError());
 }
 
+// out[i] = canonical(in[i] * k)   (in Montgomery form, k Montgomery)
+__global__ void k_scale_to_canonical(const Fr* __restrict__ in, Fr k, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (in[i] * k).to_canonical();
+}
+void fr_scale_to_canonical(zk_ctx* ctx, const Fr* in, Fr k, Fr* out, size_t n) {
+    if (!n) return;
+    ProfScope ps(ctx, "fr_scale_to_canonical", 64.0 * n);
+    hipLaunchKernelGGL(k_scale_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, k, out, n);
+    ZK_HIP(hipGetLastError());
+}
+
 __global__ void k_sub_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = a[i] - b[i];

@@ -2,7 +2,7 @@
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  Every rank holds the CRS
 and the QAP, recomputes the cheap NTT stage, accumulates only the Pippenger windows
-w = rank (mod world) of the five inner products (zk_prove_partial), all-gathers the partial sums
+w = rank (mod world) of the inner products (zk_prove_partial), all-gathers the partial sums
 as raw bytes (RCCL cannot reduce group elements) and finishes locally (zk_prove_combine).
 SURVEY.md 8e.  The same function drives the CPU `gloo` test with a stand-in backend.
 """
@@ -20,8 +20,8 @@ class GpuProver:
     def new_buffer(self, nbytes):
         return self.torch.zeros(nbytes, dtype=self.torch.uint8, device="cuda")
 
-    def partial(self, rank, world, out):
-        self.ctx.prove_partial(self.crs, self.qap, self.d_weights.data_ptr(), self.m, rank, world, out.data_ptr())
+    def partial(self, rank, world, r, s, out):
+        self.ctx.prove_partial(self.crs, self.qap, self.d_weights.data_ptr(), self.m, r, s, rank, world, out.data_ptr())
 
     def combine(self, gathered, world, r, s):
         self.torch.cuda.synchronize()
@@ -34,7 +34,7 @@ def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     if buffers is None:
         buffers = (prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES))
     part, gathered = buffers
-    prover.partial(rank, world, part)
+    prover.partial(rank, world, r, s, part)
     if world > 1:
         dist.all_gather_into_tensor(gathered, part)
     else:
