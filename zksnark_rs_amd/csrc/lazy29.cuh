@@ -235,4 +235,80 @@ ZK_HD bool madd_lazy(JacR<F>& p, const typename LazyOf<F>::type& qx, const typen
     return true;
 }
 
+
+// ---- general Jacobian addition / doubling in lazy form (reduction tail of the MSM) -------------
+template <class F>
+ZK_HD JacR<F> jacr_load(const Jac<F>& p) {
+    typedef typename LazyOf<F>::type L;
+    JacR<F> r;
+    r.inf = p.is_inf();
+    r.X = L::load(p.X); r.Y = L::load(p.Y); r.Z = L::load(p.Z);
+    return r;
+}
+template <class F>
+ZK_HD Jac<F> jacr_store(const JacR<F>& p) {
+    return p.inf ? Jac<F>::infinity() : Jac<F>{p.X.store_exact(), p.Y.store_exact(), p.Z.store_exact()};
+}
+
+// dbl-2009-l (a = 0) with every intermediate kept multipliable (see the bounds in the header)
+template <class F>
+ZK_HD JacR<F> dbl_lazy(const JacR<F>& p) {
+    typedef typename LazyOf<F>::type L;
+    if (p.inf) return p;
+    L A = p.X.sqr(), B = p.Y.sqr(), C = B.sqr();
+    L t = (p.X + B).norm().sqr();
+    L D = (t - A - C);
+    D = (D + D).norm();
+    L E = (A + A + A).norm();
+    L X3 = (E.sqr() - D - D).norm();
+    L c2 = (C + C).norm(), c4 = (c2 + c2).norm();
+    L Y3 = (E * (D - X3) - (c4 + c4)).norm();
+    L yz = p.Y * p.Z;
+    JacR<F> r;
+    r.inf = false;
+    r.X = X3; r.Y = Y3; r.Z = (yz + yz).norm();
+    return r;
+}
+
+// p + q, both Jacobian (12M + 4S, no constant factors):
+//   U1 = X1 Z2^2, U2 = X2 Z1^2, S1 = Y1 Z2^3, S2 = Y2 Z1^3, H = U2 - U1, R = S2 - S1,
+//   X3 = R^2 - H^3 - 2 U1 H^2,  Y3 = R (U1 H^2 - X3) - S1 H^3,  Z3 = Z1 Z2 H
+template <class F>
+ZK_HD JacR<F> add_lazy(const JacR<F>& p, const JacR<F>& q) {
+    typedef typename LazyOf<F>::type L;
+    if (p.inf) return q;
+    if (q.inf) return p;
+    L Z1Z1 = p.Z.sqr(), Z2Z2 = q.Z.sqr();
+    L U1 = p.X * Z2Z2, U2 = q.X * Z1Z1;
+    L S1 = (p.Y * q.Z) * Z2Z2, S2 = (q.Y * p.Z) * Z1Z1;
+    L H = U2 - U1, R = S2 - S1;
+    L HH = H.sqr();
+    if (HH.is_zero_mod_p()) {
+        if (R.sqr().is_zero_mod_p()) return dbl_lazy(p);
+        JacR<F> r = p;
+        r.inf = true;
+        return r;
+    }
+    L HHH = H * HH;
+    L V = U1 * HH;
+    L X3 = (R.sqr() - HHH - (V + V)).norm();
+    L Y3 = (R * (V - X3) - S1 * HHH).norm();
+    JacR<F> r;
+    r.inf = false;
+    r.X = X3; r.Y = Y3; r.Z = (p.Z * q.Z) * H;
+    return r;
+}
+
+// k * P for a small non-negative k
+template <class F>
+ZK_HD JacR<F> mul_small_lazy(const JacR<F>& p, uint32_t k) {
+    JacR<F> acc = p;
+    acc.inf = true;
+    for (int i = 31 - __builtin_clz(k | 1); i >= 0; --i) {
+        acc = dbl_lazy(acc);
+        if ((k >> i) & 1) acc = add_lazy(acc, p);
+    }
+    return acc;
+}
+
 }  // namespace zk

@@ -232,9 +232,9 @@ __global__ __launch_bounds__(64) void k_msm_merge(const Jac<F>* __restrict__ par
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     const Jac<F>* src = partial + ((size_t)b << log_lanes);
-    Jac<F> acc = src[0];
-    for (int t = 1; t < (1 << log_lanes); ++t) acc = jac_add_ni(acc, src[t]);
-    bucket_sums[b] = acc;
+    JacR<F> acc = jacr_load(src[0]);
+    for (int t = 1; t < (1 << log_lanes); ++t) acc = add_lazy(acc, jacr_load(src[t]));
+    bucket_sums[b] = jacr_store(acc);
 }
 
 // segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} b * S_b
@@ -244,26 +244,26 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restri
     if (t >= segs) return;
     int lo = t * MSM_SEG + 1, hi = min(buckets, lo + MSM_SEG - 1);
     const Jac<F>* wb = bkt - 1;  // wb[b], b in 1..buckets
-    Jac<F> running = Jac<F>::infinity(), acc = Jac<F>::infinity();
+    JacR<F> running = jacr_load(Jac<F>::infinity()), acc = running;
     for (int b = hi; b >= lo; --b) {
-        running = jac_add_ni(running, wb[b]);
-        acc = jac_add_ni(acc, running);
+        running = add_lazy(running, jacr_load(wb[b]));
+        acc = add_lazy(acc, running);
     }
-    if (lo > 1) acc = jac_add_ni(acc, jac_mul_small(running, (uint32_t)(lo - 1)));
-    out[t] = acc;
+    if (lo > 1) acc = add_lazy(acc, mul_small_lazy(running, (uint32_t)(lo - 1)));
+    out[t] = jacr_store(acc);
 }
 
-// sums `count` points into one (one workgroup of 256 lanes)
+// sums `count` points into one (one workgroup of 256 lanes; tree over LDS in the 8 x 32 form)
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
-    Jac<F> acc = Jac<F>::infinity();
-    for (int k = threadIdx.x; k < count; k += 256) acc = jac_add_ni(acc, in[k]);
-    sh[threadIdx.x] = acc;
+    JacR<F> acc = jacr_load(Jac<F>::infinity());
+    for (int k = threadIdx.x; k < count; k += 256) acc = add_lazy(acc, jacr_load(in[k]));
+    sh[threadIdx.x] = jacr_store(acc);
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) sh[threadIdx.x] = jac_add_ni(sh[threadIdx.x], sh[threadIdx.x + d]);
+        if ((int)threadIdx.x < d) sh[threadIdx.x] = jacr_store(add_lazy(jacr_load(sh[threadIdx.x]), jacr_load(sh[threadIdx.x + d])));
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = sh[0];
