@@ -36,17 +36,21 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         hipDeviceProp_t prop;
         ZK_HIP(hipGetDeviceProperties(&prop, device_ordinal));
         ctx->cu_count = prop.multiProcessorCount;
-        ZK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        // A and B1 (streams 2, 3) and the side stream that consumes them run at high priority so the
-        // dynamic-base multiplications s*A, r*B1 start early and hide behind the other inner products
         int prio_least = 0, prio_greatest = 0;
         ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        // the main stream carries the NTT stage (many short dependent kernels): high priority so that it
+        // is not starved by the accumulation kernels of the MSM streams
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
+        // A and B1 (streams 2, 3) and the side stream that consumes them run at high priority so the
+        // dynamic-base multiplications s*A, r*B1 start early and hide behind the other inner products
         ZK_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_greatest));
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
-            ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, (i == 2 || i == 3) ? prio_greatest : prio_least));
+            ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
             ZK_HIP(hipEventCreateWithFlags(&ctx->msm_done[i], hipEventDisableTiming));
+            ZK_HIP(hipEventCreateWithFlags(&ctx->acc_evt[i], hipEventDisableTiming));
         }
         ZK_HIP(hipEventCreateWithFlags(&ctx->fork_evt, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&ctx->ntt_done, hipEventDisableTiming));
         msm_set_lds_attributes();
     });
     if (rc != ZK_OK) { delete ctx; return rc; }
@@ -63,8 +67,10 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         ctx->msm_ws[i].reset();
         if (ctx->msm_stream[i]) { (void)hipStreamSynchronize(ctx->msm_stream[i]); (void)hipStreamDestroy(ctx->msm_stream[i]); }
         if (ctx->msm_done[i]) (void)hipEventDestroy(ctx->msm_done[i]);
+        if (ctx->acc_evt[i]) (void)hipEventDestroy(ctx->acc_evt[i]);
     }
     if (ctx->fork_evt) (void)hipEventDestroy(ctx->fork_evt);
+    if (ctx->ntt_done) (void)hipEventDestroy(ctx->ntt_done);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -99,6 +99,8 @@ struct zk_ctx {
     hipStream_t msm_stream[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t msm_done[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_evt = nullptr;
+    hipEvent_t ntt_done = nullptr;
+    hipEvent_t acc_evt[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // end of each accumulation (chain)
     int cu_count = 256;
 
     hipEvent_t get_event() {

@@ -187,7 +187,7 @@ template <class F> struct AccWaves { static constexpr int value = 3; };
 template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
 template <class F>
-__global__ __launch_bounds__(64, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
+__global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
                                                        const uint32_t* __restrict__ start, int buckets, int log_lanes, Jac<F>* __restrict__ partial) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= ((size_t)buckets << log_lanes)) return;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict
 
 template <class F>
 void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out) {
+             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done) {
     const bool g2 = sizeof(F) > sizeof(Fq);
     const int c = tab.c, windows = tab.windows, buckets = 1 << (c - 1);
     const size_t n = tab.n;
@@ -281,6 +281,8 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     if (n_used == 0 || owned == 0) {
         static const Jac<F> inf = Jac<F>::infinity();
         ZK_HIP(hipMemcpyAsync(d_out, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
+        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
+        if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
         return;
     }
     // chunking of the scalar array for the LDS counting sort
@@ -325,9 +327,11 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
         // every lane writes one Jacobian partial
         size_t threads = (size_t)buckets << log_lanes;
+        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(Jac<F>) * threads, st);
-        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(threads, 64)), dim3(64), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, log_lanes, d_partial);
+        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, log_lanes, d_partial);
     }
+    if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(Jac<F>) * (((size_t)buckets << log_lanes) + 2.0 * buckets + 2.0 * segs), st);
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, d_partial, buckets, log_lanes, d_bsum);
@@ -336,7 +340,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     ZK_HIP(hipGetLastError());
 }
-template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*);
+template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t);
 
 #ifdef ZK_MSM_COMMON
 void msm_set_lds_attributes() {

@@ -23,7 +23,7 @@ void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n);
 
 struct MsmResults {
     G1J a;      // sum u_i [x^i]_1
-    G1J hb;     // sum h_i [x^i t/delta]_1 + sum (r v_i) [x^i]_1   (H and r*B1 share one MSM: both only occur in c)
+    G1J hb;     // sum h_i [x^i t/delta]_1 + sum (r v_i + s u_i) [x^i]_1   (H, r*B1 and s*A only occur in c)
     G1J l;      // sum a_i sum_delta_i
     G1J spare;
     G2J b2;
@@ -35,9 +35,6 @@ struct AssemblePre {
     G1J r_delta;      // r * delta1
     G1J fixed_c;      // s * alpha1 + r * beta1 + (r s) * delta1
     G2J s_delta2;     // s * delta2
-};
-struct AssembleDyn {
-    G1J s_a;          // s * A_msm (the only dynamic-base multiplication left)
 };
 
 __device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
@@ -78,25 +75,6 @@ __global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft
     }
 }
 
-// 4-bit windowed k * P for a point only known at run time (one lane)
-__device__ G1J dyn_mul_g1(const G1J& p, const Fr& k) {
-    G1J tab[16];
-    tab[0] = G1J::infinity();
-    tab[1] = p;
-    for (int d = 2; d < 16; ++d) tab[d] = jac_add_ni(tab[d - 1], p);
-    G1J acc = G1J::infinity();
-    for (int w = 63; w >= 0; --w) {
-        for (int k4 = 0; k4 < 4; ++k4) acc = jac_dbl_ni(acc);
-        acc = jac_add_ni(acc, tab[nibble(k, w)]);
-    }
-    return acc;
-}
-// s * A_msm: launched as soon as A is done, hidden behind the remaining inner products
-__global__ __launch_bounds__(128) void k_assemble_dyn(const MsmResults* __restrict__ ms, Fr r, Fr s, AssembleDyn* __restrict__ out) {
-    if (threadIdx.x == 0) out->s_a = dyn_mul_g1(ms->a, s);
-    (void)r;
-}
-
 __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
     Fq x = x_mont.to_canonical();
 #pragma unroll
@@ -129,15 +107,16 @@ __device__ void encode_g2(const G2J& p, uint8_t* out) {
 
 // (mod.rs:274-293)  a = A + alpha + r delta ;  b = B2 + beta2 + s delta2 ;
 // c = H + L + s a + r (beta + B1 + s delta) - (r s) delta
-//   = [H + r B1] + L + s A + [s alpha + r beta + (r s) delta]
-// where H + r B1 comes out of ONE inner product (scalars h_i and r v_i over the bases xi_t | xi)
-__global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const AssembleDyn* __restrict__ dyn,
+//   = [H + r B1 + s A] + L + [s alpha + r beta + (r s) delta]
+// where H + r B1 + s A comes out of ONE inner product: scalars h_i over xi_t and (r v_i + s u_i) over
+// xi.  No scalar multiplication with a run-time base is left.
+__global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
                                                   const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x & 63) return;
     if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
     if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(jac_add_ni(ms->hb, ms->l), dyn->s_a), pre->fixed_c), proof + 65 + 129);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
 }
 
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
@@ -167,16 +146,10 @@ static Fr fr_from_words64(const uint64_t w[4]) {
 
 struct AssembleScratch {
     AssemblePre pre;
-    AssembleDyn dyn;
 };
 
 static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
     hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
-    ZK_HIP(hipGetLastError());
-}
-static void launch_dyn(zk_ctx* ctx, hipStream_t st, const MsmResults* d_ms, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
-    ProfScope ps(ctx, "assemble_dyn", 0, st);
-    hipLaunchKernelGGL(k_assemble_dyn, dim3(1), dim3(128), 0, st, d_ms, rc, sc, &d_as->dyn);
     ZK_HIP(hipGetLastError());
 }
 // final additions + affine normalisation + canonical encoding, then copy the 259 bytes out
@@ -184,7 +157,7 @@ static void finish(zk_ctx* ctx, const zk_crs& crs, const MsmResults* d_ms, Assem
     hipStream_t st = ctx->stream;
     {
         ProfScope ps(ctx, "assemble", 0);
-        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms, &d_as->pre, &d_as->dyn, crs.alpha1.p, crs.beta2.p, d_proof);
+        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms, &d_as->pre, crs.alpha1.p, crs.beta2.p, d_proof);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(proof_out, d_proof, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
@@ -211,7 +184,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
-    const Fr r_mont = Fr::from_canonical(rc);
+    const Fr r_mont = Fr::from_canonical(rc), s_mont = Fr::from_canonical(sc);
     hipEvent_t pre_evt = nullptr;
     if (!d_partial_out) {
         crs_ensure_fixed_tables(ctx, crs);
@@ -226,40 +199,37 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     DevBuf<MsmResults> d_ms(1);
     MsmResults* ms = d_ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    auto launch = [&](int k, auto& table, const Fr* scalars, size_t count, auto* out) {
+    // `after`: slot whose accumulation must finish first (-1: none).  The accumulation kernels are
+    // chained B2 -> A -> L -> H+rB1: the long G2 kernel runs while the rest of the NTT stage proceeds at
+    // high priority, its long reduction tail hides behind the G1 accumulations, and the last tail
+    // exposed is the short G1 one.
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
         hipStream_t ms_st = ctx->msm_stream[k];
         if (!ctx->msm_ws[k]) ctx->msm_ws[k] = std::make_shared<MsmWorkspace>();
         ZK_HIP(hipEventRecord(ctx->fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, ctx->fork_evt, 0));
-        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out);
+        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out,
+                after >= 0 ? ctx->acc_evt[after] : (after == -2 ? ctx->ntt_done : nullptr), ctx->acc_evt[k]);
         ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
     };
-    auto launch_dyn_after_a = [&]() {
-        if (d_partial_out) return;
-        // s*A needs only A: start it now (side stream, high priority), behind the remaining inner products
-        ZK_HIP(hipStreamWaitEvent(ctx->side, ctx->msm_done[2], 0));
-        launch_dyn(ctx, ctx->side, ms, rc, sc, d_as.p);
-        ZK_HIP(hipEventRecord(pre_evt, ctx->side));
-    };
-
     if (!q.dense) {
         crs_ensure_tables(ctx, crs, true, q.log_n);
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
         q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
-        launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);     // L: sum a_i * sum_delta_i (witness only)
         spmv(ctx, q.u_gate, q.a_mont.p, a_len, q.ue.p);
         spmv(ctx, q.v_gate, q.a_mont.p, a_len, q.ve.p);
         fr_pointwise_mul(ctx, q.ue.p, q.ve.p, q.x0.p, n);                 // U.V on <w>
-        ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients (bit-reversed order)
-        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
-        launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);                      // A
-        launch_dyn_after_a();
-        ntt_dif(ctx, q.ve.p, q.log_n, true, true);
+        ntt_dif(ctx, q.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);                     // B in G2
-        fr_scale_to_canonical(ctx, q.ve.p, r_mont, q.hb_can.p + n, n);    // r * v_i: B in G1 folded into the H product
+        launch(0, -1, crs.t_xi2, q.vc_can.p, n, &ms->b2);                 // B in G2: first in the accumulation chain
+        ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients
+        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
+        launch(2, 0, crs.t_xi1, q.uc_can.p, n, &ms->a);                   // A
+        launch(1, 2, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);   // L: sum a_i * sum_delta_i
+        // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
+        fr_lincomb_to_canonical(ctx, q.ve.p, r_mont, q.ue.p, s_mont, q.hb_can.p + n, n);
         ZK_HIP(hipMemcpyAsync(q.ug.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ZK_HIP(hipMemcpyAsync(q.vg.p, q.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ntt_dit(ctx, q.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
@@ -270,7 +240,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         Fr half = host_fr_from_u64(2).inv();
         h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.hb_can.p, n);
         // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
-        launch(4, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);                 // H + r B1
+        launch(4, 1, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
     } else {
         ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
         crs_ensure_tables(ctx, crs, false, 0);
@@ -279,16 +249,15 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         size_t nc = (size_t)1 << lc;
         q.ue.ensure(n); q.ve.ensure(n); q.wc.ensure(n); q.prod_a.ensure(nc); q.prod_b.ensure(nc);
         q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
-        launch(1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
         dense_matvec(ctx, q.du.p, q.a_mont.p, a_len, n, q.ue.p);
         dense_matvec(ctx, q.dv.p, q.a_mont.p, a_len, n, q.ve.p);
         dense_matvec(ctx, q.dw.p, q.a_mont.p, a_len, n, q.wc.p);
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(2, crs.t_xi1, q.uc_can.p, n, &ms->a);
-        launch_dyn_after_a();
-        launch(0, crs.t_xi2, q.vc_can.p, n, &ms->b2);
-        fr_scale_to_canonical(ctx, q.ve.p, r_mont, q.hb_can.p + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
+        launch(2, -1, crs.t_xi1, q.uc_can.p, n, &ms->a);
+        launch(0, -1, crs.t_xi2, q.vc_can.p, n, &ms->b2);
+        fr_lincomb_to_canonical(ctx, q.ve.p, r_mont, q.ue.p, s_mont, q.hb_can.p + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
         ZK_HIP(hipMemsetAsync(q.prod_a.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
         ZK_HIP(hipMemcpyAsync(q.prod_a.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -303,7 +272,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         size_t len_r = 2 * n - 1, d = q.t_degree;
         if (len_r > d) poly_divide(ctx, q.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, q.prod_b.p);
         fr_from_mont(ctx, q.prod_b.p, q.hb_can.p, n - 1);
-        launch(4, crs.t_hb1, q.hb_can.p, 2 * n - 1, &ms->hb);
+        launch(4, -1, crs.t_hb1, q.hb_can.p, 2 * n - 1, &ms->hb);
     }
     for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
 
@@ -339,7 +308,6 @@ void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int
     launch_pre(ctx, crs, ctx->stream, rc, sc, d_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, ctx->stream, (const uint8_t*)d_partials, world, d_ms.p);
     ZK_HIP(hipGetLastError());
-    launch_dyn(ctx, ctx->stream, d_ms.p, rc, sc, d_as.p);
     finish(ctx, crs, d_ms.p, d_as.p, d_proof.p, proof_out);
 }
 

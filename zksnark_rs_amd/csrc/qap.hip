@@ -199,6 +199,18 @@ void fr_scale_to_canonical(zk_ctx* ctx, const Fr* in, Fr k, Fr* out, size_t n) {
     ZK_HIP(hipGetLastError());
 }
 
+// out[i] = canonical(a[i] * ka + b[i] * kb)
+__global__ void k_lincomb_to_canonical(const Fr* __restrict__ a, Fr ka, const Fr* __restrict__ b, Fr kb, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (a[i] * ka + b[i] * kb).to_canonical();
+}
+void fr_lincomb_to_canonical(zk_ctx* ctx, const Fr* a, Fr ka, const Fr* b, Fr kb, Fr* out, size_t n) {
+    if (!n) return;
+    ProfScope ps(ctx, "fr_lincomb_to_canonical", 96.0 * n);
+    hipLaunchKernelGGL(k_lincomb_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, a, ka, b, kb, out, n);
+    ZK_HIP(hipGetLastError());
+}
+
 __global__ void k_sub_inplace(Fr* __restrict__ a, const Fr* __restrict__ b, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = a[i] - b[i];
