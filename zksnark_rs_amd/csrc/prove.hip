@@ -200,7 +200,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
     MsmResults* ms = d_ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
     // `after`: slot whose accumulation must finish first (-1: none).  The accumulation kernels are
-    // chained B2 -> A -> L -> H+rB1: the long G2 kernel runs while the rest of the NTT stage proceeds at
+    // chained (see the call sites): the long G2 kernel runs while the rest of the NTT stage proceeds at
     // high priority, its long reduction tail hides behind the G1 accumulations, and the last tail
     // exposed is the short G1 one.
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
@@ -218,16 +218,18 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         ntt_ensure_coset_tables(ctx, *tabs);
         q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
         q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
+        // accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
+        // ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
+        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);  // L: sum a_i * sum_delta_i
         spmv(ctx, q.u_gate, q.a_mont.p, a_len, q.ue.p);
         spmv(ctx, q.v_gate, q.a_mont.p, a_len, q.ve.p);
         fr_pointwise_mul(ctx, q.ue.p, q.ve.p, q.x0.p, n);                 // U.V on <w>
         ntt_dif(ctx, q.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
         fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(0, -1, crs.t_xi2, q.vc_can.p, n, &ms->b2);                 // B in G2: first in the accumulation chain
+        launch(0, 1, crs.t_xi2, q.vc_can.p, n, &ms->b2);                  // B in G2
         ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients
         fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
         launch(2, 0, crs.t_xi1, q.uc_can.p, n, &ms->a);                   // A
-        launch(1, 2, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);   // L: sum a_i * sum_delta_i
         // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
         fr_lincomb_to_canonical(ctx, q.ve.p, r_mont, q.ue.p, s_mont, q.hb_can.p + n, n);
         ZK_HIP(hipMemcpyAsync(q.ug.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -240,7 +242,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* 
         Fr half = host_fr_from_u64(2).inv();
         h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.hb_can.p, n);
         // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
-        launch(4, 1, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
+        launch(4, 2, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
     } else {
         ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
         crs_ensure_tables(ctx, crs, false, 0);
