@@ -31,14 +31,17 @@ namespace zk {
 
 #ifdef ZK_MSM_COMMON
 int msm_auto_window(size_t n) {
+    // The top window holds only 254 - (W-1) c bits; when that is 1-4 bits every scalar lands in the same
+    // handful of buckets of that window and a few lanes get n/4 additions each (profiles/
+    // r1_window_sweep_2p20.jsonl: c = 8, 10, 12, 14 are 6-15x slower than c = 13, 15, 16).  Pick from the
+    // window sizes whose top window is at least 6 bits wide.
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg;
-    if (c < 3) c = 3;
-    if (c > MSM_MAX_C) c = MSM_MAX_C;
-    return c;
+    if (lg >= 16) return 16;   // top window 14 bits
+    if (lg == 15) return 15;   // 14 bits
+    if (lg >= 11) return 13;   // 7 bits
+    return 8;                  // 6 bits
 }
-
 #endif  // ZK_MSM_COMMON
 
 constexpr int MSM_SEG = 8;       // buckets per lane in the running-sum reduction
