@@ -82,6 +82,21 @@ def cpu_baseline(zk, ctx, seed):
     }
 
 
+PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE in separate runs of this same command, profiles/r1_pmc_traffic.json; FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process, so this is
+    null when the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][PMC_KERNEL[name]]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +180,7 @@ def main():
             bytes_per_launch = e["algo_bytes"] / e["launches"]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
                         "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch,
                         "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
                         "note": "integer-ALU-bound kernel (254-bit modular multiply); HBM fraction is low by construction, see DESIGN.md"}
