@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260929)
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
+                    help="proofs in flight per GPU (zk_prove_submit/zk_prove_wait); 1 = synchronous zk_prove_dev")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,24 +138,33 @@ def main():
         prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
         bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
 
-    def step():
+    depth = 1 if shard else args.depth
+
+    def run(k):
+        """k proofs, all submitted and completed inside this call; returns their bytes."""
         if shard:
-            return prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs)
-        return ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"])
+            return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
+        if depth == 1:
+            return [ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
+        out, inflight = [], []
+        for _ in range(k):
+            if len(inflight) == depth:
+                out.append(ctx.prove_wait(inflight.pop(0)))
+            inflight.append(ctx.prove_submit(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]))
+        while inflight:
+            out.append(ctx.prove_wait(inflight.pop(0)))
+        return out
 
     proof = None
-    for _ in range(args.warmup):
-        proof = step()
+    for p in run(args.warmup):
+        proof = p
     ctx.set_option("profile", 1)
     ctx.profile_reset()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        p = step()
-        assert proof is None or p == proof, "non-deterministic proof bytes"
-        proof = p
+    proofs_out = run(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -164,6 +175,9 @@ def main():
         elapsed = float(t.item())
     prof = ctx.profile()
     ctx.set_option("profile", 0)
+    for p in proofs_out:
+        assert proof is None or p == proof, "non-deterministic proof bytes"
+        proof = p
 
     proofs = args.steps * (world if (world > 1 and not shard) else 1)
     value = proofs / elapsed
@@ -194,7 +208,7 @@ def main():
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM"
                                    % (args.log_n, m),
                        "parallelism": ("msm-window-shard x%d + RCCL all-gather" % world) if shard else ("replicas x%d" % world),
-                       "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
+                       "proofs_in_flight": depth, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},

@@ -184,6 +184,16 @@ int zk_prove(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* 
 int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                  const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
 
+/* Pipelined form of zk_prove_dev for a stream of proofs: zk_prove_submit enqueues the whole proof
+ * and returns at once with a ticket; zk_prove_wait blocks until that proof's bytes are ready.  At most
+ * two proofs may be in flight per context (a third submit returns ZK_ERR_ARG until one is waited for);
+ * the second proof's witness products and NTT stage then run under the first one's reduction tail.
+ * The witness buffer must stay valid and unmodified until the matching wait.  Errors that are only
+ * detected on the device (witness element >= r) are reported by zk_prove_wait. */
+int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                    const uint64_t r[4], const uint64_t s[4], int* ticket);
+int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t proof_out[ZK_PROOF_BYTES]);
+
 /* Multi-GPU: every rank holds the CRS and recomputes the NTT stage; rank g owns
  * Pippenger windows w = g (mod world) of each inner product and writes its partial sums
  * (Jacobian, device Montgomery limbs) to d_partial_out (ZK_PARTIAL_BYTES).  The caller all-gathers

@@ -118,6 +118,50 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     assert ctx.prove_dev(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]) == want
 
 
+def test_pipelined_submit_wait(ctx, orc):
+    """zk_prove_submit / zk_prove_wait: two proofs in flight, of different circuits, witnesses and
+    (r, s), give the same bytes as the synchronous call; a third submit is refused; a device-side
+    range error surfaces at wait and leaves the context usable."""
+    torch = pytest.importorskip("torch")
+    insts = [chain_instance(ctx, 12, 301), chain_instance(ctx, 9, 302)]
+    jobs = []
+    for inst in insts:
+        crs = ctx.setup(inst["qap"], inst["td"])
+        rng = SplitMix64(inst["log_n"])
+        for k in range(3):
+            w = inst["weights"].copy()
+            w[5, 0] ^= np.uint64(k)          # k != 0: unsatisfying witness, still a defined output
+            r, s = rng.fr(), rng.fr()
+            dw = torch.from_numpy(w.view(np.int64)).cuda()
+            jobs.append((crs, inst, dw, r, s, ctx.prove(crs, inst["qap"], w, r, s)))
+    assert jobs[0][5] == orc.trapdoor_proof_sparse(insts[0]["desc"], insts[0]["td"], insts[0]["weights"], jobs[0][3], jobs[0][4])
+    order = [0, 3, 1, 4, 2, 5, 0, 0, 3]      # alternate between the two circuits
+    inflight, got = [], []
+    for j in order:
+        crs, inst, dw, r, s, _ = jobs[j]
+        if len(inflight) == 2:
+            got.append(ctx.prove_wait(inflight.pop(0)))
+        inflight.append(ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s))
+    with pytest.raises(zk.ZkError):
+        crs, inst, dw, r, s, _ = jobs[0]
+        ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s)   # two already in flight
+    while inflight:
+        got.append(ctx.prove_wait(inflight.pop(0)))
+    assert got == [jobs[j][5] for j in order]
+    with pytest.raises(zk.ZkError):
+        ctx.prove_wait(0)                     # nothing in flight
+    # witness element >= r: reported by the wait, next proof unaffected
+    crs, inst, dw, r, s, want = jobs[0]
+    bad = inst["weights"].copy()
+    bad[4] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)
+    dbad = torch.from_numpy(bad.view(np.int64)).cuda()
+    t0 = ctx.prove_submit(crs, inst["qap"], dbad.data_ptr(), inst["m"], r, s)
+    t1 = ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s)
+    with pytest.raises(zk.ZkError):
+        ctx.prove_wait(t0)
+    assert ctx.prove_wait(t1) == want
+
+
 # ---- dense path: QAP<CoefficientPoly<FrLocal>> from .zk programs (roots 1..n) -----------------
 @pytest.mark.parametrize("prog", ["simple.zk", "lispesque_quad.zk", "lispesque_cubic.zk", "deg_15.zk"])
 def test_prove_zk_program_matches_faithful_oracle(ctx, orc, prog):

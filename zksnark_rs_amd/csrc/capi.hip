@@ -44,13 +44,10 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         // A and B1 (streams 2, 3) and the side stream that consumes them run at high priority so the
         // dynamic-base multiplications s*A, r*B1 start early and hide behind the other inner products
         ZK_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_greatest));
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->finish, hipStreamNonBlocking, prio_greatest));
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
-            ZK_HIP(hipEventCreateWithFlags(&ctx->msm_done[i], hipEventDisableTiming));
-            ZK_HIP(hipEventCreateWithFlags(&ctx->acc_evt[i], hipEventDisableTiming));
         }
-        ZK_HIP(hipEventCreateWithFlags(&ctx->fork_evt, hipEventDisableTiming));
-        ZK_HIP(hipEventCreateWithFlags(&ctx->ntt_done, hipEventDisableTiming));
         msm_set_lds_attributes();
     });
     if (rc != ZK_OK) { delete ctx; return rc; }
@@ -63,14 +60,12 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->ntt_tables.clear();
-    for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
-        ctx->msm_ws[i].reset();
-        if (ctx->msm_stream[i]) { (void)hipStreamSynchronize(ctx->msm_stream[i]); (void)hipStreamDestroy(ctx->msm_stream[i]); }
-        if (ctx->msm_done[i]) (void)hipEventDestroy(ctx->msm_done[i]);
-        if (ctx->acc_evt[i]) (void)hipEventDestroy(ctx->acc_evt[i]);
-    }
-    if (ctx->fork_evt) (void)hipEventDestroy(ctx->fork_evt);
-    if (ctx->ntt_done) (void)hipEventDestroy(ctx->ntt_done);
+    (void)hipDeviceSynchronize();
+    ctx->prove_state.reset();
+    ctx->msm_ws0.reset();
+    for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i)
+        if (ctx->msm_stream[i]) (void)hipStreamDestroy(ctx->msm_stream[i]);
+    if (ctx->finish) (void)hipStreamDestroy(ctx->finish);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -182,6 +177,15 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !proof_out) return ZK_ERR_ARG;
     return guarded(ctx, [&] { prove_dev(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, proof_out, 0, 1, nullptr); ctx->resolve_profile(); });
 }
+int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                    const uint64_t r[4], const uint64_t s[4], int* ticket) {
+    if (!ctx || !crs || !qap || !d_weights || !r || !s || !ticket) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, 0, 1, nullptr); });
+}
+int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!ctx || !proof_out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_wait(ctx, ticket, proof_out); });
+}
 int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                      const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out) {
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
@@ -195,7 +199,7 @@ int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int
 
 int zk_profile_reset(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_ARG;
-    return guarded(ctx, [&] { ZK_HIP(hipStreamSynchronize(ctx->stream)); ctx->resolve_profile(); ctx->prof.clear(); });
+    return guarded(ctx, [&] { ZK_HIP(hipDeviceSynchronize()); ctx->resolve_profile(-2); ctx->prof.clear(); });
 }
 int zk_profile_count(const zk_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
 int zk_profile_entry(const zk_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches, double* algo_bytes) {

@@ -74,17 +74,22 @@ struct PendingEvent {
     std::string name;
     hipEvent_t e0, e1;
     double bytes;
+    int slot;     // in-flight proof the launch belongs to (-1: none)
 };
 
 struct NttTables;  // ntt.hip
 struct MsmWorkspace;  // kernels.hpp
+struct ProveState;    // prove.hip
 
 }  // namespace zk
 
 struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;  // side stream for latency-bound tails
+    hipStream_t side = nullptr;    // side stream for the r/s-only fixed-base multiplications
+    hipStream_t finish = nullptr;  // join + assembly + copy-out of a proof
+    std::shared_ptr<zk::ProveState> prove_state;
+    int cur_slot = -1;
     std::string last_error;
     long opt_window_bits = 0;
     long opt_profile = 0;
@@ -95,12 +100,8 @@ struct zk_ctx {
     std::vector<hipEvent_t> event_pool;
     std::map<unsigned, std::shared_ptr<zk::NttTables>> ntt_tables;
     static constexpr int MSM_STREAMS = 5;
-    std::shared_ptr<zk::MsmWorkspace> msm_ws[MSM_STREAMS];
+    std::shared_ptr<zk::MsmWorkspace> msm_ws0;   // workspace of the stand-alone zk_msm_* entry points
     hipStream_t msm_stream[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t msm_done[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_evt = nullptr;
-    hipEvent_t ntt_done = nullptr;
-    hipEvent_t acc_evt[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // end of each accumulation (chain)
     int cu_count = 256;
 
     hipEvent_t get_event() {
@@ -109,9 +110,12 @@ struct zk_ctx {
         ZK_HIP(hipEventCreate(&e));
         return e;
     }
-    // resolves pending event pairs (call after the stream is synchronised)
-    void resolve_profile() {
+    // resolves the pending event pairs of one in-flight proof (-1: launches outside any proof; -2: all);
+    // call after the work they bracket is known to be complete
+    void resolve_profile(int slot = -1) {
+        std::vector<zk::PendingEvent> keep;
         for (auto& pe : pending) {
+            if (slot >= -1 && pe.slot != slot) { keep.push_back(pe); continue; }
             float ms = 0;
             if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
                 auto& e = prof[pe.name];
@@ -122,7 +126,7 @@ struct zk_ctx {
             event_pool.push_back(pe.e0);
             event_pool.push_back(pe.e1);
         }
-        pending.clear();
+        pending.swap(keep);
     }
 };
 
@@ -138,6 +142,7 @@ struct ProfScope {
         if (on) {
             pe.name = name;
             pe.bytes = algo_bytes;
+            pe.slot = c->cur_slot;
             pe.e0 = ctx->get_event();
             pe.e1 = ctx->get_event();
             (void)hipEventRecord(pe.e0, st);

@@ -382,8 +382,8 @@ void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
     int c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(n));
     MsmTable<F> tab;
     msm_build_table<F>(ctx, dp.p, n, c, tab);
-    if (!ctx->msm_ws[0]) ctx->msm_ws[0] = std::make_shared<MsmWorkspace>();
-    msm_run<F>(ctx, *ctx->msm_ws[0], st, tab, ds.p, n, 0, 1, dres.p);
+    if (!ctx->msm_ws0) ctx->msm_ws0 = std::make_shared<MsmWorkspace>();
+    msm_run<F>(ctx, *ctx->msm_ws0, st, tab, ds.p, n, 0, 1, dres.p);
     hipLaunchKernelGGL(k_jac_to_affine_canonical<F>, dim3(1), dim3(64), 0, st, dres.p, daff.p, 1);
     ZK_HIP(hipGetLastError());
     int hflag = 0;

@@ -27,8 +27,6 @@ struct zk_qap {
     size_t t_degree = 0;      // actual degree of t (dense)
     zk::DevBuf<zk::Fr> t_cinv; // 1 / leading coefficient of t (dense)
     bool t_is_zero = false;
-    // scratch reused across proofs
-    zk::DevBuf<zk::Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b;
 };
 
 struct zk_crs {
@@ -76,6 +74,9 @@ void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, 
 // finished locally (world must be 1); otherwise the five partial sums are written there.
 void prove_dev(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
                uint8_t* proof_out, int rank, int world, void* d_partial_out);
+int prove_submit(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
+                 int rank, int world, void* d_partial_out);
+void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
 void prove_combine(zk_ctx*, const zk_crs&, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
 
 }  // namespace zk

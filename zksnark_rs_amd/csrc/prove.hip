@@ -14,6 +14,7 @@
 //   a, b, c assembly with r, s            :274-293   one small kernel; scalar mults by r, s
 //
 // (r, s) are injected: the reference draws them from thread_rng (mod.rs:231).
+#include <cstring>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
 
@@ -148,149 +149,214 @@ struct AssembleScratch {
     AssemblePre pre;
 };
 
+// ---- pipeline state: everything one in-flight proof owns ---------------------------------------
+// Two slots let zk_prove_submit enqueue proof k+1 (its sorting / NTT stage / first accumulation)
+// while the latency-bound tail of proof k (reductions, assembly, copy-out) is still running.
+struct ProveSlot {
+    DevBuf<Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b;
+    MsmWorkspace ws[zk_ctx::MSM_STREAMS];
+    DevBuf<MsmResults> ms;
+    DevBuf<AssembleScratch> as;
+    DevBuf<uint8_t> d_proof;
+    DevBuf<int> flag;
+    uint8_t* h_proof = nullptr;    // pinned
+    int* h_flag = nullptr;         // pinned
+    hipEvent_t fork_evt = nullptr, pre_evt = nullptr, done_evt = nullptr;
+    hipEvent_t msm_done[zk_ctx::MSM_STREAMS] = {}, acc_evt[zk_ctx::MSM_STREAMS] = {};
+    bool busy = false, partial = false;
+    void init() {
+        ms.alloc(1); as.alloc(1); d_proof.alloc(ZK_PROOF_BYTES); flag.alloc(1);
+        ZK_HIP(hipHostMalloc((void**)&h_proof, ZK_PROOF_BYTES));
+        ZK_HIP(hipHostMalloc((void**)&h_flag, sizeof(int)));
+        ZK_HIP(hipEventCreateWithFlags(&fork_evt, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&pre_evt, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&done_evt, hipEventDisableTiming));
+        for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
+            ZK_HIP(hipEventCreateWithFlags(&msm_done[k], hipEventDisableTiming));
+            ZK_HIP(hipEventCreateWithFlags(&acc_evt[k], hipEventDisableTiming));
+        }
+    }
+    ~ProveSlot() {
+        if (h_proof) (void)hipHostFree(h_proof);
+        if (h_flag) (void)hipHostFree(h_flag);
+        for (hipEvent_t e : {fork_evt, pre_evt, done_evt}) if (e) (void)hipEventDestroy(e);
+        for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
+            if (msm_done[k]) (void)hipEventDestroy(msm_done[k]);
+            if (acc_evt[k]) (void)hipEventDestroy(acc_evt[k]);
+        }
+    }
+};
+struct ProveState {
+    static constexpr int SLOTS = 2;
+    ProveSlot slot[SLOTS];
+    int next = 0;
+    hipEvent_t last_acc = nullptr;   // end of the most recently enqueued accumulation chain
+    ProveState() { for (auto& s : slot) s.init(); }
+};
+
+static ProveState& prove_state(zk_ctx* ctx) {
+    if (!ctx->prove_state) ctx->prove_state = std::make_shared<ProveState>();
+    return *ctx->prove_state;
+}
+
 static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
     hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
     ZK_HIP(hipGetLastError());
 }
-// final additions + affine normalisation + canonical encoding, then copy the 259 bytes out
-static void finish(zk_ctx* ctx, const zk_crs& crs, const MsmResults* d_ms, AssembleScratch* d_as, uint8_t* d_proof, uint8_t* proof_out) {
-    hipStream_t st = ctx->stream;
-    {
-        ProfScope ps(ctx, "assemble", 0);
-        hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms, &d_as->pre, crs.alpha1.p, crs.beta2.p, d_proof);
-    }
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(proof_out, d_proof, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
-    ZK_HIP(hipStreamSynchronize(st));
-}
 
-void prove_dev(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* d_weights, size_t m_in, const uint64_t* r, const uint64_t* s,
-               uint8_t* proof_out, int rank, int world, void* d_partial_out) {
-    zk_crs& crs = const_cast<zk_crs&>(crs_c);   // lazily built caches / scratch only
-    zk_qap& q = const_cast<zk_qap&>(qap_c);
+// Enqueues one proof (or one rank's partial sums) and returns without waiting.  ticket = slot index.
+int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* d_weights, size_t m_in, const uint64_t* r, const uint64_t* s,
+                 int rank, int world, void* d_partial_out) {
+    zk_crs& crs = const_cast<zk_crs&>(crs_c);   // lazily built tables only
+    const zk_qap& q = qap_c;
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
     ZK_REQUIRE(d_partial_out || world == 1, ZK_ERR_ARG, "prove: world > 1 needs a partial output buffer");
+    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
+    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+    ZK_REQUIRE(!q.dense || !q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
+    const Fr r_mont = Fr::from_canonical(rc), s_mont = Fr::from_canonical(sc);
+    ProveState& ps = prove_state(ctx);
+    const int ticket = ps.next;
+    ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: more than two proofs in flight (call zk_prove_wait first)");
+    // one-off table construction happens before anything of this proof is enqueued
+    if (!q.dense) crs_ensure_tables(ctx, crs, true, q.log_n); else crs_ensure_tables(ctx, crs, false, 0);
+    if (!d_partial_out) crs_ensure_fixed_tables(ctx, crs);
+
     const size_t n = q.n, m = q.m, l = q.input;
     const size_t a_len = std::min(m_in, m);   // zip(weights) truncates (mod.rs:233-253)
     hipStream_t st = ctx->stream;
+    ctx->cur_slot = ticket;
+    S.partial = d_partial_out != nullptr;
 
-    DevBuf<int> flag(1);
-    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
-    q.a_mont.ensure(std::max<size_t>(a_len, 1));
-    fr_to_mont(ctx, d_weights, q.a_mont.p, a_len, flag.p);
+    ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
+    S.a_mont.ensure(std::max<size_t>(a_len, 1));
+    fr_to_mont(ctx, d_weights, S.a_mont.p, a_len, S.flag.p);
 
-    // the r/s-only fixed-base multiplications overlap with everything below on the side stream
-    DevBuf<AssembleScratch> d_as(1);
-    DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
-    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
-    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
-    const Fr r_mont = Fr::from_canonical(rc), s_mont = Fr::from_canonical(sc);
-    hipEvent_t pre_evt = nullptr;
+    // the r/s-only fixed-base multiplications run on the side stream beside everything below
     if (!d_partial_out) {
-        crs_ensure_fixed_tables(ctx, crs);
-        pre_evt = ctx->get_event();
-        launch_pre(ctx, crs, ctx->side, rc, sc, d_as.p);
-        ZK_HIP(hipEventRecord(pre_evt, ctx->side));
+        launch_pre(ctx, crs, ctx->side, rc, sc, S.as.p);
+        ZK_HIP(hipEventRecord(S.pre_evt, ctx->side));
     }
 
-    // The five inner products run on their own streams; each is forked from the main stream as
-    // soon as its scalars exist (L needs only the witness, A only sum a_i u_i, ...), so the NTT stage
-    // and the latency-bound reduction tails hide behind bucket accumulation.  Joined before assembly.
-    DevBuf<MsmResults> d_ms(1);
-    MsmResults* ms = d_ms.p;
+    // The inner products run on their own streams, each forked from the main stream as soon as its
+    // scalars exist.  `after`: MSM slot whose accumulation must finish first (-1: the previous proof's
+    // chain).  The accumulation kernels each fill every SIMD, so they are chained in a chosen order
+    // instead of thrashing each other; sorting phases and reduction tails overlap freely.
+    MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    // `after`: slot whose accumulation must finish first (-1: none).  The accumulation kernels are
-    // chained (see the call sites): the long G2 kernel runs while the rest of the NTT stage proceeds at
-    // high priority, its long reduction tail hides behind the G1 accumulations, and the last tail
-    // exposed is the short G1 one.
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
         hipStream_t ms_st = ctx->msm_stream[k];
-        if (!ctx->msm_ws[k]) ctx->msm_ws[k] = std::make_shared<MsmWorkspace>();
-        ZK_HIP(hipEventRecord(ctx->fork_evt, st));
-        ZK_HIP(hipStreamWaitEvent(ms_st, ctx->fork_evt, 0));
-        msm_run(ctx, *ctx->msm_ws[k], ms_st, table, scalars, count, rank, world, out,
-                after >= 0 ? ctx->acc_evt[after] : (after == -2 ? ctx->ntt_done : nullptr), ctx->acc_evt[k]);
-        ZK_HIP(hipEventRecord(ctx->msm_done[k], ms_st));
+        ZK_HIP(hipEventRecord(S.fork_evt, st));
+        ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
+        msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, after >= 0 ? S.acc_evt[after] : ps.last_acc, S.acc_evt[k]);
+        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        ps.last_acc = S.acc_evt[k];
     };
     if (!q.dense) {
-        crs_ensure_tables(ctx, crs, true, q.log_n);
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
-        q.ue.ensure(n); q.ve.ensure(n); q.x0.ensure(n); q.y0.ensure(n); q.ug.ensure(n); q.vg.ensure(n);
-        q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
+        S.ue.ensure(n); S.ve.ensure(n); S.x0.ensure(n); S.y0.ensure(n); S.ug.ensure(n); S.vg.ensure(n);
+        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
         // accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
         // ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);  // L: sum a_i * sum_delta_i
-        spmv(ctx, q.u_gate, q.a_mont.p, a_len, q.ue.p);
-        spmv(ctx, q.v_gate, q.a_mont.p, a_len, q.ve.p);
-        fr_pointwise_mul(ctx, q.ue.p, q.ve.p, q.x0.p, n);                 // U.V on <w>
-        ntt_dif(ctx, q.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
-        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(0, 1, crs.t_xi2, q.vc_can.p, n, &ms->b2);                  // B in G2
-        ntt_dif(ctx, q.ue.p, q.log_n, true, true);                        // U coefficients
-        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
-        launch(2, 0, crs.t_xi1, q.uc_can.p, n, &ms->a);                   // A
+        spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.ue.p);
+        spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.ve.p);
+        fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n);                 // U.V on <w>
+        ntt_dif(ctx, S.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
+        fr_from_mont(ctx, S.ve.p, S.vc_can.p, n);
+        launch(0, 1, crs.t_xi2, S.vc_can.p, n, &ms->b2);                  // B in G2
+        ntt_dif(ctx, S.ue.p, q.log_n, true, true);                        // U coefficients
+        fr_from_mont(ctx, S.ue.p, S.uc_can.p, n);
+        launch(2, 0, crs.t_xi1, S.uc_can.p, n, &ms->a);                   // A
         // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-        fr_lincomb_to_canonical(ctx, q.ve.p, r_mont, q.ue.p, s_mont, q.hb_can.p + n, n);
-        ZK_HIP(hipMemcpyAsync(q.ug.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ZK_HIP(hipMemcpyAsync(q.vg.p, q.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ntt_dit(ctx, q.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
-        ntt_dit(ctx, q.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p);
-        fr_pointwise_mul(ctx, q.ug.p, q.vg.p, q.y0.p, n);                 // U.V on g<w>
-        ntt_dif(ctx, q.x0.p, q.log_n, true, true);                        // lo + hi
-        ntt_dif(ctx, q.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
+        fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, S.hb_can.p + n, n);
+        ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
+        ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p);
+        fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n);                 // U.V on g<w>
+        ntt_dif(ctx, S.x0.p, q.log_n, true, true);                        // lo + hi
+        ntt_dif(ctx, S.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
         Fr half = host_fr_from_u64(2).inv();
-        h_combine(ctx, q.x0.p, q.y0.p, tabs->coset_inv_brev_half.p, half, q.hb_can.p, n);
+        h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, S.hb_can.p, n);
         // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
-        launch(4, 2, crs.t_hb1, q.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
+        launch(4, 2, crs.t_hb1, S.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
     } else {
-        ZK_REQUIRE(!q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
-        crs_ensure_tables(ctx, crs, false, 0);
         unsigned lc = 1;
         while (((size_t)1 << lc) < 2 * n) ++lc;
         size_t nc = (size_t)1 << lc;
-        q.ue.ensure(n); q.ve.ensure(n); q.wc.ensure(n); q.prod_a.ensure(nc); q.prod_b.ensure(nc);
-        q.uc_can.ensure(n); q.vc_can.ensure(n); q.hb_can.ensure(2 * n);
+        S.ue.ensure(n); S.ve.ensure(n); S.wc.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
+        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        dense_matvec(ctx, q.du.p, q.a_mont.p, a_len, n, q.ue.p);
-        dense_matvec(ctx, q.dv.p, q.a_mont.p, a_len, n, q.ve.p);
-        dense_matvec(ctx, q.dw.p, q.a_mont.p, a_len, n, q.wc.p);
-        fr_from_mont(ctx, q.ue.p, q.uc_can.p, n);
-        fr_from_mont(ctx, q.ve.p, q.vc_can.p, n);
-        launch(2, -1, crs.t_xi1, q.uc_can.p, n, &ms->a);
-        launch(0, -1, crs.t_xi2, q.vc_can.p, n, &ms->b2);
-        fr_lincomb_to_canonical(ctx, q.ve.p, r_mont, q.ue.p, s_mont, q.hb_can.p + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
-        ZK_HIP(hipMemsetAsync(q.prod_a.p, 0, nc * sizeof(Fr), st));
-        ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
-        ZK_HIP(hipMemcpyAsync(q.prod_a.p, q.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ZK_HIP(hipMemcpyAsync(q.prod_b.p, q.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ntt_dif(ctx, q.prod_a.p, lc, false, false);
-        ntt_dif(ctx, q.prod_b.p, lc, false, false);
-        fr_pointwise_mul(ctx, q.prod_a.p, q.prod_b.p, q.prod_a.p, nc);
-        ntt_dit(ctx, q.prod_a.p, lc, true, true, nullptr);                // U*V coefficients, natural order
-        fr_sub_inplace(ctx, q.prod_a.p, q.wc.p, n);                       // - W
+        dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
+        dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
+        dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
+        fr_from_mont(ctx, S.ue.p, S.uc_can.p, n);
+        fr_from_mont(ctx, S.ve.p, S.vc_can.p, n);
+        launch(2, 1, crs.t_xi1, S.uc_can.p, n, &ms->a);
+        launch(0, 2, crs.t_xi2, S.vc_can.p, n, &ms->b2);
+        fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, S.hb_can.p + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
+        ZK_HIP(hipMemsetAsync(S.prod_a.p, 0, nc * sizeof(Fr), st));
+        ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
+        ZK_HIP(hipMemcpyAsync(S.prod_a.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ZK_HIP(hipMemcpyAsync(S.prod_b.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ntt_dif(ctx, S.prod_a.p, lc, false, false);
+        ntt_dif(ctx, S.prod_b.p, lc, false, false);
+        fr_pointwise_mul(ctx, S.prod_a.p, S.prod_b.p, S.prod_a.p, nc);
+        ntt_dit(ctx, S.prod_a.p, lc, true, true, nullptr);                // U*V coefficients, natural order
+        fr_sub_inplace(ctx, S.prod_a.p, S.wc.p, n);                       // - W
         // quotient by t (degree d); remainder dropped (coefficient_poly.rs:148-157)
-        ZK_HIP(hipMemsetAsync(q.prod_b.p, 0, nc * sizeof(Fr), st));
+        ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
-        if (len_r > d) poly_divide(ctx, q.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, q.prod_b.p);
-        fr_from_mont(ctx, q.prod_b.p, q.hb_can.p, n - 1);
-        launch(4, -1, crs.t_hb1, q.hb_can.p, 2 * n - 1, &ms->hb);
+        if (len_r > d) poly_divide(ctx, S.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, S.prod_b.p);
+        fr_from_mont(ctx, S.prod_b.p, S.hb_can.p, n - 1);
+        launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }
-    for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) ZK_HIP(hipStreamWaitEvent(st, ctx->msm_done[k], 0));
 
-    int hflag = 0;
-    ZK_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof
+    hipStream_t fin = ctx->finish;
+    ZK_HIP(hipEventRecord(S.fork_evt, st));
+    ZK_HIP(hipStreamWaitEvent(fin, S.fork_evt, 0));
+    for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k)
+        if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
     if (d_partial_out) {
-        ZK_HIP(hipMemsetAsync(d_partial_out, 0, ZK_PARTIAL_BYTES, st));
-        ZK_HIP(hipMemcpyAsync(d_partial_out, ms, sizeof(MsmResults), hipMemcpyDeviceToDevice, st));
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "prove: witness element >= r");
-        return;
+        ZK_HIP(hipMemsetAsync(d_partial_out, 0, ZK_PARTIAL_BYTES, fin));
+        ZK_HIP(hipMemcpyAsync(d_partial_out, ms, sizeof(MsmResults), hipMemcpyDeviceToDevice, fin));
+    } else {
+        ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
+        {
+            ProfScope pscope(ctx, "assemble", 0, fin);
+            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
+        }
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
     }
-    ZK_HIP(hipStreamWaitEvent(st, pre_evt, 0));
-    ctx->event_pool.push_back(pre_evt);
-    finish(ctx, crs, ms, d_as.p, d_proof.p, proof_out);
-    ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "prove: witness element >= r");
+    ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
+    ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.busy = true;
+    ctx->cur_slot = -1;
+    ps.next = (ticket + 1) % ProveState::SLOTS;
+    return ticket;
+}
+
+// Waits for a submitted proof; proof_out may be null for partial submissions.
+void prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
+    ProveState& ps = prove_state(ctx);
+    ZK_REQUIRE(ticket >= 0 && ticket < ProveState::SLOTS && ps.slot[ticket].busy, ZK_ERR_ARG, "prove_wait: no proof in flight for this ticket");
+    ProveSlot& S = ps.slot[ticket];
+    S.busy = false;
+    ZK_HIP(hipEventSynchronize(S.done_evt));
+    ctx->resolve_profile(ticket);
+    ZK_REQUIRE(!*S.h_flag, ZK_ERR_RANGE, "prove: witness element >= r");
+    if (!S.partial && proof_out) std::memcpy(proof_out, S.h_proof, ZK_PROOF_BYTES);
+}
+
+void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
+               uint8_t* proof_out, int rank, int world, void* d_partial_out) {
+    int t = prove_submit(ctx, crs, qap, d_weights, m, r, s, rank, world, d_partial_out);
+    prove_wait(ctx, t, proof_out);
 }
 
 void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
@@ -307,10 +373,13 @@ void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int
     DevBuf<MsmResults> d_ms(1);
     DevBuf<AssembleScratch> d_as(1);
     DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
-    launch_pre(ctx, crs, ctx->stream, rc, sc, d_as.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, ctx->stream, (const uint8_t*)d_partials, world, d_ms.p);
+    hipStream_t st = ctx->stream;
+    launch_pre(ctx, crs, st, rc, sc, d_as.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, d_ms.p);
+    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms.p, &d_as.p->pre, crs.alpha1.p, crs.beta2.p, d_proof.p);
     ZK_HIP(hipGetLastError());
-    finish(ctx, crs, d_ms.p, d_as.p, d_proof.p, proof_out);
+    ZK_HIP(hipMemcpyAsync(proof_out, d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
 }
 
 }  // namespace zk
