@@ -198,9 +198,8 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     const uint32_t hi = start[b + 1], stride = 1u << log_lanes;
     typedef typename LazyOf<F>::type L;
     // accumulator and temporaries live in the multiplier's radix (lazy29.cuh) for the whole bucket
-    JacR<F> acc;
-    acc.inf = true;
-    acc.X = acc.Y = acc.Z = L::load(F::zero());
+    typename AccOf<F>::type acc;
+    acc_clear(acc);
     // software pipeline: the next point's gather (a random line of a multi-GiB table) and the
     // index after it are in flight while the current addition executes
     uint32_t k = start[b] + t;
@@ -214,11 +213,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         if (!p.is_inf()) {
             L qx = L::load(p.x), qy = L::load(p.y);
             if (e & 1) qy = qy.neg();
-            if (!madd_lazy<F>(acc, qx, qy)) {
+            if (!acc_madd(acc, qx, qy)) {
                 // same point twice in one bucket: doubling through the generic formulas (rare)
-                Jac<F> j = jac_dbl(Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()});
-                acc.X = L::load(j.X); acc.Y = L::load(j.Y); acc.Z = L::load(j.Z);
-                acc.inf = j.is_inf();
+                acc_load(acc, jac_dbl(acc_store(acc)));
             }
         }
         p = p_next;
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         e_next = e_next2;
         k = kn;
     }
-    partial[tid] = acc.inf ? Jac<F>::infinity() : Jac<F>{acc.X.store_exact(), acc.Y.store_exact(), acc.Z.store_exact()};
+    partial[tid] = acc_store(acc);
 }
 
 // S_b = sum_t partial[b][t]
