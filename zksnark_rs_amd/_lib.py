@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+LIB_PATH = os.environ.get("ZKGPU_LIB") or os.path.join(_HERE, "libzkgpu.so")   # ZKGPU_LIB: experiment builds only
 
 ZK_OK = 0
 ZK_ERR_ARG, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_SIZE, ZK_ERR_DIV_BY_ZERO, ZK_ERR_RANGE, ZK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7

@@ -22,6 +22,12 @@
 #pragma once
 #include "ec.cuh"
 
+// independent 64-bit accumulation chains per product column of the Montgomery multiplier
+// (3: even / odd partial products and the reduction terms; 2: products / reduction; 1: one chain)
+#ifndef ZK_MONT_CHAINS
+#define ZK_MONT_CHAINS 2
+#endif
+
 namespace zk {
 
 template <class PR>
@@ -82,6 +88,7 @@ struct FpR {
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
             const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+#if ZK_MONT_CHAINS == 3
             int64_t acc0 = carry, acc1 = 0, acc2 = 0;
             if (SQR) {
 #pragma unroll
@@ -98,6 +105,32 @@ struct FpR {
             for (int i = lo; i <= hi; ++i)
                 if (i < k || k >= 9) acc2 += (int64_t)m[i] * (int32_t)PR::P29[k - i];
             int64_t acc = acc0 + acc1 + acc2;
+#else
+            int64_t acc0 = carry, acc2 = 0;
+            if (SQR) {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) {
+                    const int j = k - i;
+                    if (i < j) acc0 += (int64_t)a2[i] * a.v[j];
+                    else if (i == j) acc0 += (int64_t)a.v[i] * a.v[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = lo; i <= hi; ++i) acc0 += (int64_t)a.v[i] * b.v[k - i];
+            }
+#if ZK_MONT_CHAINS == 2
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i < k || k >= 9) acc2 += (int64_t)m[i] * (int32_t)PR::P29[k - i];
+            int64_t acc = acc0 + acc2;
+#else
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i < k || k >= 9) acc0 += (int64_t)m[i] * (int32_t)PR::P29[k - i];
+            int64_t acc = acc0;
+            (void)acc2;
+#endif
+#endif
             if (k < 9) {
                 m[k] = (int32_t)(((uint32_t)acc * PR::INV29) & (uint32_t)M29);
                 acc += (int64_t)m[k] * (int32_t)PR::P29[0];
@@ -204,15 +237,59 @@ struct Fp2R {
     ZK_HD Fp2R neg() const { return Fp2R{c0.neg(), c1.neg()}; }
     ZK_HD Fp2R norm() const { return Fp2R{c0.norm(), c1.norm()}; }
     // operands: components with |limb| < 2^29 (normal forms or differences of two normal forms)
+    // (a0 + a1 i)(b0 + b1 i) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) i with the two coordinates reduced side by
+    // side: 4 x 81 product terms accumulate straight into the two column sums and only 2 x 81 reduction
+    // terms follow.  Same multiply-add count as Karatsuba's three full multiplications (486), but none
+    // of its limb-wise additions, normalisations and per-multiplication column overhead -- which at
+    // this size cost as much as the 81 multiply-adds Karatsuba saves.
+    // Columns: 18 products < 2^58 + 9 reduction terms < 2^58 + carry < 2^63.  Output in normal form,
+    // |value| < 2 (8p)^2 / 2^261 + p < 2p.
     ZK_HD Fp2R operator*(const Fp2R& o) const {
-        FpR<PR> aa = c0 * o.c0, bb = c1 * o.c1;
-        FpR<PR> s = (c0 + c1).norm() * (o.c0 + o.c1);   // one side normalised: (N) x (|limb| < 2^30)
-        return Fp2R{(aa - bb).norm(), (s - aa - bb).norm()};
+        typedef FpR<PR> L;
+        int32_t m0[9], m1[9], nb1[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nb1[i] = -o.c1.v[i];
+        Fp2R r;
+        int64_t carry0 = 0, carry1 = 0;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+            int64_t p0 = carry0, p1 = carry1, q0 = 0, q1 = 0;
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) {
+                p0 += (int64_t)c0.v[i] * o.c0.v[k - i];
+                p0 += (int64_t)c1.v[i] * nb1[k - i];
+                p1 += (int64_t)c0.v[i] * o.c1.v[k - i];
+                p1 += (int64_t)c1.v[i] * o.c0.v[k - i];
+            }
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (i < k || k >= 9) {
+                    q0 += (int64_t)m0[i] * (int32_t)PR::P29[k - i];
+                    q1 += (int64_t)m1[i] * (int32_t)PR::P29[k - i];
+                }
+            int64_t acc0 = p0 + q0, acc1 = p1 + q1;
+            if (k < 9) {
+                m0[k] = (int32_t)(((uint32_t)acc0 * PR::INV29) & (uint32_t)L::M29);
+                m1[k] = (int32_t)(((uint32_t)acc1 * PR::INV29) & (uint32_t)L::M29);
+                acc0 += (int64_t)m0[k] * (int32_t)PR::P29[0];
+                acc1 += (int64_t)m1[k] * (int32_t)PR::P29[0];
+            } else {
+                r.c0.v[k - 9] = (int32_t)((uint32_t)acc0 & (uint32_t)L::M29);
+                r.c1.v[k - 9] = (int32_t)((uint32_t)acc1 & (uint32_t)L::M29);
+            }
+            carry0 = acc0 >> 29;
+            carry1 = acc1 >> 29;
+        }
+        r.c0.v[8] = (int32_t)carry0;
+        r.c1.v[8] = (int32_t)carry1;
+        ZK_SCHED_FENCE();
+        return r;
     }
+    // (a0 + a1)(a0 - a1) + 2 a0 a1 i; the doubled limbs (<= 2^30) sit on one side of the second product
     ZK_HD Fp2R sqr() const {
-        FpR<PR> ab = c0 * c1;
         FpR<PR> d = (c0 + c1).norm() * (c0 - c1);       // (N) x (|limb| < 2^30)
-        return Fp2R{d, (ab + ab).norm()};
+        return Fp2R{d, (c0 + c0) * c1};
     }
     ZK_HD bool is_zero_mod_p() const { return c0.is_zero_mod_p() && c1.is_zero_mod_p(); }
     ZK_HD Fq2 store_exact() const { return Fq2{c0.store_exact(), c1.store_exact()}; }
@@ -242,7 +319,7 @@ template <class F>
 ZK_HD bool madd_lazy(JacR<F>& p, const typename LazyOf<F>::type& qx, const typename LazyOf<F>::type& qy) {
     typedef typename LazyOf<F>::type L;
     if (p.inf) {
-        p.X = qx; p.Y = qy; p.inf = false;
+        p.X = qx; p.Y = qy.norm(); p.inf = false;   // qy may be a negated point (limbs <= 0): R = S2 - Y1 must stay below 2^29
         // Z = 1 in Montgomery form
         p.Z = L::load(F::one());
         return true;
@@ -286,7 +363,7 @@ template <class PR>
 ZK_HD bool madd_xyzz(XyzzR<PR>& p, const FpR<PR>& qx, const FpR<PR>& qy) {
     typedef FpR<PR> L;
     if (p.inf) {
-        p.X = qx; p.Y = qy; p.inf = false;
+        p.X = qx; p.Y = qy.norm(); p.inf = false;   // qy may be a negated point (limbs <= 0): R = S2 - Y1 must stay below 2^29
         p.ZZ = p.ZZZ = L::load(Fp<PR>::one());
         return true;
     }
