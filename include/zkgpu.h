@@ -58,7 +58,9 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
-/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lds_buckets" (0/1), "profile" (0/1) */
+/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (bucket lists are split over
+ * more lanes while each lane keeps at least this many additions; default 24), "profile" (0/1: per-kernel
+ * event timing, read back with zk_profile_*).  Unknown keys return ZK_ERR_UNSUPPORTED. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);
 

@@ -78,8 +78,7 @@ const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_st
 static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_window_bits")) return &ctx->opt_window_bits;
     if (!std::strcmp(key, "profile")) return &ctx->opt_profile;
-    if (!std::strcmp(key, "msm_precompute")) return &ctx->opt_precompute;
-    if (!std::strcmp(key, "msm_balance")) return &ctx->opt_balance;
+    if (!std::strcmp(key, "msm_lane_entries")) return &ctx->opt_lane_entries;
     return nullptr;
 }
 int zk_set_option(zk_ctx* ctx, const char* key, long value) {

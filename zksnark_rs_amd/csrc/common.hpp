@@ -93,8 +93,7 @@ struct zk_ctx {
     std::string last_error;
     long opt_window_bits = 0;
     long opt_profile = 0;
-    long opt_precompute = 1;
-    long opt_balance = 1;
+    long opt_lane_entries = 24;   // lanes per bucket are doubled while each lane keeps at least this many additions
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;

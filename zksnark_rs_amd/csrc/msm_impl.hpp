@@ -290,10 +290,11 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
-    // lanes per bucket: aim at ~32 entries per lane
+    // lanes per bucket: split while every lane keeps at least opt_lane_entries additions on average
     size_t entries = (size_t)owned * n_used;
     int log_lanes = 0;
-    while (log_lanes < 6 && (entries >> (log_lanes + 1)) / buckets >= 24) ++log_lanes;
+    const size_t min_per_lane = (size_t)std::max<long>(ctx->opt_lane_entries, 1);
+    while (log_lanes < 6 && (entries >> (log_lanes + 1)) / buckets >= min_per_lane) ++log_lanes;
     const int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
 
     ws.hist.ensure((size_t)chunks * buckets);
