@@ -46,7 +46,7 @@ void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
 void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
 
 // ---- msm.hip ----
-constexpr int MSM_MAX_C = 16;   // 2^(c-1) LDS counters per sorting workgroup (128 KiB at c = 16)
+constexpr int MSM_MAX_C = 17;   // 2^(c-1) LDS counters per sorting workgroup: 128 KiB at c = 16, packed 16-bit at c = 17
 
 // T[w][i] = 2^(c w) P_i, w < windows, i < n (affine, Montgomery)
 template <class F>

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void k_msm_precompute(const Aff<F>* __restrict_
 
 template <class F>
 void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& t) {
-    ZK_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZK_ERR_ARG, "msm: window_bits must be in [2, 16]");
+    ZK_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZK_ERR_ARG, "msm: window_bits must be in [2, 17]");
     t.c = c;
     t.windows = 254 / c + 1;
     t.n = n;
@@ -102,35 +102,52 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, 
     }
 }
 
-// hist[chunk][b] = number of digits of magnitude b+1 among the chunk's scalars
 #ifdef ZK_MSM_COMMON
+// hist[chunk][b] = number of digits of magnitude b+1 among the chunk's scalars.
+// PACKED (c = 17): two 16-bit counters per LDS word, 2^16 buckets in 128 KiB; the host sizes the chunks
+// so that one chunk holds at most 65535 digits and a counter cannot carry into its neighbour.
+template <bool PACKED>
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
                                                            int first, int step, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int buckets = 1 << (c - 1);
-    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = 0;
+    const int words = PACKED ? buckets >> 1 : buckets;
+    for (int b = threadIdx.x; b < words; b += SORT_THREADS) lds[b] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         Fr k = scalars[i];
-        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { atomicAdd(&lds[mag - 1], 1u); });
+        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) {
+            const uint32_t b = mag - 1;
+            if (PACKED) atomicAdd(&lds[b >> 1], 1u << ((b & 1) * 16)); else atomicAdd(&lds[b], 1u);
+        });
     }
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * buckets;
-    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) row[b] = lds[b];
+    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) row[b] = PACKED ? (lds[b >> 1] >> ((b & 1) * 16)) & 0xffffu : lds[b];
 }
 
-// per bucket: hist[chunk][b] -> exclusive prefix over chunks; total[b]
-__global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int buckets, uint32_t* __restrict__ total) {
+// total[b] = sum over chunks of hist[chunk][b]
+__global__ void k_msm_bucket_totals(const uint32_t* __restrict__ hist, int chunks, int buckets, uint32_t* __restrict__ total) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     uint32_t run = 0;
+#pragma unroll 8
+    for (int ch = 0; ch < chunks; ++ch) run += hist[(size_t)ch * buckets + b];
+    total[b] = run;
+}
+
+// hist[chunk][b] -> position of the chunk's first entry of bucket b in the sorted list
+__global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int buckets, const uint32_t* __restrict__ start) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= buckets) return;
+    uint32_t run = start[b];
+#pragma unroll 8
     for (int ch = 0; ch < chunks; ++ch) {
         uint32_t v = hist[(size_t)ch * buckets + b];
         hist[(size_t)ch * buckets + b] = run;
         run += v;
     }
-    total[b] = run;
 }
 
 // exclusive scan of total[0..buckets) -> start[0..buckets]; one workgroup
@@ -156,30 +173,45 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
     if (threadIdx.x == 1023) start[buckets] = part[1023];
 }
 
-// sorted[pos] = ((w*n + i) << 1) | neg, grouped by bucket
+// sorted[pos] = ((w*n + i) << 1) | neg, grouped by bucket.  `base` = this chunk's row of positions
+// (k_msm_chunk_prefix).  Unpacked: the positions are copied to LDS and bumped there.  PACKED: LDS holds
+// 16-bit running counts and the position is base[b] (an L2-resident 256 KiB row) + count.
+template <bool PACKED>
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                              int first, int step, const uint32_t* __restrict__ prefix,
-                                                              const uint32_t* __restrict__ start, uint32_t* __restrict__ sorted) {
+                                                              int first, int step, const uint32_t* __restrict__ prefix, uint32_t* __restrict__ sorted) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int buckets = 1 << (c - 1);
     const uint32_t* row = prefix + (size_t)blockIdx.x * buckets;
-    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = start[b] + row[b];
+    if (PACKED) { for (int b = threadIdx.x; b < (buckets >> 1); b += SORT_THREADS) lds[b] = 0; }
+    else { for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = row[b]; }
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         Fr k = scalars[i];
         for_each_digit(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
-            uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
+            const uint32_t b = mag - 1;
+            uint32_t pos;
+            if (PACKED) pos = row[b] + ((atomicAdd(&lds[b >> 1], 1u << ((b & 1) * 16)) >> ((b & 1) * 16)) & 0xffffu);
+            else pos = atomicAdd(&lds[b], 1u);
             sorted[pos] = ((uint32_t)((size_t)w * stride + i) << 1) | neg;
         });
     }
 }
+template __global__ void k_msm_hist<false>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+template __global__ void k_msm_hist<true>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+template __global__ void k_msm_scatter<false>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
+template __global__ void k_msm_scatter<true>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
 
 #else
-__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-__global__ void k_msm_chunk_prefix(uint32_t*, int, int, uint32_t*);
+template <bool PACKED> __global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+__global__ void k_msm_bucket_totals(const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, const uint32_t*, uint32_t*);
+template <bool PACKED> __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
+extern template __global__ void k_msm_hist<false>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+extern template __global__ void k_msm_hist<true>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
+extern template __global__ void k_msm_scatter<false>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
+extern template __global__ void k_msm_scatter<true>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
 // ---- bucket accumulation: `lanes` lanes per bucket ---------------------------------------------
@@ -285,10 +317,13 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
         return;
     }
-    // chunking of the scalar array for the LDS counting sort
+    // chunking of the scalar array for the LDS counting sort; with packed 16-bit counters (c = 17) a chunk
+    // must hold fewer than 2^16 digits
+    const bool packed = c > 16;
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
+    if (packed) chunk_len = std::min<size_t>(chunk_len, 65535 / (size_t)owned);
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
     // lanes per bucket: split while every lane keeps at least opt_lane_entries additions on average
     size_t entries = (size_t)owned * n_used;
@@ -307,22 +342,26 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     Jac<F>* d_partial = reinterpret_cast<Jac<F>*>(ws.partial.p);
     Jac<F>* d_bsum = reinterpret_cast<Jac<F>*>(ws.bucket_sums.p);
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
-    const size_t lds_bytes = (size_t)buckets * 4;
+    const size_t lds_bytes = packed ? (size_t)buckets * 2 : (size_t)buckets * 4;
     const double pt_bytes = (double)sizeof(Aff<F>);
 
     {
         ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * buckets, st);
-        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
+        if (packed) hipLaunchKernelGGL(k_msm_hist<true>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
+        else hipLaunchKernelGGL(k_msm_hist<false>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
     }
     {
-        ProfScope ps(ctx, "msm_offsets", 8.0 * chunks * buckets, st);
-        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(buckets, 256)), dim3(256), 0, st, ws.hist.p, chunks, buckets, ws.total.p);
+        ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * buckets, st);
+        hipLaunchKernelGGL(k_msm_bucket_totals, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.hist.p, chunks, buckets, ws.total.p);
         hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.start.p, buckets);
+        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.hist.p, chunks, buckets, ws.start.p);
     }
     {
         ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 4.0 * entries + 4.0 * chunks * buckets, st);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
-                           ws.hist.p, ws.start.p, ws.sorted.p);
+        if (packed) hipLaunchKernelGGL(k_msm_scatter<true>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+                                       ws.hist.p, ws.sorted.p);
+        else hipLaunchKernelGGL(k_msm_scatter<false>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+                                ws.hist.p, ws.sorted.p);
     }
     {
         // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
@@ -347,8 +386,11 @@ template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const M
 void msm_set_lds_attributes() {
     static bool done = false;
     if (done) return;
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (MSM_MAX_C - 1)));
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (MSM_MAX_C - 1)));
+    const int lds_max = 128 * 1024;   // 2^15 32-bit counters (c = 16) or 2^16 packed 16-bit counters (c = 17)
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     done = true;
 }
 
