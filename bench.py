@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
+    ap.add_argument("--serialize", action="store_true", help="measurement mode: no kernel overlap (stand-alone kernel durations)")
     ap.add_argument("--seed", type=int, default=20260929)
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="proofs in flight per GPU (zk_prove_submit/zk_prove_wait); 1 = synchronous zk_prove_dev")
@@ -130,6 +131,8 @@ def main():
     ctx = zk.Context(local_rank)
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
+    if args.serialize:
+        ctx.set_option("serialize", 1)
     if args.lane_entries:
         ctx.set_option("msm_lane_entries", args.lane_entries)
     inst = build_instance(zk, ctx, args.log_n, args.seed)

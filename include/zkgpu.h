@@ -60,7 +60,8 @@ const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
 /* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (bucket lists are split over
  * more lanes while each lane keeps at least this many additions; default 24), "profile" (0/1: per-kernel
- * event timing, read back with zk_profile_*).  Unknown keys return ZK_ERR_UNSUPPORTED. */
+ * event timing, read back with zk_profile_*), "serialize" (0/1: measurement mode, all kernels of a proof on
+ * one stream so that event timings are stand-alone durations).  Unknown keys return ZK_ERR_UNSUPPORTED. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);
 

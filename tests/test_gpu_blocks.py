@@ -147,6 +147,23 @@ def test_msm_matches_reference_sum(ctx, orc, n, c):
     assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
 
 
+@pytest.mark.parametrize("c", [0, 6, 13])
+def test_msm_skewed_scalars(ctx, orc, c):
+    """Boolean-heavy witnesses: most scalars are 0, 1, 2 or r-1, so a few buckets hold almost every digit
+    and most buckets are empty (lanes cross many bucket boundaries; repeated points force doublings)."""
+    n = 2000
+    rng = SplitMix64(4242 + c)
+    p1, p2, k = g1_points(orc, rng, n), g2_points(orc, rng, n), rand_fr(rng, n)
+    small = ints_to_limbs([0, 1, 2, R_MODULUS - 1, 1 << 200, 3])
+    for i in range(n):
+        if i % 8:
+            k[i] = small[(i * 7) % len(small)]
+    for i in range(0, n - 40, 40):   # repeated points with equal scalars land in the same bucket
+        p1[i + 1] = p1[i]; p2[i + 1] = p2[i]; k[i + 1] = k[i]
+    assert np.array_equal(ctx.msm_g1(p1, k, c), orc.msm_g1(p1, k, 0))
+    assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
+
+
 def test_msm_mid_size_vs_pippenger_oracle(ctx, orc):
     rng = SplitMix64(77)
     n = 1 << 12

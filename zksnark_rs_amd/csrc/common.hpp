@@ -93,7 +93,8 @@ struct zk_ctx {
     std::string last_error;
     long opt_window_bits = 0;
     long opt_profile = 0;
-    long opt_lane_entries = 24;   // lanes per bucket are doubled while each lane keeps at least this many additions
+    long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
+    long opt_lane_entries = 32;   // additions per lane of the bucket accumulation (multiple of 4)
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;

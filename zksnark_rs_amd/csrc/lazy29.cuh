@@ -405,6 +405,37 @@ ZK_HD XyzzR<PR> xyzz_from_jac(const Jac<Fp<PR>>& j) {
     return r;
 }
 
+// p + q, both XYZZ (add-2008-s, 12M + 2S); operands hold normal forms (accumulator images)
+template <class PR>
+ZK_HD XyzzR<PR> add_xyzz(const XyzzR<PR>& p, const XyzzR<PR>& q) {
+    typedef FpR<PR> L;
+    if (p.inf) return q;
+    if (q.inf) return p;
+    L U1 = p.X * q.ZZ, U2 = q.X * p.ZZ;
+    L S1 = p.Y * q.ZZZ, S2 = q.Y * p.ZZZ;
+    L P = U2 - U1, R = S2 - S1;
+    L PP = P.sqr();
+    XyzzR<PR> r;
+    if (PP.is_zero_mod_p()) {
+        if (R.sqr().is_zero_mod_p()) {       // same point: double through the Jacobian formulas (rare)
+            JacR<Fp<PR>> j = dbl_lazy(jacr_load(xyzz_store(p)));
+            return xyzz_from_jac<PR>(jacr_store(j));
+        }
+        r = p;
+        r.inf = true;
+        return r;
+    }
+    L PPP = P * PP;
+    L Q = U1 * PP;
+    L X3 = (R.sqr() - PPP - (Q + Q)).norm();
+    r.inf = false;
+    r.Y = L::mont_diff(R, Q - X3, S1, PPP);
+    r.X = X3;
+    r.ZZ = (p.ZZ * q.ZZ) * PP;
+    r.ZZZ = (p.ZZZ * q.ZZZ) * PPP;
+    return r;
+}
+
 // accumulator interface used by k_msm_accumulate: XYZZ in G1, Jacobian in G2
 template <class F> struct AccOf { typedef JacR<F> type; };
 template <> struct AccOf<Fq> { typedef XyzzR<FqParams> type; };
@@ -413,6 +444,7 @@ ZK_HD void acc_clear(XyzzR<FqParams>& a) { a.inf = true; a.X = a.Y = a.ZZ = a.ZZ
 ZK_HD bool acc_madd(XyzzR<FqParams>& a, const FpR<FqParams>& x, const FpR<FqParams>& y) { return madd_xyzz(a, x, y); }
 ZK_HD Jac<Fq> acc_store(const XyzzR<FqParams>& a) { return xyzz_store(a); }
 ZK_HD void acc_load(XyzzR<FqParams>& a, const Jac<Fq>& j) { a = xyzz_from_jac<FqParams>(j); }
+ZK_HD XyzzR<FqParams> acc_add(const XyzzR<FqParams>& a, const XyzzR<FqParams>& b) { return add_xyzz(a, b); }
 
 // ---- general Jacobian addition / doubling in lazy form (reduction tail of the MSM) -------------
 template <class F>
@@ -496,4 +528,5 @@ template <class F> ZK_HD void acc_clear(JacR<F>& a) { a.inf = true; a.X = a.Y = 
 template <class F> ZK_HD bool acc_madd(JacR<F>& a, const typename LazyOf<F>::type& x, const typename LazyOf<F>::type& y) { return madd_lazy<F>(a, x, y); }
 template <class F> ZK_HD Jac<F> acc_store(const JacR<F>& a) { return jacr_store(a); }
 template <class F> ZK_HD void acc_load(JacR<F>& a, const Jac<F>& j) { a = jacr_load(j); }
+template <class F> ZK_HD JacR<F> acc_add(const JacR<F>& a, const JacR<F>& b) { return add_lazy(a, b); }
 }  // namespace zk

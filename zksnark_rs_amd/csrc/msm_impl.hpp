@@ -214,34 +214,63 @@ extern template __global__ void k_msm_scatter<false>(const Fr*, size_t, size_t, 
 extern template __global__ void k_msm_scatter<true>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
-// ---- bucket accumulation: `lanes` lanes per bucket ---------------------------------------------
-// waves per SIMD the accumulate kernel is compiled for.  G1 fits 3 waves (136 VGPRs).  The G2 body
-// (Jacobian accumulator + affine point over Fq2 = 80 live limbs before any temporary) does not fit
-// 256 registers; forcing 2 waves only adds scratch traffic and measured slower (bench r1).
+// ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
+// waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 147 VGPRs) fits 3
+// waves; the G2 body (Jacobian accumulator + affine point over Fq2 = 80 live limbs before any
+// temporary) fits 2.
 template <class F> struct AccWaves { static constexpr int value = 3; };
 template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
+// register image of an accumulator as it is parked in HBM between accumulate and merge
+template <class F>
+struct alignas(16) AccSlot {
+    typename AccOf<F>::type a;
+};
+
+// Lane t owns entries [t E, (t+1) E) of the bucket-sorted list, whatever buckets they belong to, so every
+// lane of every wave performs the same number of additions however skewed the digit distribution is
+// (a witness full of 0/1 wires puts a large share of all digits into one bucket).  When a lane crosses a
+// bucket boundary it parks the finished accumulator image and starts a new one:
+//   first[t]  the segment that begins at the lane's first entry,
+//   last[t]   the segment that reaches the lane's last entry (when it is not also the first),
+//   mid[b]    buckets that lie strictly inside the lane's range.
+// k_msm_merge finds the images of a bucket again from the geometry alone.
 template <class F>
 __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
-                                                       const uint32_t* __restrict__ start, int buckets, int log_lanes, Jac<F>* __restrict__ partial) {
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= ((size_t)buckets << log_lanes)) return;
-    int b = (int)(tid >> log_lanes), t = (int)(tid & ((1u << log_lanes) - 1));
-    const uint32_t hi = start[b + 1], stride = 1u << log_lanes;
+                                                       const uint32_t* __restrict__ start, int buckets, uint32_t per_lane,
+                                                       AccSlot<F>* __restrict__ first, AccSlot<F>* __restrict__ last, AccSlot<F>* __restrict__ mid) {
+    const uint32_t total = start[buckets];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid * per_lane >= total) return;
+    const uint32_t k0 = (uint32_t)(tid * per_lane), k1 = min(k0 + per_lane, total);
+    // bucket of the first entry: start[b] <= k0 < start[b + 1]
+    int lo = 0, hi = buckets;   // invariant: start[lo] <= k0 < start[hi]
+    while (hi - lo > 1) {
+        int mid_b = (lo + hi) >> 1;
+        if (start[mid_b] <= k0) lo = mid_b; else hi = mid_b;
+    }
+    int b = lo;
+    uint32_t bend = start[b + 1];
     typedef typename LazyOf<F>::type L;
-    // accumulator and temporaries live in the multiplier's radix (lazy29.cuh) for the whole bucket
     typename AccOf<F>::type acc;
     acc_clear(acc);
-    // software pipeline: the next point's gather (a random line of a multi-GiB table) and the
-    // index after it are in flight while the current addition executes
-    uint32_t k = start[b] + t;
-    uint32_t e = k < hi ? sorted[k] : 0;
-    uint32_t e_next = k + stride < hi ? sorted[k + stride] : 0;
-    Aff<F> p = k < hi ? table[e >> 1] : Aff<F>::infinity();
-    while (k < hi) {
-        const uint32_t kn = k + stride;
-        const Aff<F> p_next = kn < hi ? table[e_next >> 1] : Aff<F>::infinity();
-        const uint32_t e_next2 = kn + stride < hi ? sorted[kn + stride] : 0;
+    bool is_first = true;
+    // software pipeline: the next point's gather (a random line of a multi-GiB table) is in flight
+    // while the current addition executes
+    uint32_t k = k0;
+    uint32_t e = sorted[k];
+    uint32_t e_next = k + 1 < k1 ? sorted[k + 1] : 0;
+    Aff<F> p = table[e >> 1];
+    while (k < k1) {
+        if (k == bend) {   // bucket boundary: park the finished image
+            if (is_first) first[tid].a = acc; else mid[b].a = acc;
+            is_first = false;
+            acc_clear(acc);
+            do { ++b; bend = start[b + 1]; } while (bend <= k);   // skip empty buckets
+        }
+        const uint32_t kn = k + 1;
+        const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
+        const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
         if (!p.is_inf()) {
             L qx = L::load(p.x), qy = L::load(p.y);
             if (e & 1) qy = qy.neg();
@@ -255,18 +284,25 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         e_next = e_next2;
         k = kn;
     }
-    partial[tid] = acc_store(acc);
+    if (is_first) first[tid].a = acc; else last[tid].a = acc;
 }
 
-// S_b = sum_t partial[b][t]
+// S_b = sum of the parked images of bucket b (see k_msm_accumulate)
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_merge(const Jac<F>* __restrict__ partial, int buckets, int log_lanes, Jac<F>* __restrict__ bucket_sums) {
+__global__ __launch_bounds__(64) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
+                                                  const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
-    const Jac<F>* src = partial + ((size_t)b << log_lanes);
-    JacR<F> acc = jacr_load(src[0]);
-    for (int t = 1; t < (1 << log_lanes); ++t) acc = add_lazy(acc, jacr_load(src[t]));
-    bucket_sums[b] = jacr_store(acc);
+    const uint32_t s = start[b], e = start[b + 1], total = start[buckets];
+    if (s == e) { bucket_sums[b] = Jac<F>::infinity(); return; }
+    const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
+    const uint32_t t0_end = min((t0 + 1) * per_lane, total);
+    typename AccOf<F>::type acc;
+    if (s == t0 * per_lane) acc = first[t0].a;
+    else if (e >= t0_end) acc = last[t0].a;
+    else acc = mid[b].a;
+    for (uint32_t t = t0 + 1; t <= t1; ++t) acc = acc_add(acc, first[t].a);
+    bucket_sums[b] = acc_store(acc);
 }
 
 // segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} b * S_b
@@ -325,21 +361,22 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     if (packed) chunk_len = std::min<size_t>(chunk_len, 65535 / (size_t)owned);
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
-    // lanes per bucket: split while every lane keeps at least opt_lane_entries additions on average
+    // every lane adds the same number of entries (a multiple of 4, at most opt_lane_entries)
     size_t entries = (size_t)owned * n_used;
-    int log_lanes = 0;
-    const size_t min_per_lane = (size_t)std::max<long>(ctx->opt_lane_entries, 1);
-    while (log_lanes < 6 && (entries >> (log_lanes + 1)) / buckets >= min_per_lane) ++log_lanes;
+    const uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
+    const size_t lanes = (entries + per_lane - 1) / per_lane;
     const int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
 
     ws.hist.ensure((size_t)chunks * buckets);
     ws.total.ensure(buckets);
     ws.start.ensure(buckets + 1);
     ws.sorted.ensure(entries);
-    ws.partial.ensure(((size_t)buckets << log_lanes) * sizeof(Jac<F>));
+    ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
     ws.bucket_sums.ensure((size_t)buckets * sizeof(Jac<F>));
     ws.seg_sums.ensure((size_t)segs * sizeof(Jac<F>));
-    Jac<F>* d_partial = reinterpret_cast<Jac<F>*>(ws.partial.p);
+    AccSlot<F>* d_first = reinterpret_cast<AccSlot<F>*>(ws.partial.p);
+    AccSlot<F>* d_last = d_first + lanes;
+    AccSlot<F>* d_mid = d_last + lanes;
     Jac<F>* d_bsum = reinterpret_cast<Jac<F>*>(ws.bucket_sums.p);
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
     const size_t lds_bytes = packed ? (size_t)buckets * 2 : (size_t)buckets * 4;
@@ -365,16 +402,16 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     {
         // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
-        // every lane writes one Jacobian partial
-        size_t threads = (size_t)buckets << log_lanes;
+        // every lane parks one accumulator image
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
-        ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(Jac<F>) * threads, st);
-        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, log_lanes, d_partial);
+        ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(AccSlot<F>) * lanes, st);
+        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, per_lane,
+                           d_first, d_last, d_mid);
     }
     if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     {
-        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(Jac<F>) * (((size_t)buckets << log_lanes) + 2.0 * buckets + 2.0 * segs), st);
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, d_partial, buckets, log_lanes, d_bsum);
+        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
         hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
     }

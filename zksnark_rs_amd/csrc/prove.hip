@@ -235,8 +235,9 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
 
     // the r/s-only fixed-base multiplications run on the side stream beside everything below
     if (!d_partial_out) {
-        launch_pre(ctx, crs, ctx->side, rc, sc, S.as.p);
-        ZK_HIP(hipEventRecord(S.pre_evt, ctx->side));
+        hipStream_t pre_st = ctx->opt_serialize ? st : ctx->side;
+        launch_pre(ctx, crs, pre_st, rc, sc, S.as.p);
+        ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
     }
 
     // The inner products run on their own streams, each forked from the main stream as soon as its
@@ -246,7 +247,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
-        hipStream_t ms_st = ctx->msm_stream[k];
+        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, after >= 0 ? S.acc_evt[after] : ps.last_acc, S.acc_evt[k]);
