@@ -176,6 +176,22 @@ def test_msm_mid_size_vs_pippenger_oracle(ctx, orc):
     assert np.array_equal(ctx.msm_g2(p2, k, 0), orc.msm_g2(p2, k, 10))
 
 
+def test_msm_one_heavy_bucket(ctx, orc):
+    """Nearly all scalars equal 1 (or r-1): one bucket holds ~2^15 digits, spread over >1000 lanes of the
+    accumulation, and takes the workgroup-per-bucket merge path."""
+    rng = SplitMix64(78)
+    n = 1 << 15
+    base1 = g1_points(orc, rng, 512)
+    base2 = g2_points(orc, rng, 512)
+    p1 = np.tile(base1, (n // 512, 1)); p2 = np.tile(base2, (n // 512, 1))
+    k = np.tile(ints_to_limbs([1]), (n, 1))
+    k[::3] = ints_to_limbs([R_MODULUS - 1])[0]
+    k[::97] = rand_fr(rng, len(k[::97]))
+    for c in (0, 9):
+        assert np.array_equal(ctx.msm_g1(p1, k, c), orc.msm_g1(p1, k, 10))
+    assert np.array_equal(ctx.msm_g2(p2, k, 0), orc.msm_g2(p2, k, 10))
+
+
 def test_msm_linearity_large(ctx, orc):
     """Size-independent property at 2^18 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b)."""
     rng = SplitMix64(78)

@@ -56,7 +56,7 @@ struct MsmTable {
     int c = 0, windows = 0;
 };
 struct MsmWorkspace {
-    DevBuf<uint32_t> hist, total, start, sorted;
+    DevBuf<uint32_t> hist, total, start, sorted, heavy;
     DevBuf<uint8_t> partial, bucket_sums, seg_sums;
 };
 int msm_auto_window(size_t n);

@@ -287,22 +287,57 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     if (is_first) first[tid].a = acc; else last[tid].a = acc;
 }
 
-// S_b = sum of the parked images of bucket b (see k_msm_accumulate)
+// S_b = sum of the parked images of bucket b (see k_msm_accumulate).  One lane per bucket; buckets spread
+// over more than MSM_HEAVY lanes (skewed digit distributions) are queued for k_msm_merge_heavy instead.
+constexpr uint32_t MSM_HEAVY = 96;
+
+template <class F>
+__device__ __forceinline__ typename AccOf<F>::type merge_head(uint32_t b, uint32_t s, uint32_t e, uint32_t t0, uint32_t per_lane, uint32_t total,
+                                                              const AccSlot<F>* first, const AccSlot<F>* last, const AccSlot<F>* mid) {
+    const uint32_t t0_end = min((t0 + 1) * per_lane, total);
+    if (s == t0 * per_lane) return first[t0].a;
+    if (e >= t0_end) return last[t0].a;
+    return mid[b].a;
+}
+
 template <class F>
 __global__ __launch_bounds__(64) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
-                                                  const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums) {
+                                                  const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums,
+                                                  uint32_t* __restrict__ heavy) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     const uint32_t s = start[b], e = start[b + 1], total = start[buckets];
     if (s == e) { bucket_sums[b] = Jac<F>::infinity(); return; }
     const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
-    const uint32_t t0_end = min((t0 + 1) * per_lane, total);
-    typename AccOf<F>::type acc;
-    if (s == t0 * per_lane) acc = first[t0].a;
-    else if (e >= t0_end) acc = last[t0].a;
-    else acc = mid[b].a;
+    if (t1 - t0 > MSM_HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)b; return; }
+    typename AccOf<F>::type acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid);
     for (uint32_t t = t0 + 1; t <= t1; ++t) acc = acc_add(acc, first[t].a);
     bucket_sums[b] = acc_store(acc);
+}
+
+// heavy buckets: one workgroup each, lanes stride over the images, tree over LDS
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
+                                                         const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums,
+                                                         const uint32_t* __restrict__ heavy) {
+    __shared__ AccSlot<F> sh[256];
+    const uint32_t count = heavy[0], total = start[buckets];
+    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+        const uint32_t b = heavy[1 + h];
+        const uint32_t s = start[b], e = start[b + 1];
+        const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
+        typename AccOf<F>::type acc;
+        if (threadIdx.x == 0) acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid); else acc_clear(acc);
+        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += 256) acc = acc_add(acc, first[t].a);
+        sh[threadIdx.x].a = acc;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) sh[threadIdx.x].a = acc_add(sh[threadIdx.x].a, sh[threadIdx.x + d].a);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) bucket_sums[b] = acc_store(sh[0].a);
+        __syncthreads();
+    }
 }
 
 // segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} b * S_b
@@ -374,6 +409,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
     ws.bucket_sums.ensure((size_t)buckets * sizeof(Jac<F>));
     ws.seg_sums.ensure((size_t)segs * sizeof(Jac<F>));
+    ws.heavy.ensure((size_t)buckets + 1);
     AccSlot<F>* d_first = reinterpret_cast<AccSlot<F>*>(ws.partial.p);
     AccSlot<F>* d_last = d_first + lanes;
     AccSlot<F>* d_mid = d_last + lanes;
@@ -411,7 +447,9 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum);
+        ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(64), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
         hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
     }
