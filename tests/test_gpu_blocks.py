@@ -133,7 +133,7 @@ def test_ntt_full_size_properties(ctx):
     assert np.array_equal(ctx.ntt_fr(delta), ones)
 
 
-@pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (2, 3), (17, 4), (100, 0), (300, 7), (1000, 11), (1000, 13), (1000, 16), (3000, 17)])
+@pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (2, 3), (17, 4), (100, 0), (300, 7), (1000, 11), (1000, 13), (1000, 16), (3000, 17), (3000, 20), (500, 22)])
 def test_msm_matches_reference_sum(ctx, orc, n, c):
     """GPU Pippenger == n double-and-add multiplications folded sequentially (mod.rs:255-272)."""
     rng = SplitMix64(300 + n)

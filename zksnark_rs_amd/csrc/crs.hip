@@ -107,7 +107,14 @@ void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n) {
 void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
     if (c.tables_kind == (brev ? 1 : 0) && c.tables_c == ctx->opt_window_bits) return;
     if (brev) crs_ensure_brev(ctx, c, log_n);
-    auto pick = [&](size_t count) { return ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(count); };
+    // msm_window_bits: 0 = automatic, c = the same window for every table, 100*big + small = `big` for tables of
+    // 2^21 points and more and `small` below (tuning sweeps)
+    auto pick = [&](size_t count) {
+        const long o = ctx->opt_window_bits;
+        if (o <= 0) return msm_auto_window(count);
+        if (o < 100) return (int)o;
+        return (int)(count >= ((size_t)1 << 21) - 8 ? o / 100 : o % 100);
+    };
     const size_t n = c.n, nl = c.m - c.input - 1;
     // xi_t has n-1 points; the bit-reversed copy is padded with infinity to n entries
     msm_build_table<Fq>(ctx, brev ? c.xi1_br.p : c.xi1.p, n, pick(n), c.t_xi1);

@@ -46,7 +46,7 @@ void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
 void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
 
 // ---- msm.hip ----
-constexpr int MSM_MAX_C = 17;   // 2^(c-1) LDS counters per sorting workgroup: 128 KiB at c = 16, packed 16-bit at c = 17
+constexpr int MSM_MAX_C = 22;   // window bits; the two-level sort keeps only 2^10 + 2^(c-11) counters in LDS
 
 // T[w][i] = 2^(c w) P_i, w < windows, i < n (affine, Montgomery)
 template <class F>
@@ -56,7 +56,8 @@ struct MsmTable {
     int c = 0, windows = 0;
 };
 struct MsmWorkspace {
-    DevBuf<uint32_t> hist, total, start, sorted, heavy;
+    DevBuf<uint32_t> hist, total, bin_start, bin_cnt, start, sorted, heavy;
+    DevBuf<uint64_t> records;
     DevBuf<uint8_t> partial, bucket_sums, seg_sums;
 };
 int msm_auto_window(size_t n);

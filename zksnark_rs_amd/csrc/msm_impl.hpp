@@ -46,6 +46,7 @@ int msm_auto_window(size_t n) {
 
 constexpr int MSM_SEG = 8;       // buckets per lane in the running-sum reduction
 constexpr int SORT_THREADS = 1024;
+constexpr int SORT2_THREADS = 256;   // level-2 workgroups (several per bin)
 
 // ---- table precompute: T[w][i] = 2^(c w) P_i ------------------------------------------------
 template <class F>
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(64) void k_msm_precompute(const Aff<F>* __restrict_
 
 template <class F>
 void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& t) {
-    ZK_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZK_ERR_ARG, "msm: window_bits must be in [2, 17]");
+    ZK_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
     t.c = c;
     t.windows = 254 / c + 1;
     t.n = n;
@@ -103,58 +104,88 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, 
 }
 
 #ifdef ZK_MSM_COMMON
-// hist[chunk][b] = number of digits of magnitude b+1 among the chunk's scalars.
-// PACKED (c = 17): two 16-bit counters per LDS word, 2^16 buckets in 128 KiB; the host sizes the chunks
-// so that one chunk holds at most 65535 digits and a counter cannot carry into its neighbour.
-template <bool PACKED>
+// ---- two-level counting sort of the digits by bucket -------------------------------------------
+// A bucket id (|digit| - 1, c - 1 bits) splits into a bin (high bits, at most 2^10 bins) and a sub-bucket.
+// Level 1 (one workgroup per scalar chunk) groups the digits by bin: per (chunk, bin) the 8-byte records
+// (sub-bucket, (w*n + i) << 1 | sign) form runs of hundreds of bytes, so the stores fill whole lines --
+// a direct counting sort over 2^15 buckets emits 16-byte runs and was bound by partial-line write
+// bursts (1.35 ms of a 2^20 proof).  Level 2 (one workgroup per bin) finishes the sort inside a bin
+// whose records and 4-byte output both sit in L2, and emits the bucket offsets.  LDS holds only
+// 2^10 + 2^(c-11) counters, so the window size is no longer tied to the LDS capacity.
+
+// atomicAdd(&ctr[idx], 1) for all active lanes, with lanes of a wave that hit the SAME counter served by one
+// atomic (skewed digit distributions put most lanes of a wave on one or two counters, and same-address LDS
+// atomics serialise).  Groups are peeled while they are large; evenly spread indices fall through to the
+// plain atomic after one round.
+__device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t idx) {
+    uint32_t res = 0;
+    bool pending = true;
+    for (int round = 0; round < 6; ++round) {
+        bool big = false;
+        if (pending) {
+            const uint32_t v = __builtin_amdgcn_readfirstlane(idx);
+            if (idx == v) {
+                const uint64_t m = __ballot(1);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                uint32_t base = 0;
+                if (rank == 0) base = atomicAdd(&ctr[v], cnt);
+                res = __builtin_amdgcn_readfirstlane(base) + rank;
+                pending = false;
+                big = cnt >= 8;
+            }
+        }
+        if (!__any(big)) break;
+    }
+    if (pending) res = atomicAdd(&ctr[idx], 1u);
+    return res;
+}
+
+// hist[chunk][bin] = number of digits of the chunk whose bucket falls into the bin
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
-                                                           int first, int step, uint32_t* __restrict__ hist) {
+                                                           int first, int step, int sub_bits, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int buckets = 1 << (c - 1);
-    const int words = PACKED ? buckets >> 1 : buckets;
-    for (int b = threadIdx.x; b < words; b += SORT_THREADS) lds[b] = 0;
+    const int bins = 1 << (c - 1 - sub_bits);
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         Fr k = scalars[i];
-        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) {
-            const uint32_t b = mag - 1;
-            if (PACKED) atomicAdd(&lds[b >> 1], 1u << ((b & 1) * 16)); else atomicAdd(&lds[b], 1u);
-        });
+        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, (mag - 1) >> sub_bits); });
     }
     __syncthreads();
-    uint32_t* row = hist + (size_t)blockIdx.x * buckets;
-    for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) row[b] = PACKED ? (lds[b >> 1] >> ((b & 1) * 16)) & 0xffffu : lds[b];
+    uint32_t* row = hist + (size_t)blockIdx.x * bins;
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) row[b] = lds[b];
 }
 
 // total[b] = sum over chunks of hist[chunk][b]
-__global__ void k_msm_bucket_totals(const uint32_t* __restrict__ hist, int chunks, int buckets, uint32_t* __restrict__ total) {
+__global__ void k_msm_bin_totals(const uint32_t* __restrict__ hist, int chunks, int bins, uint32_t* __restrict__ total) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= buckets) return;
+    if (b >= bins) return;
     uint32_t run = 0;
 #pragma unroll 8
-    for (int ch = 0; ch < chunks; ++ch) run += hist[(size_t)ch * buckets + b];
+    for (int ch = 0; ch < chunks; ++ch) run += hist[(size_t)ch * bins + b];
     total[b] = run;
 }
 
-// hist[chunk][b] -> position of the chunk's first entry of bucket b in the sorted list
-__global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int buckets, const uint32_t* __restrict__ start) {
+// hist[chunk][b] -> position of the chunk's first record of bin b
+__global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int bins, const uint32_t* __restrict__ start) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= buckets) return;
+    if (b >= bins) return;
     uint32_t run = start[b];
 #pragma unroll 8
     for (int ch = 0; ch < chunks; ++ch) {
-        uint32_t v = hist[(size_t)ch * buckets + b];
-        hist[(size_t)ch * buckets + b] = run;
+        uint32_t v = hist[(size_t)ch * bins + b];
+        hist[(size_t)ch * bins + b] = run;
         run += v;
     }
 }
 
-// exclusive scan of total[0..buckets) -> start[0..buckets]; one workgroup
-__global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ total, uint32_t* __restrict__ start, int buckets) {
+// exclusive scan of total[0..count) -> start[0..count]; one workgroup
+__global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ total, uint32_t* __restrict__ start, int count) {
     __shared__ uint32_t part[1024];
-    int per = (buckets + 1023) / 1024;
-    int lo = threadIdx.x * per, hi = min(lo + per, buckets);
+    int per = (count + 1023) / 1024;
+    int lo = min((int)threadIdx.x * per, count), hi = min(lo + per, count);
     uint32_t s = 0;
     for (int b = lo; b < hi; ++b) s += total[b];
     part[threadIdx.x] = s;
@@ -170,48 +201,121 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
         start[b] = run;
         run += total[b];
     }
-    if (threadIdx.x == 1023) start[buckets] = part[1023];
+    if (threadIdx.x == 1023) start[count] = part[1023];
 }
 
-// sorted[pos] = ((w*n + i) << 1) | neg, grouped by bucket.  `base` = this chunk's row of positions
-// (k_msm_chunk_prefix).  Unpacked: the positions are copied to LDS and bumped there.  PACKED: LDS holds
-// 16-bit running counts and the position is base[b] (an L2-resident 256 KiB row) + count.
-template <bool PACKED>
+// level 1: records[pos] = (sub-bucket << 32) | ((w*n + i) << 1 | neg), grouped by bin
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                              int first, int step, const uint32_t* __restrict__ prefix, uint32_t* __restrict__ sorted) {
+                                                              int first, int step, int sub_bits, const uint32_t* __restrict__ prefix,
+                                                              uint64_t* __restrict__ records) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int buckets = 1 << (c - 1);
-    const uint32_t* row = prefix + (size_t)blockIdx.x * buckets;
-    if (PACKED) { for (int b = threadIdx.x; b < (buckets >> 1); b += SORT_THREADS) lds[b] = 0; }
-    else { for (int b = threadIdx.x; b < buckets; b += SORT_THREADS) lds[b] = row[b]; }
+    const int bins = 1 << (c - 1 - sub_bits);
+    const uint32_t sub_mask = (1u << sub_bits) - 1;
+    const uint32_t* row = prefix + (size_t)blockIdx.x * bins;
+    for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = row[b];
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         Fr k = scalars[i];
         for_each_digit(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
-            uint32_t pos;
-            if (PACKED) pos = row[b] + ((atomicAdd(&lds[b >> 1], 1u << ((b & 1) * 16)) >> ((b & 1) * 16)) & 0xffffu);
-            else pos = atomicAdd(&lds[b], 1u);
-            sorted[pos] = ((uint32_t)((size_t)w * stride + i) << 1) | neg;
+            uint32_t pos = lds_inc(lds, b >> sub_bits);
+            records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + i) << 1) | neg);
         });
     }
 }
-template __global__ void k_msm_hist<false>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-template __global__ void k_msm_hist<true>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-template __global__ void k_msm_scatter<false>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
-template __global__ void k_msm_scatter<true>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
+
+// level 2: counting sort by sub-bucket inside every bin, `parts` workgroups per bin (a bin that holds a
+// heavy bucket can be a large share of all records), positions by a per-bin prefix over (sub-bucket, part)
+__device__ __forceinline__ void bin_slice(const uint32_t* bin_start, int parts, uint32_t& lo, uint32_t& hi) {
+    const int bin = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint32_t s = bin_start[bin], len = bin_start[bin + 1] - s;
+    lo = s + (uint32_t)((uint64_t)len * part / parts);
+    hi = s + (uint32_t)((uint64_t)len * (part + 1) / parts);
+}
+
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
+                                                                uint32_t* __restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int subs = 1 << sub_bits;
+    uint32_t lo, hi;
+    bin_slice(bin_start, parts, lo, hi);
+    for (int b = threadIdx.x; b < subs; b += SORT2_THREADS) lds[b] = 0;
+    __syncthreads();
+    // four records in flight per lane: a bin holding a heavy bucket makes this loop long and latency-bound
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * SORT2_THREADS) {
+        uint64_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j * SORT2_THREADS < hi) lds_inc(lds, (uint32_t)(r[j] >> 32));
+    }
+    __syncthreads();
+    uint32_t* row = cnt + (size_t)blockIdx.x * subs;
+    for (int b = threadIdx.x; b < subs; b += SORT2_THREADS) row[b] = lds[b];
+}
+
+// one workgroup per bin: cnt[bin][part][sub] -> first position of that (part, sub); start[bucket]
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_start, int bins, int parts, int sub_bits,
+                                                                   uint32_t* __restrict__ start) {
+    __shared__ uint32_t part_sum[SORT2_THREADS];
+    const int subs = 1 << sub_bits;
+    const int bin = blockIdx.x;
+    uint32_t* rows = cnt + (size_t)bin * parts * subs;
+    const int per = (subs + SORT2_THREADS - 1) / SORT2_THREADS;
+    const int lo = min((int)threadIdx.x * per, subs), hi = min(lo + per, subs);
+    uint32_t sum = 0;
+    for (int b = lo; b < hi; ++b)
+        for (int p = 0; p < parts; ++p) sum += rows[(size_t)p * subs + b];
+    part_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < SORT2_THREADS; d <<= 1) {
+        uint32_t v = (int)threadIdx.x >= d ? part_sum[threadIdx.x - d] : 0;
+        __syncthreads();
+        part_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = bin_start[bin] + (threadIdx.x ? part_sum[threadIdx.x - 1] : 0);
+    for (int b = lo; b < hi; ++b) {
+        start[(size_t)bin * subs + b] = run;
+        for (int p = 0; p < parts; ++p) {
+            uint32_t v = rows[(size_t)p * subs + b];
+            rows[(size_t)p * subs + b] = run;
+            run += v;
+        }
+    }
+    if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = bin_start[bins];
+}
+
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
+                                                                   const uint32_t* __restrict__ pos, uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int subs = 1 << sub_bits;
+    uint32_t lo, hi;
+    bin_slice(bin_start, parts, lo, hi);
+    const uint32_t* row = pos + (size_t)blockIdx.x * subs;
+    for (int b = threadIdx.x; b < subs; b += SORT2_THREADS) lds[b] = row[b];
+    __syncthreads();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * SORT2_THREADS) {
+        uint64_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j * SORT2_THREADS < hi) sorted[lds_inc(lds, (uint32_t)(r[j] >> 32))] = (uint32_t)r[j];
+    }
+}
 
 #else
-template <bool PACKED> __global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-__global__ void k_msm_bucket_totals(const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, int, uint32_t*);
+__global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-template <bool PACKED> __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
-extern template __global__ void k_msm_hist<false>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-extern template __global__ void k_msm_hist<true>(const Fr*, size_t, size_t, int, int, int, int, uint32_t*);
-extern template __global__ void k_msm_scatter<false>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
-extern template __global__ void k_msm_scatter<true>(const Fr*, size_t, size_t, size_t, int, int, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, const uint32_t*, uint64_t*);
+__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, int, int, int, uint32_t*);
+__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
 // ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
@@ -356,20 +460,20 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restri
     out[t] = jacr_store(acc);
 }
 
-// sums `count` points into one (one workgroup of 256 lanes; tree over LDS in the 8 x 32 form)
+// sums points: workgroup g of G adds in[g], in[g + G], ... (256 lanes, tree over LDS in the 8 x 32 form) -> out[g]
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
     JacR<F> acc = jacr_load(Jac<F>::infinity());
-    for (int k = threadIdx.x; k < count; k += 256) acc = add_lazy(acc, jacr_load(in[k]));
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < count; k += 256 * gridDim.x) acc = add_lazy(acc, jacr_load(in[k]));
     sh[threadIdx.x] = jacr_store(acc);
     __syncthreads();
     for (int d = 128; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) sh[threadIdx.x] = jacr_store(add_lazy(jacr_load(sh[threadIdx.x]), jacr_load(sh[threadIdx.x + d])));
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
 template <class F>
@@ -388,13 +492,11 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
         return;
     }
-    // chunking of the scalar array for the LDS counting sort; with packed 16-bit counters (c = 17) a chunk
-    // must hold fewer than 2^16 digits
-    const bool packed = c > 16;
+    // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
+    const int sub_bits = std::max(0, c - 1 - 10), bins = 1 << (c - 1 - sub_bits);
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
-    if (packed) chunk_len = std::min<size_t>(chunk_len, 65535 / (size_t)owned);
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
     // every lane adds the same number of entries (a multiple of 4, at most opt_lane_entries)
     size_t entries = (size_t)owned * n_used;
@@ -402,8 +504,10 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     const size_t lanes = (entries + per_lane - 1) / per_lane;
     const int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
 
-    ws.hist.ensure((size_t)chunks * buckets);
-    ws.total.ensure(buckets);
+    ws.hist.ensure((size_t)chunks * bins);
+    ws.total.ensure(bins);
+    ws.bin_start.ensure(bins + 1);
+    ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
     ws.sorted.ensure(entries);
     ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
@@ -415,26 +519,31 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     AccSlot<F>* d_mid = d_last + lanes;
     Jac<F>* d_bsum = reinterpret_cast<Jac<F>*>(ws.bucket_sums.p);
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
-    const size_t lds_bytes = packed ? (size_t)buckets * 2 : (size_t)buckets * 4;
     const double pt_bytes = (double)sizeof(Aff<F>);
 
     {
-        ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * buckets, st);
-        if (packed) hipLaunchKernelGGL(k_msm_hist<true>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
-        else hipLaunchKernelGGL(k_msm_hist<false>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, chunk_len, c, windows, rank, world, ws.hist.p);
+        ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
+        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits, ws.hist.p);
     }
     {
-        ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * buckets, st);
-        hipLaunchKernelGGL(k_msm_bucket_totals, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.hist.p, chunks, buckets, ws.total.p);
-        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.start.p, buckets);
-        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.hist.p, chunks, buckets, ws.start.p);
+        ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
+        hipLaunchKernelGGL(k_msm_bin_totals, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.total.p);
+        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.bin_start.p, bins);
+        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.bin_start.p);
     }
     {
-        ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 4.0 * entries + 4.0 * chunks * buckets, st);
-        if (packed) hipLaunchKernelGGL(k_msm_scatter<true>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
-                                       ws.hist.p, ws.sorted.p);
-        else hipLaunchKernelGGL(k_msm_scatter<false>, dim3(chunks), dim3(SORT_THREADS), lds_bytes, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
-                                ws.hist.p, ws.sorted.p);
+        ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world, sub_bits,
+                           ws.hist.p, ws.records.p);
+    }
+    {
+        ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
+        const int subs = 1 << sub_bits, parts = std::max(1, std::min(8, 2048 / subs));
+        ws.bin_cnt.ensure((size_t)bins * parts * subs);
+        hipLaunchKernelGGL(k_msm_bin_hist, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits, ws.bin_cnt.p);
+        hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, bins, parts, sub_bits, ws.start.p);
+        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits,
+                           ws.bin_cnt.p, ws.sorted.p);
     }
     {
         // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
@@ -451,7 +560,14 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(64), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
-        hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
+        // one workgroup while each lane has at most ~16 additions, otherwise two levels
+        const int groups = std::min(256, (segs + 4095) / 4096);
+        if (groups > 1) {
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_bsum);   // bucket sums are dead by now
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_bsum, groups, d_out);
+        } else {
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
+        }
     }
     ZK_HIP(hipGetLastError());
 }
@@ -461,11 +577,6 @@ template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const M
 void msm_set_lds_attributes() {
     static bool done = false;
     if (done) return;
-    const int lds_max = 128 * 1024;   // 2^15 32-bit counters (c = 16) or 2^16 packed 16-bit counters (c = 17)
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     done = true;
 }
 
