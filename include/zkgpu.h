@@ -58,8 +58,8 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
-/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (bucket lists are split over
- * more lanes while each lane keeps at least this many additions; default 24), "profile" (0/1: per-kernel
+/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (additions per lane of the
+ * bucket accumulation, a multiple of 4; default 32), "profile" (0/1: per-kernel
  * event timing, read back with zk_profile_*), "serialize" (0/1: measurement mode, all kernels of a proof on
  * one stream so that event timings are stand-alone durations).  Unknown keys return ZK_ERR_UNSUPPORTED. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);

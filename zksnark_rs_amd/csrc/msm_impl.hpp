@@ -31,16 +31,19 @@ namespace zk {
 
 #ifdef ZK_MSM_COMMON
 int msm_auto_window(size_t n) {
-    // The top window holds only 254 - (W-1) c bits; when that is 1-4 bits every scalar lands in the same
-    // handful of buckets of that window and a few lanes get n/4 additions each (profiles/
-    // r1_window_sweep_2p20.jsonl: c = 8, 10, 12, 14 are 6-15x slower than c = 13, 15, 16).  Pick from the
-    // window sizes whose top window is at least 6 bits wide.
+    // Measured on MI355X (profiles/r1_window_sweep_2p20.jsonl and the r1 sweeps in DESIGN.md 4c): every
+    // scalar costs one addition per window, so wider windows win until the 2^(c-1) buckets' merge /
+    // running-sum tail and the sort's sub-bucket level outweigh the saved window: c = 17 (15 windows)
+    // beats 16 (16 windows) by 5 % at 2^20..2^21 points; 18 has as many windows as 17, and 19/20 lose
+    // again in the pipelined prover.  A narrow top window (254 - (W-1) c bits) is harmless since the
+    // accumulation is balanced per lane, so small sizes just scale c with log2(n).
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    if (lg >= 16) return 16;   // top window 14 bits
-    if (lg == 15) return 15;   // 14 bits
-    if (lg >= 11) return 13;   // 7 bits
-    return 8;                  // 6 bits
+    if (lg >= 17) return 17;
+    if (lg >= 16) return 16;
+    if (lg >= 14) return 15;
+    if (lg >= 11) return 13;
+    return 8;
 }
 #endif  // ZK_MSM_COMMON
 
@@ -498,7 +501,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
-    // every lane adds the same number of entries (a multiple of 4, at most opt_lane_entries)
+    // every lane adds the same number of entries (a multiple of 4; 24..48 measured equal within noise)
     size_t entries = (size_t)owned * n_used;
     const uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
     const size_t lanes = (entries + per_lane - 1) / per_lane;
@@ -558,7 +561,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(64), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(8), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
         // one workgroup while each lane has at most ~16 additions, otherwise two levels
         const int groups = std::min(256, (segs + 4095) / 4096);
