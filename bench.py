@@ -140,16 +140,18 @@ def main():
     m = inst["m"]
     shard = world > 1 and args.mode == "shard"
     if shard:
-        from zksnark_rs_amd.distributed import GpuProver, prove_sharded
+        from zksnark_rs_amd.distributed import GpuProver, prove_sharded, prove_sharded_stream
         prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
         bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
 
-    depth = 1 if shard else args.depth
+    depth = args.depth
 
     def run(k):
         """k proofs, all submitted and completed inside this call; returns their bytes."""
-        if shard:
+        if shard and depth == 1:
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
+        if shard:
+            return list(prove_sharded_stream(prover, dist, rank, world, [(inst["r"], inst["s"])] * k, depth))
         if depth == 1:
             return [ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
         out, inflight = [], []

@@ -195,7 +195,7 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
  * detected on the device (witness element >= r) are reported by zk_prove_wait. */
 int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                     const uint64_t r[4], const uint64_t s[4], int* ticket);
-int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t proof_out[ZK_PROOF_BYTES]);
+int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out /* ZK_PROOF_BYTES; may be NULL for a partial ticket */);
 
 /* Multi-GPU: every rank holds the CRS and recomputes the NTT stage; rank g owns
  * Pippenger windows w = g (mod world) of each inner product and writes its partial sums
@@ -207,6 +207,10 @@ int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const vo
                      const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out);
 int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
                      const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+/* Pipelined form of zk_prove_partial (same two-in-flight rule as zk_prove_submit); finish with
+ * zk_prove_wait(ctx, ticket, NULL), after which d_partial_out holds the rank's partial sums. */
+int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                            const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out, int* ticket);
 
 /* ------------------------------------------------------------------------------------------
  * verify  (groth16::verify, groth16/mod.rs:299-320) -- host code, as in the reference

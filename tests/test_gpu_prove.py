@@ -116,6 +116,13 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
         torch.cuda.synchronize()
         assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want
     assert ctx.prove_dev(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]) == want
+    # pipelined form (zk_prove_partial_submit / zk_prove_wait): world 1 through the distributed driver
+    from zksnark_rs_amd.distributed import GpuProver, prove_sharded_stream
+    prover = GpuProver(ctx, crs, inst["qap"], dw, inst["m"])
+    jobs = [(inst["r"], inst["s"]), (inst["s"], inst["r"]), (inst["r"], inst["s"])]
+    got = list(prove_sharded_stream(prover, None, 0, 1, jobs))
+    assert got[0] == want and got[2] == want
+    assert got[1] == ctx.prove(crs, inst["qap"], inst["weights"], inst["s"], inst["r"])
 
 
 def test_pipelined_submit_wait(ctx, orc):

@@ -319,10 +319,21 @@ class Context:
         self._check(self.lib.zk_prove_submit(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, C.byref(t)))
         return t.value
 
-    def prove_wait(self, ticket):
+    def prove_wait(self, ticket, partial=False):
+        if partial:
+            self._check(self.lib.zk_prove_wait(self.ptr, ticket, None))
+            return None
         out = np.zeros(PROOF_BYTES, dtype=np.uint8)
         self._check(self.lib.zk_prove_wait(self.ptr, ticket, out.ctypes.data_as(_lib.u8p)))
         return out.tobytes()
+
+    def prove_partial_submit(self, crs, qap, d_weights_ptr, m, r, s, rank, world, d_partial_ptr):
+        r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)
+        s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
+        t = C.c_int(-1)
+        self._check(self.lib.zk_prove_partial_submit(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, rank, world,
+                                                     C.c_void_p(d_partial_ptr), C.byref(t)))
+        return t.value
 
     def prove_partial(self, crs, qap, d_weights_ptr, m, r, s, rank, world, d_partial_ptr):
         r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)

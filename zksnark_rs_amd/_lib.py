@@ -79,6 +79,8 @@ SIGNATURES = {
     "zk_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
     "zk_prove_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
     "zk_prove_wait": (C.c_int, [C.c_void_p, C.c_int, u8p]),
+    "zk_prove_partial_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_int)]),
     "zk_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
     "zk_verify": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u8p, C.POINTER(C.c_int)]),

@@ -182,8 +182,13 @@ int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const voi
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !ticket) return ZK_ERR_ARG;
     return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, 0, 1, nullptr); });
 }
-int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t proof_out[ZK_PROOF_BYTES]) {
-    if (!ctx || !proof_out) return ZK_ERR_ARG;
+int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                            const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out, int* ticket) {
+    if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || !ticket || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, rank, world, d_partial_out); });
+}
+int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
+    if (!ctx) return ZK_ERR_ARG;
     return guarded(ctx, [&] { prove_wait(ctx, ticket, proof_out); });
 }
 int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,

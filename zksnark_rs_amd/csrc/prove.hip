@@ -191,7 +191,17 @@ struct ProveState {
     ProveSlot slot[SLOTS];
     int next = 0;
     hipEvent_t last_acc = nullptr;   // end of the most recently enqueued accumulation chain
-    ProveState() { for (auto& s : slot) s.init(); }
+    // zk_prove_combine scratch (allocated once)
+    DevBuf<MsmResults> comb_ms;
+    DevBuf<AssembleScratch> comb_as;
+    DevBuf<uint8_t> comb_proof;
+    uint8_t* comb_h_proof = nullptr;
+    ProveState() {
+        for (auto& s : slot) s.init();
+        comb_ms.alloc(1); comb_as.alloc(1); comb_proof.alloc(ZK_PROOF_BYTES);
+        ZK_HIP(hipHostMalloc((void**)&comb_h_proof, ZK_PROOF_BYTES));
+    }
+    ~ProveState() { if (comb_h_proof) (void)hipHostFree(comb_h_proof); }
 };
 
 static ProveState& prove_state(zk_ctx* ctx) {
@@ -371,16 +381,16 @@ void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     crs_ensure_fixed_tables(ctx, crs);
-    DevBuf<MsmResults> d_ms(1);
-    DevBuf<AssembleScratch> d_as(1);
-    DevBuf<uint8_t> d_proof(ZK_PROOF_BYTES);
-    hipStream_t st = ctx->stream;
-    launch_pre(ctx, crs, st, rc, sc, d_as.p);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, d_ms.p);
-    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, d_ms.p, &d_as.p->pre, crs.alpha1.p, crs.beta2.p, d_proof.p);
+    ProveState& ps = prove_state(ctx);
+    // on the finish stream: a pipelined caller has the next proof's stages queued on the main stream already
+    hipStream_t st = ctx->finish;
+    launch_pre(ctx, crs, st, rc, sc, ps.comb_as.p);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, ps.comb_ms.p);
+    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.comb_proof.p);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(proof_out, d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(ps.comb_h_proof, ps.comb_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
+    std::memcpy(proof_out, ps.comb_h_proof, ZK_PROOF_BYTES);
 }
 
 }  // namespace zk

@@ -23,8 +23,17 @@ class GpuProver:
     def partial(self, rank, world, r, s, out):
         self.ctx.prove_partial(self.crs, self.qap, self.d_weights.data_ptr(), self.m, r, s, rank, world, out.data_ptr())
 
+    def partial_submit(self, rank, world, r, s, out):
+        return self.ctx.prove_partial_submit(self.crs, self.qap, self.d_weights.data_ptr(), self.m, r, s, rank, world, out.data_ptr())
+
+    def partial_wait(self, ticket):
+        self.ctx.prove_wait(ticket, partial=True)
+
+    def gather_done(self):
+        self.torch.cuda.current_stream().synchronize()   # the all-gather runs on torch's stream
+
     def combine(self, gathered, world, r, s):
-        self.torch.cuda.synchronize()
+        self.gather_done()
         return self.ctx.prove_combine(self.crs, gathered.data_ptr(), world, r, s)
 
 
@@ -40,3 +49,28 @@ def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     else:
         gathered.copy_(part)
     return prover.combine(gathered, world, r, s)
+
+
+def prove_sharded_stream(prover, dist, rank, world, jobs, depth=2):
+    """Pipelined prove_sharded over a sequence of (r, s) jobs: the partial sums of proof k+1 are enqueued
+    before proof k's all-gather and final assembly, so the GPU never idles on the collective or on the
+    latency-bound tail.  `depth` proofs are in flight (the C ABI allows two).  Yields the proof bytes in order."""
+    bufs = [(prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES)) for _ in range(depth)]
+    inflight = []
+
+    def finish(item):
+        ticket, (part, gathered), r, s = item
+        prover.partial_wait(ticket)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, part)
+        else:
+            gathered.copy_(part)
+        return prover.combine(gathered, world, r, s)
+
+    for k, (r, s) in enumerate(jobs):
+        if len(inflight) == depth:
+            yield finish(inflight.pop(0))
+        buf = bufs[k % depth]
+        inflight.append((prover.partial_submit(rank, world, r, s, buf[0]), buf, r, s))
+    while inflight:
+        yield finish(inflight.pop(0))
