@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic, 1 GPU only: time rank 0's share of a W-way window-sharded proof (no collective) instead of whole proofs")
     ap.add_argument("--serialize", action="store_true", help="measurement mode: no kernel overlap (stand-alone kernel durations)")
     ap.add_argument("--seed", type=int, default=20260929)
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
@@ -145,8 +147,28 @@ def main():
         bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
 
     depth = args.depth
+    if args.emulate_world and world == 1:
+        from zksnark_rs_amd.distributed import GpuProver, prove_sharded_stream
+        prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
+        import types
+        W = args.emulate_world
+        orig = prover.partial_submit
+        prover.partial_submit = lambda rank, world_, r, s, out: orig(0, W, r, s, out)   # rank 0 of W
+        prover.combine = lambda gathered, world_, r, s: b""                               # no collective, no assembly
+        t0 = time.perf_counter()
+        for _ in prove_sharded_stream(prover, None, 0, 1, [(inst["r"], inst["s"])] * args.warmup, depth):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in prove_sharded_stream(prover, None, 0, 1, [(inst["r"], inst["s"])] * args.steps, depth):
+            pass
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"diagnostic": "rank 0 of a %d-way window-sharded prover, partial sums only" % W, "ms_per_proof_per_rank": round(dt * 1e3, 3),
+                          "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
+        return
 
-    def run(k):
+    def run(k, shard=shard):
         """k proofs, all submitted and completed inside this call; returns their bytes."""
         if shard and depth == 1:
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
@@ -183,6 +205,24 @@ def main():
         elapsed = float(t.item())
     prof = ctx.profile()
     ctx.set_option("profile", 0)
+    # beside the window-sharded line (north_star, configs[4]): the same K steps as independent provers, one
+    # per GPU, no collective -- the throughput mode.  Reported as a secondary object, never as `value`.
+    replicas = None
+    if shard:
+        run(args.warmup, shard=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        rep_out = run(args.steps, shard=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e2 = time.perf_counter() - t1
+        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        assert all(p == proofs_out[0] for p in rep_out), "replica proof differs from the sharded proof"
+        replicas = {"mode": "replicas x%d (independent provers, no collective)" % world, "value": round(world * args.steps / e2, 4),
+                    "unit": "proofs/s", "scaling": "weak", "ms_per_step": round(1e3 * e2 / args.steps, 3)}
     for p in proofs_out:
         assert proof is None or p == proof, "non-deterministic proof bytes"
         proof = p
@@ -218,6 +258,7 @@ def main():
                        "parallelism": ("msm-window-shard x%d + RCCL all-gather" % world) if shard else ("replicas x%d" % world),
                        "proofs_in_flight": depth, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
+            **({"replicas": replicas} if replicas else {}),
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
