@@ -71,6 +71,13 @@ def cpu_baseline(zk, ctx, seed):
     cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
     fast_sec, proof = orc.time_prove_sparse(desc, cdesc, inst["weights"], inst["r"], inst["s"], False, 1)
     assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU/GPU proofs differ"
+    # the same algorithm on many host threads at BASELINE's 2^16 size (five inner products x windows, NTT stages split)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    inst = build_instance(zk, ctx, 16, seed + 16)
+    desc = ctx.sparse_desc(16, inst["m"], inst["l"], *inst["rows"])
+    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
+    mt_sec, proof = orc.time_prove_sparse_mt(desc, cdesc, inst["weights"], inst["r"], inst["s"], threads, 1)
+    assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU/GPU proofs differ"
     return {
         "value": 1.0 / t20, "unit": "proofs/s", "cores": 1, "kind": "port",
         "sample": "oracle faithful prove() on the chain circuit, measured n=2^5..2^8 (%s s/proof), "
@@ -78,6 +85,8 @@ def cpu_baseline(zk, ctx, seed):
                   "cannot be built here" % ([round(t, 3) for _, t in pts], k2, k1, t20),
         "cpu_same_algorithm": {"n": 1 << 12, "seconds_per_proof": fast_sec, "cores": 1,
                                "note": "oracle NTT+Pippenger prove measured at 2^12; ~n log n scaling => x%.0f at 2^20" % (256 * 20 / 12.0)},
+        "cpu_same_algorithm_threads": {"n": 1 << 16, "seconds_per_proof": mt_sec, "cores": threads,
+                                       "note": "same path on %d host threads at 2^16; ~n log n scaling => x%.0f at 2^20" % (threads, 16 * 20 / 16.0)},
         "wall_s": round(time.time() - t_start, 1),
     }
 

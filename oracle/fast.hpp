@@ -11,6 +11,9 @@
 //   SparseQap::*      == QAP::from(root_rep) + setup/prove with roots = omega^j
 //                        (/root/reference/src/groth16/fr.rs:140-173, mod.rs:134-296)
 #pragma once
+#include <atomic>
+#include <functional>
+#include <thread>
 #include <algorithm>
 #include "groth16.hpp"
 
@@ -24,7 +27,18 @@ static inline uint32_t bitrev32(uint32_t x, unsigned bits) {
 
 // In-place radix-2 NTT, natural order in and out: out[k] = sum_j in[j] * w^(jk), w = root of
 // unity of order 2^log_n (inverse: w^-1 and scaling by n^-1, as field::idft).
-inline void fr_ntt(std::vector<Fr>& a, unsigned log_n, bool inverse) {
+// tasks 0..count-1 pulled from an atomic counter by `threads` workers (threads <= 1: inline)
+inline void parallel_for(size_t count, unsigned threads, const std::function<void(size_t)>& fn) {
+    if (threads <= 1 || count <= 1) { for (size_t i = 0; i < count; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    unsigned nt = (unsigned)std::min<size_t>(threads, count);
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < count;) fn(i); });
+    for (auto& th : pool) th.join();
+}
+
+inline void fr_ntt(std::vector<Fr>& a, unsigned log_n, bool inverse, unsigned threads = 1) {
     size_t n = (size_t)1 << log_n;
     Fr w = fr_root_of_unity((int)log_n);
     if (inverse) w = w.inv();
@@ -36,13 +50,17 @@ inline void fr_ntt(std::vector<Fr>& a, unsigned log_n, bool inverse) {
         std::vector<Fr> tw(half);
         tw[0] = Fr::one();
         for (size_t k = 1; k < half; ++k) tw[k] = tw[k - 1] * wm;
-        for (size_t base = 0; base < n; base += 2 * half)
-            for (size_t k = 0; k < half; ++k) {
+        // n/2 butterflies per stage, split into contiguous blocks of butterfly indices
+        const size_t total = n >> 1, blocks = threads > 1 ? std::min<size_t>(total, (size_t)threads * 4) : 1;
+        parallel_for(blocks, threads, [&](size_t blk) {
+            for (size_t b = total * blk / blocks, e = total * (blk + 1) / blocks; b < e; ++b) {
+                size_t k = b & (half - 1), base = (b >> (s - 1)) << s;
                 Fr t = tw[k] * a[base + k + half];
                 Fr u = a[base + k];
                 a[base + k] = u + t;
                 a[base + k + half] = u - t;
             }
+        });
     }
     if (inverse) {
         Fr ninv = Fr::from_u64(n).inv();
@@ -76,14 +94,13 @@ Jac<F> madd(const Jac<F>& p, const Affine<F>& q) {
 
 // Pippenger bucket MSM, unsigned c-bit windows.
 template <class F>
-Jac<F> msm_pippenger(const std::vector<Affine<F>>& pts, const std::vector<U256>& sc, unsigned c) {
+Jac<F> msm_pippenger(const std::vector<Affine<F>>& pts, const std::vector<U256>& sc, unsigned c, unsigned threads = 1) {
     size_t n = std::min(pts.size(), sc.size());
     unsigned windows = (256 + c - 1) / c;
-    Jac<F> total = Jac<F>::zero();
-    std::vector<Jac<F>> buckets((size_t)1 << c);
-    for (int w = (int)windows - 1; w >= 0; --w) {
-        for (unsigned k = 0; k < c; ++k) total = total.dbl();
-        for (auto& b : buckets) b = Jac<F>::zero();
+    // windows are independent (one task each); the Horner combination over windows is serial
+    std::vector<Jac<F>> wsum(windows, Jac<F>::zero());
+    parallel_for(windows, threads, [&](size_t w) {
+        std::vector<Jac<F>> buckets((size_t)1 << c, Jac<F>::zero());
         unsigned lo = (unsigned)w * c;
         for (size_t i = 0; i < n; ++i) {
             uint32_t d = 0;
@@ -92,7 +109,12 @@ Jac<F> msm_pippenger(const std::vector<Affine<F>>& pts, const std::vector<U256>&
         }
         Jac<F> run = Jac<F>::zero(), acc = Jac<F>::zero();
         for (size_t b = buckets.size() - 1; b >= 1; --b) { run = run + buckets[b]; acc = acc + run; }
-        total = total + acc;
+        wsum[w] = acc;
+    });
+    Jac<F> total = Jac<F>::zero();
+    for (int w = (int)windows - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < c; ++k) total = total.dbl();
+        total = total + wsum[w];
     }
     return total;
 }
@@ -224,17 +246,17 @@ struct FastProveStats { double t_eval = 0, t_ntt = 0, t_msm = 0; };
 // prove for a SparseQap: NTT for interpolation / product, exact division by t = x^n - 1,
 // Pippenger for the five inner products.  Same group elements as prove_with_rs.
 inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std::vector<Fr>& weights,
-                                const Fr& r, const Fr& s, unsigned c = 0) {
+                                const Fr& r, const Fr& s, unsigned c = 0, unsigned threads = 1) {
     size_t n = q.n();
     if (c == 0) c = q.log_n <= 8 ? 4 : (q.log_n <= 14 ? q.log_n - 4 : 12);
     std::vector<Fr> U = q.eval_vec(q.u, weights), V = q.eval_vec(q.v, weights), W = q.eval_vec(q.w, weights);
-    fr_ntt(U, q.log_n, true); fr_ntt(V, q.log_n, true); fr_ntt(W, q.log_n, true);   // coefficient form
+    fr_ntt(U, q.log_n, true, threads); fr_ntt(V, q.log_n, true, threads); fr_ntt(W, q.log_n, true, threads);   // coefficient form
     // product on a domain of size 2n
     std::vector<Fr> A = U, B = V;
     A.resize(2 * n, Fr::zero()); B.resize(2 * n, Fr::zero());
-    fr_ntt(A, q.log_n + 1, false); fr_ntt(B, q.log_n + 1, false);
+    fr_ntt(A, q.log_n + 1, false, threads); fr_ntt(B, q.log_n + 1, false, threads);
     for (size_t i = 0; i < 2 * n; ++i) A[i] = A[i] * B[i];
-    fr_ntt(A, q.log_n + 1, true);
+    fr_ntt(A, q.log_n + 1, true, threads);
     for (size_t i = 0; i < n; ++i) A[i] = A[i] - W[i];           // P = U*V - W, deg <= 2n-2
     // long division by x^n - 1: q_k = r_{k+n}, r_k += r_{k+n}, top down
     std::vector<Fr> h(n > 0 ? n - 1 : 0, Fr::zero());
@@ -243,12 +265,20 @@ inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std:
         std::vector<U256> out; for (size_t i = 0; i < std::min(cnt, v.size()); ++i) out.push_back(v[i].to_u256()); return out; };
     auto xi1 = to_affine_vec(crs.s1.xi, n);
     auto xi2 = to_affine_vec(crs.s2.xi, n);
-    G1 a_g1 = msm_pippenger(xi1, scal(U, n), c);
-    G1 b_g1 = msm_pippenger(xi1, scal(V, n), c);
-    G2 b_g2 = msm_pippenger(xi2, scal(V, n), c);
-    G1 c_h = msm_pippenger(to_affine_vec(crs.s1.xi_t, n), scal(h, n), c);
     std::vector<Fr> wl(weights.begin() + std::min(weights.size(), q.input + 1), weights.end());
-    G1 c_l = msm_pippenger(to_affine_vec(crs.s1.sum_delta, (size_t)-1), scal(wl, (size_t)-1), c);
+    auto xit = to_affine_vec(crs.s1.xi_t, n), sdl = to_affine_vec(crs.s1.sum_delta, (size_t)-1);
+    auto su = scal(U, n), sv = scal(V, n), sh = scal(h, n), sl = scal(wl, (size_t)-1);
+    G1 a_g1, b_g1, c_h, c_l;
+    G2 b_g2;
+    // the five inner products are independent: with threads > 1 each gets a share of the workers
+    const unsigned per = threads > 1 ? std::max(1u, threads / 5) : 1;
+    parallel_for(5, threads > 1 ? 5 : 1, [&](size_t k) {
+        if (k == 0) a_g1 = msm_pippenger(xi1, su, c, per);
+        if (k == 1) b_g1 = msm_pippenger(xi1, sv, c, per);
+        if (k == 2) b_g2 = msm_pippenger(xi2, sv, c, per);
+        if (k == 3) c_h = msm_pippenger(xit, sh, c, per);
+        if (k == 4) c_l = msm_pippenger(sdl, sl, c, per);
+    });
     G1 a = a_g1 + crs.s1.alpha + crs.s1.delta.mul(r);
     G2 b = b_g2 + crs.s2.beta + crs.s2.delta.mul(s);
     G1 cc = c_h + c_l + a.mul(s) + (crs.s1.beta + b_g1 + crs.s1.delta.mul(s)).mul(r) - crs.s1.delta.mul(r * s);

@@ -22,6 +22,7 @@ class Oracle:
     def __init__(self, path):
         self.lib = C.CDLL(path)
         self.lib.orc_time_prove_sparse.restype = C.c_double
+        self.lib.orc_time_prove_sparse_mt.restype = C.c_double
 
     @staticmethod
     def _chk(rc):
@@ -119,6 +120,14 @@ class Oracle:
         out = np.zeros(259, np.uint8)
         sec = self.lib.orc_time_prove_sparse(C.byref(desc), C.byref(crs_desc), _p(w), C.c_size_t(w.shape[0]),
                                              _p(fr_to_limbs(r)), _p(fr_to_limbs(s)), int(faithful), int(reps), out.ctypes.data_as(u8p))
+        return sec, out.tobytes()
+
+    def time_prove_sparse_mt(self, desc, crs_desc, weights, r, s, threads, reps=1):
+        """NTT + Pippenger path on `threads` host threads; returns (seconds per proof, proof bytes)."""
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.uint64).reshape(-1, 4))
+        out = np.zeros(259, np.uint8)
+        sec = self.lib.orc_time_prove_sparse_mt(C.byref(desc), C.byref(crs_desc), _p(w), C.c_size_t(w.shape[0]),
+                                                _p(fr_to_limbs(r)), _p(fr_to_limbs(s)), int(threads), int(reps), out.ctypes.data_as(u8p))
         return sec, out.tobytes()
 
     def prove_dense(self, u, v, w, t, input, crs_desc, weights, r, s):
