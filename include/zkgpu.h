@@ -43,7 +43,8 @@ typedef enum {
     ZK_ERR_SIZE = -4,         /* size outside the supported range */
     ZK_ERR_DIV_BY_ZERO = -5,  /* "Dividend must be non-zero" (field/mod.rs:440) / Fr inverse of 0 (fr.rs:54,69) */
     ZK_ERR_RANGE = -6,        /* an Fr/Fq input is >= its modulus */
-    ZK_ERR_UNSUPPORTED = -7
+    ZK_ERR_UNSUPPORTED = -7,
+    ZK_ERR_IO = -8            /* file missing, truncated, altered or not in the expected format */
 } zk_status;
 
 #define ZK_PROOF_BYTES 259
@@ -177,6 +178,14 @@ typedef struct {
 int zk_crs_dims(const zk_crs* crs, size_t* n, size_t* m, size_t* input);
 int zk_crs_download(zk_ctx* ctx, const zk_crs* crs, const zk_crs_out* out);
 void zk_crs_free(zk_crs* crs);
+
+/* On-disk CRS container.  The reference has no serialisation of SigmaG1/SigmaG2
+ * (groth16/mod.rs:105-121), and setup (mod.rs:134-197) draws a fresh trapdoor on every call, so a CRS must be
+ * written down to be reused.  Format: "ZKCRSv1\0", n, m, input, FNV-1a-64 of the payload, then the arrays of
+ * zk_crs_desc in declaration order as canonical little-endian words.  zk_crs_load range-checks every coordinate
+ * and returns ZK_ERR_IO for a missing, truncated or altered file. */
+int zk_crs_save(zk_ctx* ctx, const zk_crs* crs, const char* path);
+int zk_crs_load(zk_ctx* ctx, const char* path, zk_crs** out);
 
 /* ------------------------------------------------------------------------------------------
  * prove  (groth16::prove, groth16/mod.rs:213-296) with (r, s) injected (mod.rs:231)

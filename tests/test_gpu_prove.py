@@ -125,6 +125,47 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     assert got[1] == ctx.prove(crs, inst["qap"], inst["weights"], inst["s"], inst["r"])
 
 
+def test_crs_file_round_trip(ctx, orc, tmp_path):
+    """zk_crs_save / zk_crs_load: same arrays, same proof bytes; altered, truncated and
+    missing files are refused with ZK_ERR_IO, out-of-range coordinates with ZK_ERR_RANGE."""
+    inst = chain_instance(ctx, 6, 606)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    want = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
+    path = tmp_path / "chain6.zkcrs"
+    ctx.crs_save(crs, path)
+    raw = path.read_bytes()
+    n, m, l = inst["n"], inst["m"], inst["l"]
+    assert raw[:8] == b"ZKCRSv1\0" and len(raw) == 40 + 64 * (3 + n + (l + 1) + (m - l - 1) + (n - 1)) + 128 * (3 + n)
+    assert [int.from_bytes(raw[8 + 8 * k:16 + 8 * k], "little") for k in range(3)] == [n, m, l]
+    crs2 = ctx.crs_load(path)
+    assert (crs2.n, crs2.m, crs2.input) == (n, m, l)
+    assert_crs_equal(ctx.crs_download(crs), ctx.crs_download(crs2))
+    assert ctx.prove(crs2, inst["qap"], inst["weights"], inst["r"], inst["s"]) == want
+    assert ctx.verify(crs2, [zk.limbs_to_int(inst["weights"][1]), zk.limbs_to_int(inst["weights"][2])], want)
+
+    def refused(data, status):
+        bad = tmp_path / "bad.zkcrs"
+        bad.write_bytes(data)
+        with pytest.raises(zk.ZkError) as e:
+            ctx.crs_load(bad)
+        assert e.value.status == status, (e.value.status, status)
+    IO, RANGE = -8, -6
+    flipped = bytearray(raw); flipped[40 + 64 * 5 + 3] ^= 0x10
+    refused(bytes(flipped), IO)                      # payload altered: checksum
+    refused(raw[:-8], IO)                            # truncated
+    refused(raw + b"\0", IO)                         # trailing bytes
+    refused(b"ZKCRSv2\0" + raw[8:], IO)              # wrong magic
+    # a coordinate >= q with a matching checksum is still rejected (range check on the GPU)
+    big = bytearray(raw); big[40 + 64 * 3: 40 + 64 * 3 + 32] = b"\xff" * 32
+    h = 0xcbf29ce484222325
+    for byte in big[40:]:
+        h = ((h ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    big[32:40] = h.to_bytes(8, "little")
+    refused(bytes(big), RANGE)
+    with pytest.raises(zk.ZkError):
+        ctx.crs_load(tmp_path / "does-not-exist.zkcrs")
+
+
 def test_pipelined_submit_wait(ctx, orc):
     """zk_prove_submit / zk_prove_wait: two proofs in flight, of different circuits, witnesses and
     (r, s), give the same bytes as the synchronous call; a third submit is refused; a device-side

@@ -294,6 +294,19 @@ class Context:
         c.n, c.m, c.input = n, m, input
         return c
 
+    def crs_save(self, crs, path):
+        """Write the CRS container (zk_crs_save)."""
+        self._check(self.lib.zk_crs_save(self.ptr, crs.ptr, str(path).encode()))
+
+    def crs_load(self, path):
+        p = C.c_void_p()
+        self._check(self.lib.zk_crs_load(self.ptr, str(path).encode(), C.byref(p)))
+        c = Crs(self, p, self.lib.zk_crs_free)
+        n, m, l = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self.lib.zk_crs_dims(p, C.byref(n), C.byref(m), C.byref(l)))
+        c.n, c.m, c.input = n.value, m.value, l.value
+        return c
+
     # ---- prove ----
     def prove(self, crs, qap, weights, r, s):
         """groth16::prove (mod.rs:213-296) with (r, s) injected; returns the 259-byte canonical proof."""

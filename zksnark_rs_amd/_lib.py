@@ -76,6 +76,8 @@ SIGNATURES = {
     "zk_crs_download": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CrsOut)]),
     "zk_crs_free": (None, [C.c_void_p]),
     "zk_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64p, C.c_size_t, u64p, u64p, u8p]),
+    "zk_crs_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p]),
+    "zk_crs_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "zk_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
     "zk_prove_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
     "zk_prove_wait": (C.c_int, [C.c_void_p, C.c_int, u8p]),

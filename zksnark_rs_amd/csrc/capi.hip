@@ -19,6 +19,7 @@ const char* zk_strerror(int status) {
         case ZK_ERR_DIV_BY_ZERO: return "division by zero";
         case ZK_ERR_RANGE: return "field element out of range";
         case ZK_ERR_UNSUPPORTED: return "unsupported";
+        case ZK_ERR_IO: return "file missing, truncated, altered or in the wrong format";
         default: return "unknown status";
     }
 }
@@ -160,6 +161,15 @@ int zk_crs_dims(const zk_crs* crs, size_t* n, size_t* m, size_t* input) {
     if (!crs) return ZK_ERR_ARG;
     crs_dims(*crs, n, m, input);
     return ZK_OK;
+}
+int zk_crs_save(zk_ctx* ctx, const zk_crs* crs, const char* path) {
+    if (!ctx || !crs || !path) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { crs_save(ctx, *crs, path); });
+}
+int zk_crs_load(zk_ctx* ctx, const char* path, zk_crs** out) {
+    if (!ctx || !path || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = crs_load(ctx, path); });
 }
 int zk_crs_download(zk_ctx* ctx, const zk_crs* crs, const zk_crs_out* out) {
     if (!ctx || !crs || !out) return ZK_ERR_ARG;

@@ -64,6 +64,8 @@ zk_crs* crs_upload(zk_ctx*, const zk_crs_desc&);
 zk_crs* crs_setup(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20]);
 void crs_dims(const zk_crs&, size_t* n, size_t* m, size_t* input);
 void crs_download(zk_ctx*, const zk_crs&, const zk_crs_out&);
+void crs_save(zk_ctx*, const zk_crs&, const char* path);     // serialize.hip
+zk_crs* crs_load(zk_ctx*, const char* path);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
 void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n);
