@@ -29,13 +29,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_instance(zk, ctx, log_n, seed):
+def build_instance(zk, ctx, log_n, seed, witness="uniform"):
     from zksnark_rs_amd.circuits import chain_rows, chain_weights
     rng = zk.SplitMix64(seed)
     n = 1 << log_n
     m, l, u, v, w = chain_rows(log_n)
     x = rng.fr()
-    weights = chain_weights(log_n, x, [rng.fr() for _ in range(n)])
+    if witness == "boolean":    # inputs a_k in {0, 1}: half of all wires are bits (one very heavy MSM bucket)
+        avals = [rng.next() & 1 for _ in range(n)]
+    elif witness == "small":    # 32-bit inputs
+        avals = [rng.next() & 0xFFFFFFFF for _ in range(n)]
+    else:
+        avals = [rng.fr() for _ in range(n)]
+    weights = chain_weights(log_n, x, avals)
     td = zk.ints_to_limbs([rng.fr() for _ in range(5)])
     r, s = rng.fr(), rng.fr()
     qap = ctx.qap_sparse(log_n, m, l, u, v, w)
@@ -118,6 +124,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, 1 GPU only: time rank 0's share of a W-way window-sharded proof (no collective) instead of whole proofs")
     ap.add_argument("--serialize", action="store_true", help="measurement mode: no kernel overlap (stand-alone kernel durations)")
+    ap.add_argument("--witness", choices=["uniform", "boolean", "small"], default="uniform",
+                    help="distribution of the chain circuit's inputs a_k (the metric is quoted on 'uniform')")
     ap.add_argument("--seed", type=int, default=20260929)
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="proofs in flight per GPU (zk_prove_submit/zk_prove_wait); 1 = synchronous zk_prove_dev")
@@ -146,7 +154,7 @@ def main():
         ctx.set_option("serialize", 1)
     if args.lane_entries:
         ctx.set_option("msm_lane_entries", args.lane_entries)
-    inst = build_instance(zk, ctx, args.log_n, args.seed)
+    inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness)
     d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
     m = inst["m"]
     shard = world > 1 and args.mode == "shard"
@@ -261,7 +269,7 @@ def main():
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if shard or world == 1 else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
-            "data": "synthetic (chain circuit, SplitMix64 seed %d)" % args.seed,
+            "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d)" % (args.witness, args.seed),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM"
                                    % (args.log_n, m),
                        "parallelism": ("msm-window-shard x%d + RCCL all-gather" % world) if shard else ("replicas x%d" % world),
