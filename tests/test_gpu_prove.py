@@ -93,6 +93,42 @@ def test_prove_sparse_matches_trapdoor_proof(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], bad, inst["r"], inst["s"]) == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], bad, inst["r"], inst["s"])
 
 
+def random_sparse_rows(rng, n, m, density):
+    """(ptr, gate, val) by wire with random non-zero entries (distinct gates per wire), some wires empty."""
+    ptr, gates, vals = [0], [], []
+    for _ in range(m):
+        k = rng.next() % (density + 1)
+        gs = sorted({int(rng.next() % n) for _ in range(k)})
+        gates += gs
+        vals += [rng.fr() for _ in gs]
+        ptr.append(len(gates))
+    val = ints_to_limbs(vals) if vals else np.zeros((0, 4), np.uint64)
+    return np.array(ptr, np.uint64), np.array(gates, np.uint32), val
+
+
+@pytest.mark.parametrize("log_n,m,l,faithful", [(3, 5, 1, True), (5, 70, 4, True), (6, 40, 0, True), (9, 1300, 7, False), (11, 3000, 2, False)])
+def test_random_sparse_qap_setup_and_prove(ctx, orc, log_n, m, l, faithful):
+    """Arbitrary RootRepresentation-shaped QAPs (not the chain circuit): random entries, empty wires,
+    m unrelated to n, random (unsatisfying) witnesses of the exact, a shorter and a longer length."""
+    rng = SplitMix64(7000 + log_n)
+    n = 1 << log_n
+    u, v, w = (random_sparse_rows(rng, n, m, 3) for _ in range(3))
+    desc = ctx.sparse_desc(log_n, m, l, u, v, w)
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    arrs = ctx.crs_download(crs)
+    assert_crs_equal(arrs, orc.setup_sparse(desc, td, n, m, l, faithful))
+    cdesc = ctx.crs_desc(n, m, l, arrs)
+    r, s = rng.fr(), rng.fr()
+    for count in (m, max(l + 1, m - 3), m + 2):
+        wts = ints_to_limbs([1] + [rng.fr() for _ in range(count - 1)])
+        got = ctx.prove(crs, qap, wts, r, s)
+        assert got == orc.prove_sparse(desc, cdesc, wts, r, s, faithful), count
+        if count == m:
+            assert got == orc.trapdoor_proof_sparse(desc, td, wts, r, s)
+
+
 def test_prove_full_size_2_20(ctx, orc):
     """BASELINE configs 4/5 size: 2^20 constraints, proof bytes == trapdoor closed form."""
     inst = chain_instance(ctx, 20, 2020)
