@@ -48,6 +48,7 @@ typedef enum {
 } zk_status;
 
 #define ZK_PROOF_BYTES 259
+#define ZK_MAX_IN_FLIGHT 4   /* proofs one context can have submitted and not yet waited for */
 #define ZK_FR_WORDS 4
 #define ZK_G1_WORDS 8
 #define ZK_G2_WORDS 16
@@ -61,7 +62,8 @@ const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
 /* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (additions per lane of the
  * bucket accumulation, a multiple of 4; default 32), "profile" (0/1: per-kernel
- * event timing, read back with zk_profile_*), "serialize" (0/1: measurement mode, all kernels of a proof on
+ * event timing, read back with zk_profile_*), "msm_shard_points" (zk_prove_partial: 0 = a rank owns
+ * Pippenger windows, 1 = a rank owns a range of the points), "serialize" (0/1: measurement mode, all kernels of a proof on
  * one stream so that event timings are stand-alone durations).  Unknown keys return ZK_ERR_UNSUPPORTED. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);
@@ -198,8 +200,9 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
 
 /* Pipelined form of zk_prove_dev for a stream of proofs: zk_prove_submit enqueues the whole proof
  * and returns at once with a ticket; zk_prove_wait blocks until that proof's bytes are ready.  At most
- * two proofs may be in flight per context (a third submit returns ZK_ERR_ARG until one is waited for);
- * the second proof's witness products and NTT stage then run under the first one's reduction tail.
+ * ZK_MAX_IN_FLIGHT proofs may be in flight per context (a further submit returns ZK_ERR_ARG until one is waited
+ * for); the next proof's witness products and NTT stage then run under the previous one's reduction tail.  Two
+ * in flight saturate one GPU on whole proofs; the short per-rank shares of a sharded proof profit from four.
  * The witness buffer must stay valid and unmodified until the matching wait.  Errors that are only
  * detected on the device (witness element >= r) are reported by zk_prove_wait. */
 int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
@@ -216,7 +219,7 @@ int zk_prove_partial(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const vo
                      const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out);
 int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int world,
                      const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
-/* Pipelined form of zk_prove_partial (same two-in-flight rule as zk_prove_submit); finish with
+/* Pipelined form of zk_prove_partial (same in-flight rule as zk_prove_submit); finish with
  * zk_prove_wait(ctx, ticket, NULL), after which d_partial_out holds the rank's partial sums. */
 int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                             const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out, int* ticket);

@@ -145,12 +145,15 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     crs = ctx.setup(inst["qap"], inst["td"])
     want = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
     dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
-    for world in (1, 2, 4, 8):
-        buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
-        for rank in range(world):
-            ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
-        torch.cuda.synchronize()
-        assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want
+    for by_points in (0, 1):            # partial sums by Pippenger windows / by point ranges
+        ctx.set_option("msm_shard_points", by_points)
+        for world in (1, 2, 3, 4, 8):
+            buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            for rank in range(world):
+                ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+            torch.cuda.synchronize()
+            assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want, (by_points, world)
+    ctx.set_option("msm_shard_points", 0)
     assert ctx.prove_dev(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]) == want
     # pipelined form (zk_prove_partial_submit / zk_prove_wait): world 1 through the distributed driver
     from zksnark_rs_amd.distributed import GpuProver, prove_sharded_stream
@@ -203,9 +206,9 @@ def test_crs_file_round_trip(ctx, orc, tmp_path):
 
 
 def test_pipelined_submit_wait(ctx, orc):
-    """zk_prove_submit / zk_prove_wait: two proofs in flight, of different circuits, witnesses and
-    (r, s), give the same bytes as the synchronous call; a third submit is refused; a device-side
-    range error surfaces at wait and leaves the context usable."""
+    """zk_prove_submit / zk_prove_wait: several proofs in flight, of different circuits, witnesses and
+    (r, s), give the same bytes as the synchronous call; a submit beyond ZK_MAX_IN_FLIGHT is refused; a
+    device-side range error surfaces at wait and leaves the context usable."""
     torch = pytest.importorskip("torch")
     insts = [chain_instance(ctx, 12, 301), chain_instance(ctx, 9, 302)]
     jobs = []
@@ -219,19 +222,21 @@ def test_pipelined_submit_wait(ctx, orc):
             dw = torch.from_numpy(w.view(np.int64)).cuda()
             jobs.append((crs, inst, dw, r, s, ctx.prove(crs, inst["qap"], w, r, s)))
     assert jobs[0][5] == orc.trapdoor_proof_sparse(insts[0]["desc"], insts[0]["td"], insts[0]["weights"], jobs[0][3], jobs[0][4])
-    order = [0, 3, 1, 4, 2, 5, 0, 0, 3]      # alternate between the two circuits
-    inflight, got = [], []
-    for j in order:
-        crs, inst, dw, r, s, _ = jobs[j]
-        if len(inflight) == 2:
+    order = [0, 3, 1, 4, 2, 5, 0, 0, 3, 4, 1]      # alternate between the two circuits
+    for depth in (2, zk.MAX_IN_FLIGHT):
+        inflight, got = [], []
+        for j in order:
+            crs, inst, dw, r, s, _ = jobs[j]
+            if len(inflight) == depth:
+                got.append(ctx.prove_wait(inflight.pop(0)))
+            inflight.append(ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s))
+        if depth == zk.MAX_IN_FLIGHT:
+            with pytest.raises(zk.ZkError):
+                crs, inst, dw, r, s, _ = jobs[0]
+                ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s)   # every slot taken
+        while inflight:
             got.append(ctx.prove_wait(inflight.pop(0)))
-        inflight.append(ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s))
-    with pytest.raises(zk.ZkError):
-        crs, inst, dw, r, s, _ = jobs[0]
-        ctx.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s)   # two already in flight
-    while inflight:
-        got.append(ctx.prove_wait(inflight.pop(0)))
-    assert got == [jobs[j][5] for j in order]
+        assert got == [jobs[j][5] for j in order]
     with pytest.raises(zk.ZkError):
         ctx.prove_wait(0)                     # nothing in flight
     # witness element >= r: reported by the wait, next proof unaffected

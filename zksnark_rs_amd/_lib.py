@@ -13,6 +13,7 @@ ZK_OK = 0
 ZK_ERR_ARG, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_SIZE, ZK_ERR_DIV_BY_ZERO, ZK_ERR_RANGE, ZK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 PROOF_BYTES = 259
 PARTIAL_BYTES = 768
+MAX_IN_FLIGHT = 4      # ZK_MAX_IN_FLIGHT
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

@@ -65,14 +65,15 @@ void msm_set_lds_attributes();
 template <class F>
 void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& out);
 // sum_{i < n_used} scalars[i] * P_i over the table's bases; scalars are CANONICAL Fr limbs.
-// Only windows w = rank (mod world) are accumulated (multi-GPU partial sums).  Everything is
+// Only windows w = rank (mod world) are accumulated (multi-GPU partial sums by windows); `point_offset`
+// selects the bases [point_offset, point_offset + n_used) of the table instead (partial sums by point ranges).  Everything is
 // enqueued on `st`; the result (Jacobian, Montgomery) lands in d_out.
 // `acc_wait` (may be null): event the bucket accumulation waits for; `acc_done` (may be null): event
 // recorded right after it.  The accumulation kernels each fill every SIMD, so the pipeline chains
 // them in a chosen order instead of letting them thrash each other's caches.
 template <class F>
 void msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr);
+             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0);
 template <class F>
 void msm_host(zk_ctx*, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine);
 

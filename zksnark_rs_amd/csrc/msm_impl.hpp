@@ -481,11 +481,11 @@ __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict
 
 template <class F>
 void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done) {
+             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset) {
     const bool g2 = sizeof(F) > sizeof(Fq);
     const int c = tab.c, windows = tab.windows, buckets = 1 << (c - 1);
     const size_t n = tab.n;
-    ZK_REQUIRE(n_used <= n, ZK_ERR_ARG, "msm: more scalars than table points");
+    ZK_REQUIRE(point_offset <= n && n_used <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
     int owned = 0;
     for (int w = rank; w < windows; w += world) ++owned;
     if (n_used == 0 || owned == 0) {
@@ -553,7 +553,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         // every lane parks one accumulator image
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(AccSlot<F>) * lanes, st);
-        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, st, tab.table.p, ws.sorted.p, ws.start.p, buckets, per_lane,
+        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, st, tab.table.p + point_offset, ws.sorted.p, ws.start.p, buckets, per_lane,
                            d_first, d_last, d_mid);
     }
     if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
@@ -574,7 +574,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     ZK_HIP(hipGetLastError());
 }
-template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t);
+template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t);
 
 #ifdef ZK_MSM_COMMON
 void msm_set_lds_attributes() {

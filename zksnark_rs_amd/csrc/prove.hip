@@ -150,7 +150,7 @@ struct AssembleScratch {
 };
 
 // ---- pipeline state: everything one in-flight proof owns ---------------------------------------
-// Two slots let zk_prove_submit enqueue proof k+1 (its sorting / NTT stage / first accumulation)
+// Several slots let zk_prove_submit enqueue proof k+1 (its sorting / NTT stage / first accumulation)
 // while the latency-bound tail of proof k (reductions, assembly, copy-out) is still running.
 struct ProveSlot {
     DevBuf<Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b;
@@ -187,7 +187,7 @@ struct ProveSlot {
     }
 };
 struct ProveState {
-    static constexpr int SLOTS = 2;
+    static constexpr int SLOTS = ZK_MAX_IN_FLIGHT;
     ProveSlot slot[SLOTS];
     int next = 0;
     hipEvent_t last_acc = nullptr;   // end of the most recently enqueued accumulation chain
@@ -228,7 +228,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
-    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: more than two proofs in flight (call zk_prove_wait first)");
+    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
     if (!q.dense) crs_ensure_tables(ctx, crs, true, q.log_n); else crs_ensure_tables(ctx, crs, false, 0);
     if (!d_partial_out) crs_ensure_fixed_tables(ctx, crs);
@@ -260,7 +260,14 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
-        msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, after >= 0 ? S.acc_evt[after] : ps.last_acc, S.acc_evt[k]);
+        hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
+        if (world > 1 && ctx->opt_shard_points) {
+            // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
+            const size_t lo = count * (size_t)rank / (size_t)world, hi = count * ((size_t)rank + 1) / (size_t)world;
+            msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], lo);
+        } else {
+            msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k]);
+        }
         ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
         ps.last_acc = S.acc_evt[k];
     };

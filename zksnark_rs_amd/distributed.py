@@ -51,10 +51,10 @@ def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     return prover.combine(gathered, world, r, s)
 
 
-def prove_sharded_stream(prover, dist, rank, world, jobs, depth=2):
+def prove_sharded_stream(prover, dist, rank, world, jobs, depth=4):
     """Pipelined prove_sharded over a sequence of (r, s) jobs: the partial sums of proof k+1 are enqueued
     before proof k's all-gather and final assembly, so the GPU never idles on the collective or on the
-    latency-bound tail.  `depth` proofs are in flight (the C ABI allows two).  Yields the proof bytes in order."""
+    latency-bound tail.  `depth` proofs are in flight (the C ABI allows ZK_MAX_IN_FLIGHT = 4).  Yields the proof bytes in order."""
     bufs = [(prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES)) for _ in range(depth)]
     inflight = []
 
