@@ -1,4 +1,4 @@
-// msm.hip -- fixed-base Pippenger multi-scalar multiplication in G1 and G2 for gfx950.
+// msm_impl.hpp -- fixed-base Pippenger multi-scalar multiplication in G1 and G2 for gfx950.
 //
 // Replaces the SigmaG1/SigmaG2 inner products of groth16::prove
 // (/root/reference/src/groth16/mod.rs:255-272,279-290): the reference performs n independent
@@ -13,16 +13,17 @@
 //     sum_i k_i P_i = sum_b b * ( sum_{(w,i): |digit_w(k_i)| = b} sign * T[w][i] )
 // which removes the per-window bucket reductions and the serial 254-doubling Horner tail of the
 // textbook algorithm.  Per MSM:
-//   hist      one workgroup per scalar chunk: signed-digit recoding + histogram of all owned
-//             windows in LDS (2^(c-1) counters = 128 KiB at c = 16), one row per chunk to HBM
-//   offsets   per bucket exclusive prefix over chunks, then a scan over buckets
-//   scatter   same chunks: counting sort of (w*n + i, sign) by bucket, positions from LDS atomics
-//   accumulate T lanes per bucket walk the bucket's list (strided, so the index list is read
-//             coalesced) doing mixed Jacobian+affine additions of gathered 64 B / 128 B points
-//   reduce    merge the T partials per bucket, segmented running sums for sum_b b*S_b, block
-//             tree reduction -> one point
-// Windows are independent: rank g of a multi-GPU job owns windows w = g (mod world) and needs
-// only those slices of T (MsmPlan::first_window / window_step).
+//   sort       two-level counting sort of the (window, point) digits by bucket: level 1 groups
+//              8-byte records by bin (high bits of the bucket id, one workgroup per scalar chunk,
+//              counters in LDS), level 2 sorts inside each bin by sub-bucket and emits the bucket
+//              offsets; signed-digit recoding happens on the fly in both level-1 passes
+//   accumulate every lane adds the same number of consecutive entries of the sorted list (gathered
+//              64 B / 128 B points) into a register-resident accumulator in the lazy radix-2^29
+//              form (lazy29.cuh) and parks the accumulator image at bucket boundaries
+//   merge      bucket sums from the parked images (a workgroup per bucket for heavy buckets)
+//   reduce     segmented running sums for sum_b b*S_b, block tree reductions -> one point
+// Multi-GPU partial sums: rank g of a job owns windows w = g (mod world) (the digit
+// loop skips other windows), or a range of the points with every window (point_offset).
 #pragma once
 #include "kernels.hpp"
 #include "lazy29.cuh"
