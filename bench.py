@@ -269,6 +269,17 @@ def main():
                         "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch,
                         "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
                         "note": "integer-ALU-bound kernel (254-bit modular multiply); HBM fraction is low by construction, see DESIGN.md"}
+            # the bound that actually binds: VALU issue.  Algorithmic bytes per addition = 4 B index + 64 B point + the lane's
+            # share of its 160 B parked image (G1); 2650 = VALU instructions of one mixed addition in this build's ISA
+            # (DESIGN.md 4c); 39.3e12 = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
+            if name == "msm_accumulate_g1":
+                adds = bytes_per_launch / (4.0 + 64.0 + 160.0 / 32.0)
+                rate = adds / (avg_ms * 1e-3)
+                roofline["alu"] = {"additions_per_launch": round(adds), "G_additions_per_s": round(rate / 1e9, 2),
+                                   "valu_instr_per_addition": 2650, "valu_issue_peak_T_per_s": 39.3,
+                                   "valu_issue_frac": round(rate * 2650 / 39.3e12, 3),
+                                   "note": "measured while sort / NTT / merge kernels of neighbouring products share the SIMDs; "
+                                           "stand-alone (--serialize --depth 1) the same kernel reaches 0.92"}
         n = inst["n"]
         out = {
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
