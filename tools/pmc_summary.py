@@ -8,9 +8,11 @@ Usage (on the GPU box, separate passes as gpurun requires -- FETCH_SIZE and WRIT
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are reported in KiB; FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced streaming
-reads, so it is doubled ("corrected"); WRITE_SIZE is taken as reported (uncalibrated).  For gather-dominated
-kernels (k_msm_accumulate reads one random 64 B / 128 B point per addition) the doubled figure is an upper
-bound; both raw and corrected values are kept.
+reads, so it is doubled ("corrected"); WRITE_SIZE is taken as reported (uncalibrated).  The guide asks for a
+calibration on a known byte count for other access patterns: tools/ubench_gather.hip (random per-lane gathers
+from a 4 GiB table; profiles/r1_fetch_calibration.txt) measured FETCH_SIZE = 1.00 x the gathered bytes for
+64-byte elements (the G1 accumulation's pattern) and 0.50 x for 128-byte elements and for streams, so the
+factor is 1 for k_msm_accumulate<Fq> and 2 everywhere else.  Raw values are kept beside the corrected ones.
 """
 import csv
 import glob
@@ -34,19 +36,24 @@ def load(dirname, counter):
     return per
 
 
+FETCH_FACTOR = {"zk::k_msm_accumulate<zk::Fp<zk::FqParams> >": 1.0}   # calibrated; default 2.0
+
+
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; corrected = (2 * fetch + write) * 1024 bytes",
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; corrected = (factor * fetch + write) * 1024 bytes, factor = 2 "
+                    "(streams, 128 B gathers) or 1 (64 B gathers: k_msm_accumulate<Fq>), see profiles/r1_fetch_calibration.txt",
            "kernels": {}}
     for name in sorted(set(fetch) | set(write)):
         f, w = fetch.get(name, []), write.get(name, [])
         fa = sum(f) / len(f) if f else 0.0
         wa = sum(w) / len(w) if w else 0.0
+        k = FETCH_FACTOR.get(name, 2.0)
         out["kernels"][name] = {"launches_sampled": max(len(f), len(w)), "fetch_raw_KiB_per_launch": round(fa, 1),
-                                "write_raw_KiB_per_launch": round(wa, 1),
-                                "hbm_bytes_per_launch_corrected": int((2 * fa + wa) * 1024)}
+                                "write_raw_KiB_per_launch": round(wa, 1), "fetch_factor": k,
+                                "hbm_bytes_per_launch_corrected": int((k * fa + wa) * 1024)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
