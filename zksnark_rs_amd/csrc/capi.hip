@@ -49,7 +49,6 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
         }
-        msm_set_lds_attributes();
     });
     if (rc != ZK_OK) { delete ctx; return rc; }
     *out = ctx;

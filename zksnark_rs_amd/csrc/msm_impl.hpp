@@ -577,14 +577,6 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
 }
 template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t);
 
-#ifdef ZK_MSM_COMMON
-void msm_set_lds_attributes() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-}
-
-#endif  // ZK_MSM_COMMON
 
 template <class F>
 __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) {
@@ -596,7 +588,6 @@ __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) 
 template <class F>
 void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine) {
     ZK_REQUIRE(out_affine && (n == 0 || (points && scalars)), ZK_ERR_ARG, "zk_msm: null pointer");
-    msm_set_lds_attributes();
     DevBuf<Aff<F>> dp(n), daff(1);
     DevBuf<Fr> ds(n), tmp(n);
     DevBuf<Jac<F>> dres(1);
