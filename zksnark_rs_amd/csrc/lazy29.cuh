@@ -32,6 +32,7 @@ namespace zk {
 
 template <class PR>
 struct FpR {
+    typedef Fp<PR> Elem;
     int32_t v[9];
     static constexpr int32_t M29 = 0x1fffffff;
 
@@ -230,6 +231,7 @@ struct FpR {
 // Fq2 = Fq[i]/(i^2+1) over the lazy form; components of stored values are kept in normal form
 template <class PR>
 struct Fp2R {
+    typedef Fq2 Elem;
     FpR<PR> c0, c1;
     ZK_HD static Fp2R load(const Fq2& x) { return Fp2R{FpR<PR>::load(x.c0), FpR<PR>::load(x.c1)}; }
     ZK_HD Fp2R operator+(const Fp2R& o) const { return Fp2R{c0 + o.c0, c1 + o.c1}; }
@@ -345,26 +347,32 @@ ZK_HD bool madd_lazy(JacR<F>& p, const typename LazyOf<F>::type& qx, const typen
     return true;
 }
 
-// ---- bucket accumulator of the G1 MSM: extended Jacobian (XYZZ) coordinates --------------------
+// ---- bucket accumulator of the MSMs: extended Jacobian (XYZZ) coordinates ------------------------
 // x = X / ZZ, y = Y / ZZZ with ZZ^3 = ZZZ^2.  Mixed addition (madd-2008-s) needs no Z1^2 / Z1^3:
 //   U2 = x2 ZZ1, S2 = y2 ZZZ1, P = U2 - X1, R = S2 - Y1, PP = P^2, PPP = P PP, Q = X1 PP,
 //   X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - Y1 PPP,  ZZ3 = ZZ1 PP,  ZZZ3 = ZZZ1 PPP      (8M + 2S)
-// and Y3's two products share one Montgomery reduction (mont_diff): 1467 multiply-adds against
-// 1674 for the Jacobian form above.  Only the Fq accumulator uses it; the four Fq2 coordinates of a
-// G2 accumulator would not fit the register file.
-template <class PR>
+// Over Fq, Y3's two products share one Montgomery reduction (mont_diff): 1467 multiply-adds against
+// 1674 for the Jacobian form.  Over Fq2 the four coordinates take 72 registers: the kernel sits at the
+// 256-register limit with 16 dwords of scratch, and is still 6 % faster than the Jacobian accumulator.
+// L = FpR<..> (G1) or Fp2R<..> (G2).
+template <class L>
 struct XyzzR {
-    FpR<PR> X, Y, ZZ, ZZZ;
+    L X, Y, ZZ, ZZZ;
     bool inf;
 };
 
-// Returns false when the caller must take the slow path (P == Q: doubling).
+// R D - Y PPP: one reduction over Fq; over Fq2 the fused form would need 36 products per column (> 2^63)
 template <class PR>
-ZK_HD bool madd_xyzz(XyzzR<PR>& p, const FpR<PR>& qx, const FpR<PR>& qy) {
-    typedef FpR<PR> L;
+ZK_HD FpR<PR> xyzz_ydiff(const FpR<PR>& R, const FpR<PR>& D, const FpR<PR>& Y, const FpR<PR>& PPP) { return FpR<PR>::mont_diff(R, D, Y, PPP); }
+template <class PR>
+ZK_HD Fp2R<PR> xyzz_ydiff(const Fp2R<PR>& R, const Fp2R<PR>& D, const Fp2R<PR>& Y, const Fp2R<PR>& PPP) { return (R * D - Y * PPP).norm(); }
+
+// Returns false when the caller must take the slow path (P == Q: doubling).
+template <class L>
+ZK_HD bool madd_xyzz(XyzzR<L>& p, const L& qx, const L& qy) {
     if (p.inf) {
         p.X = qx; p.Y = qy.norm(); p.inf = false;   // qy may be a negated point (limbs <= 0): R = S2 - Y1 must stay below 2^29
-        p.ZZ = p.ZZZ = L::load(Fp<PR>::one());
+        p.ZZ = p.ZZZ = L::load(L::Elem::one());
         return true;
     }
     L U2 = qx * p.ZZ;
@@ -380,7 +388,7 @@ ZK_HD bool madd_xyzz(XyzzR<PR>& p, const FpR<PR>& qx, const FpR<PR>& qy) {
     L PPP = P * PP;
     L Q = p.X * PP;
     L X3 = (R.sqr() - PPP - (Q + Q)).norm();
-    p.Y = L::mont_diff(R, Q - X3, p.Y, PPP); // Q - X3: difference of two normal forms
+    p.Y = xyzz_ydiff(R, Q - X3, p.Y, PPP);   // Q - X3: difference of two normal forms
     p.X = X3;
     p.ZZ = p.ZZ * PP;
     p.ZZZ = p.ZZZ * PPP;
@@ -388,38 +396,39 @@ ZK_HD bool madd_xyzz(XyzzR<PR>& p, const FpR<PR>& qx, const FpR<PR>& qy) {
 }
 
 // Jacobian point with the same affine image: (X ZZ^2, Y ZZZ^2, ZZZ)
-template <class PR>
-ZK_HD Jac<Fp<PR>> xyzz_store(const XyzzR<PR>& p) {
-    if (p.inf) return Jac<Fp<PR>>::infinity();
-    FpR<PR> z2 = p.ZZ.sqr(), z3 = p.ZZZ.sqr();
-    return Jac<Fp<PR>>{(p.X * z2).store_exact(), (p.Y * z3).store_exact(), p.ZZZ.store_exact()};
+template <class L>
+ZK_HD Jac<typename L::Elem> xyzz_store(const XyzzR<L>& p) {
+    typedef typename L::Elem F;
+    if (p.inf) return Jac<F>::infinity();
+    L z2 = p.ZZ.sqr(), z3 = p.ZZZ.sqr();
+    return Jac<F>{(p.X * z2).store_exact(), (p.Y * z3).store_exact(), p.ZZZ.store_exact()};
 }
-template <class PR>
-ZK_HD XyzzR<PR> xyzz_from_jac(const Jac<Fp<PR>>& j) {
-    XyzzR<PR> r;
+template <class L>
+ZK_HD XyzzR<L> xyzz_from_jac(const Jac<typename L::Elem>& j) {
+    XyzzR<L> r;
     r.inf = j.is_inf();
-    FpR<PR> z = FpR<PR>::load(j.Z);
-    r.X = FpR<PR>::load(j.X); r.Y = FpR<PR>::load(j.Y);
+    L z = L::load(j.Z);
+    r.X = L::load(j.X); r.Y = L::load(j.Y);
     r.ZZ = z.sqr();
     r.ZZZ = r.ZZ * z;
     return r;
 }
 
 // p + q, both XYZZ (add-2008-s, 12M + 2S); operands hold normal forms (accumulator images)
-template <class PR>
-ZK_HD XyzzR<PR> add_xyzz(const XyzzR<PR>& p, const XyzzR<PR>& q) {
-    typedef FpR<PR> L;
+template <class L>
+ZK_HD XyzzR<L> add_xyzz(const XyzzR<L>& p, const XyzzR<L>& q) {
+    typedef typename L::Elem F;
     if (p.inf) return q;
     if (q.inf) return p;
     L U1 = p.X * q.ZZ, U2 = q.X * p.ZZ;
     L S1 = p.Y * q.ZZZ, S2 = q.Y * p.ZZZ;
     L P = U2 - U1, R = S2 - S1;
     L PP = P.sqr();
-    XyzzR<PR> r;
+    XyzzR<L> r;
     if (PP.is_zero_mod_p()) {
         if (R.sqr().is_zero_mod_p()) {       // same point: double through the Jacobian formulas (rare)
-            JacR<Fp<PR>> j = dbl_lazy(jacr_load(xyzz_store(p)));
-            return xyzz_from_jac<PR>(jacr_store(j));
+            JacR<F> j = dbl_lazy(jacr_load(xyzz_store(p)));
+            return xyzz_from_jac<L>(jacr_store(j));
         }
         r = p;
         r.inf = true;
@@ -429,22 +438,20 @@ ZK_HD XyzzR<PR> add_xyzz(const XyzzR<PR>& p, const XyzzR<PR>& q) {
     L Q = U1 * PP;
     L X3 = (R.sqr() - PPP - (Q + Q)).norm();
     r.inf = false;
-    r.Y = L::mont_diff(R, Q - X3, S1, PPP);
+    r.Y = xyzz_ydiff(R, Q - X3, S1, PPP);
     r.X = X3;
     r.ZZ = (p.ZZ * q.ZZ) * PP;
     r.ZZZ = (p.ZZZ * q.ZZZ) * PPP;
     return r;
 }
 
-// accumulator interface used by k_msm_accumulate: XYZZ in G1, Jacobian in G2
-template <class F> struct AccOf { typedef JacR<F> type; };
-template <> struct AccOf<Fq> { typedef XyzzR<FqParams> type; };
-
-ZK_HD void acc_clear(XyzzR<FqParams>& a) { a.inf = true; a.X = a.Y = a.ZZ = a.ZZZ = FpR<FqParams>::load(Fq::zero()); }
-ZK_HD bool acc_madd(XyzzR<FqParams>& a, const FpR<FqParams>& x, const FpR<FqParams>& y) { return madd_xyzz(a, x, y); }
-ZK_HD Jac<Fq> acc_store(const XyzzR<FqParams>& a) { return xyzz_store(a); }
-ZK_HD void acc_load(XyzzR<FqParams>& a, const Jac<Fq>& j) { a = xyzz_from_jac<FqParams>(j); }
-ZK_HD XyzzR<FqParams> acc_add(const XyzzR<FqParams>& a, const XyzzR<FqParams>& b) { return add_xyzz(a, b); }
+// accumulator interface used by k_msm_accumulate / k_msm_merge
+template <class F> struct AccOf { typedef XyzzR<typename LazyOf<F>::type> type; };
+template <class L> ZK_HD void acc_clear(XyzzR<L>& a) { a.inf = true; a.X = a.Y = a.ZZ = a.ZZZ = L::load(L::Elem::zero()); }
+template <class L> ZK_HD bool acc_madd(XyzzR<L>& a, const L& x, const L& y) { return madd_xyzz(a, x, y); }
+template <class L> ZK_HD Jac<typename L::Elem> acc_store(const XyzzR<L>& a) { return xyzz_store(a); }
+template <class L> ZK_HD void acc_load(XyzzR<L>& a, const Jac<typename L::Elem>& j) { a = xyzz_from_jac<L>(j); }
+template <class L> ZK_HD XyzzR<L> acc_add(const XyzzR<L>& a, const XyzzR<L>& b) { return add_xyzz(a, b); }
 
 // ---- general Jacobian addition / doubling in lazy form (reduction tail of the MSM) -------------
 template <class F>
@@ -523,10 +530,3 @@ ZK_HD JacR<F> mul_small_lazy(const JacR<F>& p, uint32_t k) {
 
 }  // namespace zk
 
-namespace zk {
-template <class F> ZK_HD void acc_clear(JacR<F>& a) { a.inf = true; a.X = a.Y = a.Z = LazyOf<F>::type::load(F::zero()); }
-template <class F> ZK_HD bool acc_madd(JacR<F>& a, const typename LazyOf<F>::type& x, const typename LazyOf<F>::type& y) { return madd_lazy<F>(a, x, y); }
-template <class F> ZK_HD Jac<F> acc_store(const JacR<F>& a) { return jacr_store(a); }
-template <class F> ZK_HD void acc_load(JacR<F>& a, const Jac<F>& j) { a = jacr_load(j); }
-template <class F> ZK_HD JacR<F> acc_add(const JacR<F>& a, const JacR<F>& b) { return add_lazy(a, b); }
-}  // namespace zk

@@ -323,9 +323,9 @@ __global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, int, int, co
 #endif  // ZK_MSM_COMMON
 
 // ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
-// waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 147 VGPRs) fits 3
-// waves; the G2 body (Jacobian accumulator + affine point over Fq2 = 80 live limbs before any
-// temporary) fits 2.
+// waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 145 VGPRs) fits 3
+// waves; the G2 body (XYZZ over Fq2: 72 accumulator limbs + the affine point before any temporary)
+// fits 2 with 16 dwords of scratch.
 template <class F> struct AccWaves { static constexpr int value = 3; };
 template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
@@ -423,12 +423,13 @@ __global__ __launch_bounds__(64) void k_msm_merge(const uint32_t* __restrict__ s
     bucket_sums[b] = acc_store(acc);
 }
 
+constexpr int MSM_HEAVY_THREADS = 128;
 // heavy buckets: one workgroup each, lanes stride over the images, tree over LDS
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
+__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
                                                          const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums,
                                                          const uint32_t* __restrict__ heavy) {
-    __shared__ AccSlot<F> sh[256];
+    __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
     const uint32_t count = heavy[0], total = start[buckets];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         const uint32_t b = heavy[1 + h];
@@ -436,10 +437,10 @@ __global__ __launch_bounds__(256) void k_msm_merge_heavy(const uint32_t* __restr
         const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
         typename AccOf<F>::type acc;
         if (threadIdx.x == 0) acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid); else acc_clear(acc);
-        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += 256) acc = acc_add(acc, first[t].a);
+        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += MSM_HEAVY_THREADS) acc = acc_add(acc, first[t].a);
         sh[threadIdx.x].a = acc;
         __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
+        for (int d = MSM_HEAVY_THREADS / 2; d >= 1; d >>= 1) {
             if ((int)threadIdx.x < d) sh[threadIdx.x].a = acc_add(sh[threadIdx.x].a, sh[threadIdx.x + d].a);
             __syncthreads();
         }
@@ -562,7 +563,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(8), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(16), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
         // one workgroup while each lane has at most ~16 additions, otherwise two levels
         const int groups = std::min(256, (segs + 4095) / 4096);
