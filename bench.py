@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, 1 GPU only: time rank 0's share of a W-way window-sharded proof (no collective) instead of whole proofs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo + several ranks on ONE GPU is a functional check of the N > 1 path only")
     ap.add_argument("--shard", choices=["windows", "points"], default="points",
                     help="what a rank owns of each inner product in --mode shard: Pippenger windows w = rank (mod N), or the "
                          "point range [count rank / N, count (rank+1) / N) with every window (5 %% faster at N = 8: 15 windows "
@@ -147,13 +149,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
-    ctx = zk.Context(local_rank)
+    ctx = zk.Context(device)
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
     if args.serialize:
@@ -224,7 +230,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ctx.profile()
@@ -241,7 +247,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         e2 = time.perf_counter() - t1
-        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        t = torch.tensor([e2], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2 = float(t.item())
         assert all(p == proofs_out[0] for p in rep_out), "replica proof differs from the sharded proof"
@@ -266,7 +272,9 @@ def main():
             bytes_per_launch = e["algo_bytes"] / e["launches"]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        # the committed PMC pass was taken on the default workload (2^20, one GPU): not applicable elsewhere
+                        "traffic": pmc_traffic(name) if (args.log_n == 20 and world == 1 and not args.window_bits) else None,
                         "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch,
                         "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
                         "note": "integer-ALU-bound kernel (254-bit modular multiply); HBM fraction is low by construction, see DESIGN.md"}

@@ -37,6 +37,18 @@ class GpuProver:
         return self.ctx.prove_combine(self.crs, gathered.data_ptr(), world, r, s)
 
 
+def all_gather_bytes(dist, gathered, part):
+    """all-gather of the per-rank byte blobs.  RCCL ("nccl") gathers device tensors directly; with the gloo
+    backend (CPU tests, and functional runs of several ranks on one GPU) device tensors are staged through
+    the host."""
+    if part.is_cuda and dist.get_backend() == "gloo":
+        host = gathered.cpu()
+        dist.all_gather_into_tensor(host, part.cpu())
+        gathered.copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered, part)
+
+
 def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     """One proof with the inner products sharded over `world` ranks.  Returns the 259 proof bytes
     (identical on every rank)."""
@@ -45,7 +57,7 @@ def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     part, gathered = buffers
     prover.partial(rank, world, r, s, part)
     if world > 1:
-        dist.all_gather_into_tensor(gathered, part)
+        all_gather_bytes(dist, gathered, part)
     else:
         gathered.copy_(part)
     return prover.combine(gathered, world, r, s)
@@ -62,7 +74,7 @@ def prove_sharded_stream(prover, dist, rank, world, jobs, depth=4):
         ticket, (part, gathered), r, s = item
         prover.partial_wait(ticket)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, part)
+            all_gather_bytes(dist, gathered, part)
         else:
             gathered.copy_(part)
         return prover.combine(gathered, world, r, s)
