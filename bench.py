@@ -194,7 +194,7 @@ def main():
             pass
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"diagnostic": "rank 0 of a %d-way window-sharded prover, partial sums only" % W, "ms_per_proof_per_rank": round(dt * 1e3, 3),
+        print(json.dumps({"diagnostic": "rank 0 of a %d-way %s-sharded prover, partial sums only" % (W, "point-range" if args.shard == "points" else "window"), "ms_per_proof_per_rank": round(dt * 1e3, 3),
                           "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
         return
 

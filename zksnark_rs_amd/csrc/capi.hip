@@ -46,6 +46,7 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         // dynamic-base multiplications s*A, r*B1 start early and hide behind the other inner products
         ZK_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_greatest));
         ZK_HIP(hipStreamCreateWithPriority(&ctx->finish, hipStreamNonBlocking, prio_greatest));
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->main_alt, hipStreamNonBlocking, prio_greatest));
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
         }
@@ -66,6 +67,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i)
         if (ctx->msm_stream[i]) (void)hipStreamDestroy(ctx->msm_stream[i]);
     if (ctx->finish) (void)hipStreamDestroy(ctx->finish);
+    if (ctx->main_alt) (void)hipStreamDestroy(ctx->main_alt);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

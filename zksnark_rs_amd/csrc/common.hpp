@@ -88,6 +88,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;    // side stream for the r/s-only fixed-base multiplications
     hipStream_t finish = nullptr;  // join + assembly + copy-out of a proof
+    hipStream_t main_alt = nullptr;  // second main stream: odd-numbered proof slots run their SpMV / NTT stage here
     std::shared_ptr<zk::ProveState> prove_state;
     int cur_slot = -1;
     std::string last_error;

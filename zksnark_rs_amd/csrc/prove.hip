@@ -235,6 +235,13 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
 
     const size_t n = q.n, m = q.m, l = q.input;
     const size_t a_len = std::min(m_in, m);   // zip(weights) truncates (mod.rs:233-253)
+    // consecutive proofs alternate between two main streams, so that the SpMV / NTT stage of proof k+1 does not
+    // queue behind the (contended, ~25 kernel) stage of proof k; every helper launches on ctx->stream
+    struct StreamSwap {
+        zk_ctx* c; hipStream_t saved;
+        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
+    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.partial = d_partial_out != nullptr;
@@ -380,6 +387,7 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_we
 void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
     DevBuf<Fr> dw(std::max<size_t>(m, 1));
     if (m) ZK_HIP(hipMemcpyAsync(dw.p, weights, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // the proof may run on the other main stream
     prove_dev(ctx, crs, qap, dw.p, m, r, s, proof_out, 0, 1, nullptr);
 }
 
