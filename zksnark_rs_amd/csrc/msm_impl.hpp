@@ -563,7 +563,10 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(16), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
+        // heavy buckets are outliers when the average bucket spans few lanes (a small grid that mostly finds nothing
+        // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
+        const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 16u;
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
         // one workgroup while each lane has at most ~16 additions, otherwise two levels
         const int groups = std::min(256, (segs + 4095) / 4096);
