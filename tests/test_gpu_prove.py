@@ -137,6 +137,27 @@ def test_prove_full_size_2_20(ctx, orc):
     assert got == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
 
 
+def test_prove_max_size_2_21_and_size_limit(ctx, orc):
+    """Largest supported sparse size (the coset transforms need the 2^(log_n+1)-th roots, and NTT_MAX_LOG = 22):
+    2^21 constraints, 4.2 M wires, proof == trapdoor closed form; 2^22 is refused with ZK_ERR_SIZE."""
+    log_n = 21
+    rng = SplitMix64(2121)
+    n = 1 << log_n
+    m, l, u, v, w = chain_rows(log_n)
+    weights = chain_weights(log_n, rng.fr(), [rng.next() for _ in range(n)])   # 64-bit inputs keep generation fast
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    desc = ctx.sparse_desc(log_n, m, l, u, v, w)
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    crs = ctx.setup(qap, td)
+    assert ctx.prove(crs, qap, weights, r, s) == orc.trapdoor_proof_sparse(desc, td, weights, r, s)
+    del crs, qap
+    m2, l2, u2, v2, w2 = chain_rows(4)
+    with pytest.raises(zk.ZkError) as e:
+        ctx.qap_sparse(22, m2, l2, u2, v2, w2)
+    assert e.value.status == -4
+
+
 def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     """zk_prove_partial for every rank + zk_prove_combine == zk_prove (the N>1 data path, run
     sequentially on one device; the RCCL all-gather is replaced by writing into one buffer)."""
