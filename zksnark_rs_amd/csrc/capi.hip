@@ -47,6 +47,7 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         ZK_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_greatest));
         ZK_HIP(hipStreamCreateWithPriority(&ctx->finish, hipStreamNonBlocking, prio_greatest));
         ZK_HIP(hipStreamCreateWithPriority(&ctx->main_alt, hipStreamNonBlocking, prio_greatest));
+        msm_init_attributes();
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
         }

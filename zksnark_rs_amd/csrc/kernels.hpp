@@ -61,6 +61,7 @@ struct MsmWorkspace {
     DevBuf<uint8_t> partial, bucket_sums, seg_sums;
 };
 int msm_auto_window(size_t n);
+void msm_init_attributes();
 template <class F>
 void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& out);
 // sum_{i < n_used} scalars[i] * P_i over the table's bases; scalars are CANONICAL Fr limbs.

@@ -145,6 +145,33 @@ __device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t idx) {
     return res;
 }
 
+// Block-wide exclusive scan: out[i] = sum_{j < i} in[j] for i < count (in and out may alias), using THREADS lanes
+// and a THREADS-entry scratch array; returns the total.  Every lane of the block must call it.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uint32_t* out, int count, uint32_t* scratch) {
+    const int per = (count + THREADS - 1) / THREADS;
+    const int lo = min((int)threadIdx.x * per, count), hi = min(lo + per, count);
+    uint32_t sum = 0;
+    for (int b = lo; b < hi; ++b) sum += in[b];
+    scratch[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < THREADS; d <<= 1) {
+        uint32_t v = (int)threadIdx.x >= d ? scratch[threadIdx.x - d] : 0;
+        __syncthreads();
+        scratch[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? scratch[threadIdx.x - 1] : 0;
+    const uint32_t total = scratch[THREADS - 1];
+    for (int b = lo; b < hi; ++b) {
+        uint32_t v = in[b];
+        out[b] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
 // hist[chunk][bin] = number of digits of the chunk whose bucket falls into the bin
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
                                                            int first, int step, int sub_bits, uint32_t* __restrict__ hist) {
@@ -208,10 +235,12 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
     if (threadIdx.x == 1023) start[count] = part[1023];
 }
 
-// level 1: records[pos] = (sub-bucket << 32) | ((w*n + i) << 1 | neg), grouped by bin
+// level 1: records[pos] = (sub-bucket << 32) | ((w*n + i) << 1 | neg), grouped by bin: one 8-byte store per digit at the
+// position taken from the bin's LDS counter.  (An LDS-staged form that writes the records in runs, like level 2 below,
+// was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                              int first, int step, int sub_bits, const uint32_t* __restrict__ prefix,
-                                                              uint64_t* __restrict__ records) {
+                                                                     int first, int step, int sub_bits, const uint32_t* __restrict__ prefix,
+                                                                     uint64_t* __restrict__ records) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins = 1 << (c - 1 - sub_bits);
     const uint32_t sub_mask = (1u << sub_bits) - 1;
@@ -292,22 +321,56 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
     if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = bin_start[bins];
 }
 
-__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
-                                                                   const uint32_t* __restrict__ pos, uint32_t* __restrict__ sorted) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+// level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
+// them by sub-bucket inside LDS and stores runs of consecutive 4-byte entries
+constexpr int BINS_THREADS = 512;
+constexpr int BIN_STAGE = 8192;
+constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
+                                                                  const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t scratch[BINS_THREADS];
     const int subs = 1 << sub_bits;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem);
+    uint16_t* ssub = reinterpret_cast<uint16_t*>(smem + (size_t)BIN_STAGE * 4);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)BIN_STAGE * 6);
+    uint32_t* lstart = cnt + subs;
+    uint32_t* pos = lstart + subs;     // running write position per sub-bucket for this (bin, part)
     uint32_t lo, hi;
     bin_slice(bin_start, parts, lo, hi);
-    const uint32_t* row = pos + (size_t)blockIdx.x * subs;
-    for (int b = threadIdx.x; b < subs; b += SORT2_THREADS) lds[b] = row[b];
-    __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * SORT2_THREADS) {
-        uint64_t r[4];
+    const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
+    for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] = row[b];
+    for (uint32_t base = lo; base < hi; base += BIN_STAGE) {
+        for (int b = threadIdx.x; b < subs; b += BINS_THREADS) cnt[b] = 0;
+        __syncthreads();
+        uint32_t ent[BIN_PER_LANE], sub[BIN_PER_LANE], rank[BIN_PER_LANE];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
+        for (int j = 0; j < BIN_PER_LANE; ++j) {
+            const uint32_t k = base + j * BINS_THREADS + threadIdx.x;
+            const uint64_t r = k < hi ? records[k] : 0;
+            ent[j] = (uint32_t)r;
+            sub[j] = (uint32_t)(r >> 32);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k + j * SORT2_THREADS < hi) sorted[lds_inc(lds, (uint32_t)(r[j] >> 32))] = (uint32_t)r[j];
+        for (int j = 0; j < BIN_PER_LANE; ++j)
+            if (base + j * BINS_THREADS + threadIdx.x < hi) rank[j] = lds_inc(cnt, sub[j]);
+        __syncthreads();
+        const uint32_t total = block_exclusive_scan<BINS_THREADS>(cnt, lstart, subs, scratch);
+#pragma unroll
+        for (int j = 0; j < BIN_PER_LANE; ++j)
+            if (base + j * BINS_THREADS + threadIdx.x < hi) {
+                const uint32_t p = lstart[sub[j]] + rank[j];
+                stage[p] = ent[j];
+                ssub[p] = (uint16_t)sub[j];
+            }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < total; p += BINS_THREADS) {
+            const uint32_t sb = ssub[p];
+            sorted[pos[sb] + (p - lstart[sb])] = stage[p];
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] += cnt[b];
+        __syncthreads();
     }
 }
 
@@ -317,6 +380,8 @@ __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, const uint32_t*, uint64_t*);
+constexpr int BINS_THREADS = 512;
+constexpr int BIN_STAGE = 8192;
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, int, int, int, uint32_t*);
 __global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
@@ -498,7 +563,8 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         return;
     }
     // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
-    const int sub_bits = std::max(0, c - 1 - 10), bins = 1 << (c - 1 - sub_bits);
+    // 2^8 bins (more only to keep the sub-bucket level at 2^11 counters at most)
+    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = 1 << (c - 1 - sub_bits);
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
@@ -538,8 +604,8 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     {
         ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world, sub_bits,
-                           ws.hist.p, ws.records.p);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+                           sub_bits, ws.hist.p, ws.records.p);
     }
     {
         ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
@@ -547,7 +613,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         ws.bin_cnt.ensure((size_t)bins * parts * subs);
         hipLaunchKernelGGL(k_msm_bin_hist, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits, ws.bin_cnt.p);
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, bins, parts, sub_bits, ws.start.p);
-        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits,
+        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(bins * parts), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, parts, sub_bits,
                            ws.bin_cnt.p, ws.sorted.p);
     }
     {
@@ -581,6 +647,16 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
 }
 template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t);
 
+
+#ifdef ZK_MSM_COMMON
+// the staged level-2 scatter uses more than the default 64 KiB of dynamic LDS
+void msm_init_attributes() {
+    static bool done = false;
+    if (done) return;
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE * 6 + 2048 * 12));
+    done = true;
+}
+#endif  // ZK_MSM_COMMON
 
 template <class F>
 __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) {
