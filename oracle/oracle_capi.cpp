@@ -320,6 +320,50 @@ double orc_time_prove_sparse(const zk_qap_sparse_desc* d, const zk_crs_desc* crs
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
+// unit costs of the reference's primitives on this host, one thread (seconds each): out[0] = Fr multiply-add
+// (the inner step of Mul<T>/Add, schoolbook Mul and long division), out[1] = Fr inversion (fr.rs:54,69),
+// out[2] = G1 scalar multiplication, out[3] = G2 scalar multiplication (exp_encrypted_g1/g2, fr.rs:114-119).
+// bench.py prices SURVEY 8d's operation count of the reference's prove() with them.
+void orc_unit_costs(double out[4]) {
+    SplitMix64 rng(0xC057);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    {
+        const int n = 4000000;
+        Fr a = rng.fr(), b = rng.fr(), acc = rng.fr();
+        auto t0 = now();
+        for (int i = 0; i < n; ++i) { acc = acc * a + b; }
+        out[0] = secs(t0, now()) / n;
+        if (acc.is_zero()) out[0] += 1e-30;   // keep the loop observable
+    }
+    {
+        const int n = 3000;
+        Fr a = rng.fr();
+        auto t0 = now();
+        for (int i = 0; i < n; ++i) a = a.inv() + Fr::one();
+        out[1] = secs(t0, now()) / n;
+        if (a.is_zero()) out[1] += 1e-30;
+    }
+    {
+        const int n = 300;
+        const G1 base = enc_base_g1();   // a CRS-like base; each term is base * scalar folded into a sum (fr.rs:191-198)
+        G1 p = G1::zero();
+        auto t0 = now();
+        for (int i = 0; i < n; ++i) p = p + base.mul(rng.fr());
+        out[2] = secs(t0, now()) / n;
+        if (p.is_zero()) out[2] += 1e-30;
+    }
+    {
+        const int n = 100;
+        const G2 base = enc_base_g2();
+        G2 p = G2::zero();
+        auto t0 = now();
+        for (int i = 0; i < n; ++i) p = p + base.mul(rng.fr());
+        out[3] = secs(t0, now()) / n;
+        if (p.is_zero()) out[3] += 1e-30;
+    }
+}
+
 // same, NTT + Pippenger path only, on `threads` host threads (five inner products x windows, NTT stages split)
 double orc_time_prove_sparse_mt(const zk_qap_sparse_desc* d, const zk_crs_desc* crs, const uint64_t* weights, size_t m_w,
                                 const uint64_t r[4], const uint64_t s[4], int threads, int reps, uint8_t proof[259]) {

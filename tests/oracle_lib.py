@@ -122,6 +122,12 @@ class Oracle:
                                              _p(fr_to_limbs(r)), _p(fr_to_limbs(s)), int(faithful), int(reps), out.ctypes.data_as(u8p))
         return sec, out.tobytes()
 
+    def unit_costs(self):
+        """(Fr multiply-add, Fr inversion, G1 scalar mul, G2 scalar mul) in seconds on one host thread."""
+        out = (C.c_double * 4)()
+        self.lib.orc_unit_costs(out)
+        return tuple(out)
+
     def time_prove_sparse_mt(self, desc, crs_desc, weights, r, s, threads, reps=1):
         """NTT + Pippenger path on `threads` host threads; returns (seconds per proof, proof bytes)."""
         w = np.ascontiguousarray(np.asarray(weights, dtype=np.uint64).reshape(-1, 4))
