@@ -1,40 +1,6 @@
-# INTEGRATION — binding `libzkgpu.so` from the reference crate
-
-The reference (`republicprotocol/zksnark-rs`, crate `zksnark` 0.0.2) is pure Rust with no FFI.
-`include/zkgpu.h` is the seam: a C ABI whose entry points are what a `src/groth16/gpu.rs` module
-inside the crate binds (the module must live inside the crate because `QAP`, `SigmaG1`, `SigmaG2`
-and `Proof` have private fields — `src/groth16/mod.rs:60-67,105-128`).  Rust is not installed in
-this image, so the shim below is the binding a maintainer adds; it is not compiled here.  The same
-ABI is exercised end to end by `tests/` through ctypes (`zksnark_rs_amd/_lib.py`).
-
-## 1. Build
-
-```
-# libzkgpu.so (HIP kernels + C ABI), needs ROCm >= 7.0 and targets gfx950 only
-make -C zksnark_rs_amd/csrc            # -> zksnark_rs_amd/libzkgpu.so
-```
-
-`build.rs` of the crate:
-
-```rust
-fn main() {
-    let dir = std::env::var("ZKGPU_LIB_DIR").expect("set ZKGPU_LIB_DIR to the directory holding libzkgpu.so");
-    println!("cargo:rustc-link-search=native={}", dir);
-    println!("cargo:rustc-link-lib=dylib=zkgpu");
-    println!("cargo:rustc-link-search=native=/opt/rocm/lib");
-    println!("cargo:rustc-link-lib=dylib=amdhip64");
-}
-```
-
-## 2. `src/groth16/gpu.rs` (reference-side binding; also kept as files under `bindings/rust/`)
-
-Element conventions (see the header): Fr/Fq = `[u64; 4]` little-endian canonical integers,
-G1 affine = `[u64; 8]` (`x‖y`), G2 affine = `[u64; 16]` (`x.c0‖x.c1‖y.c0‖y.c1`), infinity = all zero.
-`bn` exposes coordinates through its `rustc-serialize` `Encodable` impl (32-byte big-endian field
-elements; verify against the crate on a machine that has it — SURVEY §8b), which is what the two
-`*_to_words` helpers use.
-
-```rust
+// src/groth16/gpu.rs -- binding of libzkgpu.so inside the reference crate.  Not compiled in this
+// repository: the image has no Rust toolchain; the same C ABI is exercised by tests/ through ctypes and through the
+// C++ mirror include/zksnark.hpp (tests/cpp/reference_tests.cpp).
 //! GPU prover behind the reference API: same argument order, borrow pattern and by-value
 //! return as groth16::prove (mod.rs:213-217).
 use super::{CoefficientPoly, Proof, QAP, SigmaG1, SigmaG2};
@@ -131,63 +97,3 @@ pub fn prove(qap: &QAP<CoefficientPoly<FrLocal>>, sigma: (&SigmaG1<G1Local>, &Si
     let (r, s) = (FrLocal::random_elem(), FrLocal::random_elem());
     GpuProver::new(qap, sigma).prove_with_rs(weights, r, s)
 }
-```
-
-`fr_to_words`, `g1_to_words`, `g2_to_words`, `g1_from_bytes`, `g2_from_bytes` are ~10-line helpers
-over bn's `rustc-serialize` encoding (tag byte + 32-byte big-endian coordinates): split each
-coordinate into four little-endian `u64` words, and parse the 65/129-byte proof blocks back
-(`0x04‖x‖y`, G2 coordinates as `c1‖c0`; `0x00` = identity).
-
-For a stream of proofs keep two in flight: `zk_prove_submit(ctx, crs, qap, d_weights, m, r, s, &ticket)`
-returns as soon as the proof is enqueued and `zk_prove_wait(ctx, ticket, bytes)` blocks for its 259
-bytes; the second proof's witness products and NTT stage then run under the first one's reduction
-tail (+17 % throughput at 2^20).  The witness must already be in HBM for these two
-(`hipMemcpyAsync` on any stream, synchronised before the submit).
-
-Large circuits should not go through the dense `QAP<CoefficientPoly<FrLocal>>` (3·m·n field
-elements): build the sparse form from the `RootRepresentation` (`circuit/mod.rs:201-214`) with roots
-`w^j` and call `zk_qap_upload_sparse` + `zk_setup` instead; `zksnark_rs_amd/circuits.py` shows the
-row layout for the chain circuit.
-
-## 3. C++ host API — `include/zksnark.hpp`
-
-Header-only mirror of the reference API over the same C ABI, for callers in compiled code and as the
-template for the Rust module above (same names, argument order, by-value results; the reference's panics
-become `zksnark::Error`):
-
-```cpp
-#include "zksnark.hpp"
-using namespace zksnark;
-Context ctx(0);
-std::string code = read_to_string("test_programs/simple.zk");
-QAP qap = QAP::from(ctx, ASTParser::try_parse(code));           // ASTParser + QAP::from (fr.rs:140-173)
-auto weights = groth16::weights(code, {3, 2, 4});                // a, b, c
-auto sigma = groth16::setup(ctx, qap);                            // (SigmaG1, SigmaG2)
-auto proof = groth16::prove(ctx, qap, sigma, weights);
-assert(groth16::verify(ctx, sigma, {FrLocal(2), FrLocal(34)}, proof));
-```
-
-`tests/cpp/reference_tests.cpp` is the reference's own test list (`simple_circuit_test`,
-`single_mult_honest_bn`, `bn_encrypt_{quad,cubic,deg_15}_test`) written against this header; build line in
-`tests/test_cpp_api.py`.
-
-## 4. Python (ctypes) — what the parity tests and bench use
-
-```python
-import zksnark_rs_amd as zk
-ctx  = zk.Context(0)                                   # zk_ctx_create
-qap  = ctx.qap_sparse(log_n, m, l, u_rows, v_rows, w_rows)   # zk_qap_upload_sparse
-crs  = ctx.setup(qap, trapdoor)                        # zk_setup          (groth16::setup)
-pf   = ctx.prove(crs, qap, weights, r, s)              # zk_prove          (groth16::prove) -> 259 bytes
-ok   = ctx.verify(crs, inputs, pf)                     # zk_verify         (groth16::verify)
-ctx.crs_save(crs, "circuit.zkcrs"); crs = ctx.crs_load("circuit.zkcrs")   # zk_crs_save / zk_crs_load
-t    = ctx.prove_submit(crs, qap, d_w.data_ptr(), m, r, s); pf = ctx.prove_wait(t)   # pipelined form
-```
-
-`zksnark_rs_amd/groth16.py` wraps the same calls under the reference's names
-(`setup(qap)`, `prove(qap, (sigma_g1, sigma_g2), weights)`, `verify(...)`, `QAP.from_zk(code)`), and
-`zksnark_rs_amd/circuit.py` is the `.zk` front end (`zk_circuit_parse`, `zk_circuit_weights`,
-`zk_circuit_qap`).
-
-Multi-GPU (one process per GPU, RCCL): `zksnark_rs_amd/distributed.py::prove_sharded` (one proof) and
-`prove_sharded_stream` (two proofs in flight per rank, `zk_prove_partial_submit` + `zk_prove_wait`).

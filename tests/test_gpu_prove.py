@@ -93,6 +93,21 @@ def test_prove_sparse_matches_trapdoor_proof(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], bad, inst["r"], inst["s"]) == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], bad, inst["r"], inst["s"])
 
 
+@pytest.mark.parametrize("log_n", [3, 10])
+def test_prove_empty_short_and_zero_witness(ctx, orc, log_n):
+    """zip truncation at its extremes (mod.rs:233-253): an empty witness, 1..4 elements, and an all-zero witness
+    (every scalar digit is zero: the sorted lists are empty) still give the reference's bytes."""
+    inst = chain_instance(ctx, log_n, 5000 + log_n)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(crs))
+    faithful = log_n <= 6
+    for count in (0, 1, 2, 3, 4):
+        wts = inst["weights"][:count].copy() if count else np.zeros((0, 4), np.uint64)
+        assert ctx.prove(crs, inst["qap"], wts, inst["r"], inst["s"]) == orc.prove_sparse(inst["desc"], cdesc, wts, inst["r"], inst["s"], faithful), count
+    zero = np.zeros_like(inst["weights"])
+    assert ctx.prove(crs, inst["qap"], zero, inst["r"], inst["s"]) == orc.prove_sparse(inst["desc"], cdesc, zero, inst["r"], inst["s"], faithful)
+
+
 def random_sparse_rows(rng, n, m, density):
     """(ptr, gate, val) by wire with random non-zero entries (distinct gates per wire), some wires empty."""
     ptr, gates, vals = [0], [], []
