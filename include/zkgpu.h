@@ -63,7 +63,9 @@ const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last fai
 /* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (additions per lane of the
  * bucket accumulation, a multiple of 4; default 32), "profile" (0/1: per-kernel
  * event timing, read back with zk_profile_*), "msm_shard_points" (zk_prove_partial: 0 = a rank owns
- * Pippenger windows, 1 = a rank owns a range of the points), "serialize" (0/1: measurement mode, all kernels of a proof on
+ * Pippenger windows, 1 = a rank owns a range of the points), "dense_long_division" (1: the dense form always divides
+ * by t with the reference's long division; default 0 = power-series inverse above 512 quotient coefficients),
+ * "serialize" (0/1: measurement mode, all kernels of a proof on
  * one stream so that event timings are stand-alone durations).  Unknown keys return ZK_ERR_UNSUPPORTED. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);

@@ -316,6 +316,43 @@ def test_prove_zk_program_matches_faithful_oracle(ctx, orc, prog):
     assert ctx.prove(crs, qap, short, r, s) == orc.prove_dense(q["u"], q["v"], q["w"], q["t"], q["input"], cdesc, short, r, s)
 
 
+def chain_program(n):
+    """deg_15.zk generalised to n gates: t1 = x*a1, tk = x*(t(k-1) + ak), y = 1*(t(n-1) + an)."""
+    ins = " ".join("a%d" % k for k in range(1, n + 1))
+    body = ["    (= t1 (* x a1))"]
+    body += ["    (= t%d (* x (+ t%d a%d)))" % (k, k - 1, k) for k in range(2, n)]
+    body.append("    (= y (* 1 (+ t%d a%d))))" % (n - 1, n))
+    return "(in x %s)\n(out y)\n(verify x y)\n\n(program\n%s\n" % (ins, "\n".join(body))
+
+
+@pytest.mark.parametrize("n", [600, 1024, 16384])
+def test_dense_arbitrary_roots_at_larger_n(ctx, n):
+    """ASTParser circuits (roots 1..n) beyond toy sizes, up to the 16384-gate limit of the dense form (3 m n field
+    elements = 52 GB there): the quotient by t comes from the power-series inverse of
+    rev(t) above 512 coefficients.  Same bytes as the reference's long division (forced through an option), valid
+    and invalid witnesses, and the proof verifies (the pairing check needs no trapdoor)."""
+    from zksnark_rs_amd.circuit import Circuit
+    code = chain_program(n)
+    circ = Circuit(code)
+    assert (circ.n, circ.m, circ.input) == (n, 2 * n + 2, 2)
+    rng = SplitMix64(8800 + n)
+    weights = circ.weights([rng.fr() for _ in range(n + 1)])
+    qap = circ.qap(ctx)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    r, s = rng.fr(), rng.fr()
+    bad = weights.copy(); bad[5, 0] ^= np.uint64(1)
+    got, got_bad = ctx.prove(crs, qap, weights, r, s), ctx.prove(crs, qap, bad, r, s)
+    ctx.set_option("dense_long_division", 1)
+    try:
+        assert ctx.prove(crs, qap, weights, r, s) == got
+        assert ctx.prove(crs, qap, bad, r, s) == got_bad
+    finally:
+        ctx.set_option("dense_long_division", 0)
+    pub = [zk.limbs_to_int(weights[1]), zk.limbs_to_int(weights[2])]
+    assert ctx.verify(crs, pub, got)
+    assert not ctx.verify(crs, pub, got_bad)
+
+
 def test_single_mult_honest_bn(ctx, orc):
     """fr.rs:248-271: the hand-written 1-gate QAP with t = x + 250."""
     f = lambda rows: ints_to_limbs(rows).reshape(len(rows), 1, 4)

@@ -83,6 +83,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "profile")) return &ctx->opt_profile;
     if (!std::strcmp(key, "msm_lane_entries")) return &ctx->opt_lane_entries;
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;
+    if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
     return nullptr;
 }

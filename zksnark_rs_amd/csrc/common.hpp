@@ -95,6 +95,7 @@ struct zk_ctx {
     long opt_window_bits = 0;
     long opt_profile = 0;
     long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges
+    long opt_long_division = 0;   // dense form: always use the reference's long division (A/B check of the Newton form)
     long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
     long opt_lane_entries = 32;   // additions per lane of the bucket accumulation (multiple of 4)
     std::map<std::string, zk::ProfEntry> prof;

@@ -368,7 +368,7 @@ __global__ void k_rows_to_dense(const uint32_t* __restrict__ ptr, const uint32_t
 static zk_qap* circuit_to_qap(zk_ctx* ctx, const zk_circuit& c) {
     const size_t n = c.n_gates, m = c.u.size();
     ZK_REQUIRE(n >= 1, ZK_ERR_ARG, "circuit has no gates");
-    ZK_REQUIRE(n <= 4096, ZK_ERR_SIZE, "dense QAP construction supports at most 4096 gates; use the sparse roots-of-unity form");
+    ZK_REQUIRE(n <= 16384, ZK_ERR_SIZE, "dense QAP construction supports at most 16384 gates (3 m n field elements); use the sparse roots-of-unity form");
     hipStream_t st = ctx->stream;
     std::unique_ptr<zk_qap> q(new zk_qap());
     q->ctx = ctx; q->dense = true; q->n = n; q->m = m; q->input = c.input;

@@ -27,6 +27,10 @@ struct zk_qap {
     size_t t_degree = 0;      // actual degree of t (dense)
     zk::DevBuf<zk::Fr> t_cinv; // 1 / leading coefficient of t (dense)
     bool t_is_zero = false;
+    // dense form, large n: NTT image (size 2^tinv_log) of the power-series inverse of rev(t) mod x^K,
+    // K = 2n-1-deg t quotient coefficients; built on first use (qap_ensure_tinv)
+    zk::DevBuf<zk::Fr> t_rinv_ntt;
+    unsigned tinv_log = 0;
 };
 
 struct zk_crs {

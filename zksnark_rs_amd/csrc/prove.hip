@@ -153,7 +153,7 @@ struct AssembleScratch {
 // Several slots let zk_prove_submit enqueue proof k+1 (its sorting / NTT stage / first accumulation)
 // while the latency-bound tail of proof k (reductions, assembly, copy-out) is still running.
 struct ProveSlot {
-    DevBuf<Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b;
+    DevBuf<Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b, div_work;
     MsmWorkspace ws[zk_ctx::MSM_STREAMS];
     DevBuf<MsmResults> ms;
     DevBuf<AssembleScratch> as;
@@ -231,6 +231,11 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
     if (!q.dense) crs_ensure_tables(ctx, crs, true, q.log_n); else crs_ensure_tables(ctx, crs, false, 0);
+    if (q.dense && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
+        unsigned lc0 = 1;
+        while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
+        qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
+    }
     if (!d_partial_out) crs_ensure_fixed_tables(ctx, crs);
 
     const size_t n = q.n, m = q.m, l = q.input;
@@ -335,7 +340,15 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         // quotient by t (degree d); remainder dropped (coefficient_poly.rs:148-157)
         ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
-        if (len_r > d) poly_divide(ctx, S.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, S.prod_b.p);
+        if (len_r > d) {
+            // long division below 512 quotient coefficients (as the reference); above, the O(n log n) form
+            if (len_r - d >= 512 && !ctx->opt_long_division) {
+                S.div_work.ensure(nc);
+                poly_divide_newton(ctx, q, S.prod_a.p, len_r, lc, S.div_work.p, S.prod_b.p);
+            } else {
+                poly_divide(ctx, S.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, S.prod_b.p);
+            }
+        }
         fr_from_mont(ctx, S.prod_b.p, S.hb_can.p, n - 1);
         launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }

@@ -245,4 +245,79 @@ void poly_divide(zk_ctx* ctx, Fr* r, size_t len_r, const Fr* t, size_t d, const 
     ZK_HIP(hipGetLastError());
 }
 
+
+// ---- quotient by t through the power-series inverse of rev(t) (dense form at large n) -----------
+// polynomial_division (field/mod.rs:428-469) is O(n^2) and strictly sequential: n dependent steps, one workgroup.
+// The quotient of P (len_r coefficients) by t (degree d) is also
+//     rev_K(q) = rev_K(P) * rev(t)^-1  mod x^K,   K = len_r - d,
+// the same unique polynomial, so the same field elements.  rev(t)^-1 mod x^K comes from Newton's iteration
+// g <- 2g - rev(t) g^2 (doubling precision, three NTTs per step) once per QAP; a proof then costs two NTTs.
+__global__ void k_reverse_prefix(const Fr* __restrict__ src, size_t src_len, size_t count, Fr* __restrict__ dst, size_t dst_len) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dst_len) return;
+    dst[i] = i < count ? src[src_len - 1 - i] : Fr::zero();   // dst[i] = coefficient src_len-1-i, zero padded
+}
+__global__ void k_newton_combine(const Fr* __restrict__ g, size_t have, const Fr* __restrict__ e, size_t want, Fr* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= want) return;
+    Fr gi = i < have ? g[i] : Fr::zero();
+    out[i] = gi + gi - e[i];
+}
+static void reverse_prefix(zk_ctx* ctx, const Fr* src, size_t src_len, size_t count, Fr* dst, size_t dst_len) {
+    hipLaunchKernelGGL(k_reverse_prefix, dim3(ceil_div(dst_len, 256)), dim3(256), 0, ctx->stream, src, src_len, count, dst, dst_len);
+    ZK_HIP(hipGetLastError());
+}
+
+void qap_ensure_tinv(zk_ctx* ctx, zk_qap& q, size_t K, unsigned log_size) {
+    if (q.t_rinv_ntt.p && q.tinv_log == log_size) return;
+    const size_t d = q.t_degree, size = (size_t)1 << log_size;
+    hipStream_t st = ctx->stream;
+    // rt = rev(t): rt[i] = t[d - i], i <= d
+    size_t bufsz = size;
+    while (bufsz < 2 * K) bufsz <<= 1;
+    DevBuf<Fr> rt(d + 1), g(bufsz), f(bufsz), e(bufsz), g2(bufsz);
+    reverse_prefix(ctx, q.dt.p, d + 1, d + 1, rt.p, d + 1);
+    // g0 = 1 / rt[0] = 1 / leading coefficient of t
+    ZK_HIP(hipMemsetAsync(g.p, 0, bufsz * sizeof(Fr), st));
+    ZK_HIP(hipMemcpyAsync(g.p, q.t_cinv.p, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    for (size_t have = 1; have < K;) {
+        const size_t want = std::min(2 * have, K);
+        unsigned lg = 1;
+        while (((size_t)1 << lg) < 2 * want) ++lg;   // rt_trunc g^2 has want + 2 have - 2 <= 2 want coefficients: no wrap-around
+        const size_t sz = (size_t)1 << lg;
+        // f = rt mod x^want, g2 = g mod x^have, both zero padded to sz
+        ZK_HIP(hipMemsetAsync(f.p, 0, sz * sizeof(Fr), st));
+        ZK_HIP(hipMemcpyAsync(f.p, rt.p, std::min(want, d + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ZK_HIP(hipMemsetAsync(g2.p, 0, sz * sizeof(Fr), st));
+        ZK_HIP(hipMemcpyAsync(g2.p, g.p, have * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ntt_dif(ctx, f.p, lg, false, false);
+        ntt_dif(ctx, g2.p, lg, false, false);
+        fr_pointwise_mul(ctx, f.p, g2.p, e.p, sz);
+        fr_pointwise_mul(ctx, e.p, g2.p, e.p, sz);
+        ntt_dit(ctx, e.p, lg, true, true, nullptr);                 // e = rt_trunc * g^2 (natural order)
+        hipLaunchKernelGGL(k_newton_combine, dim3(ceil_div(want, 256)), dim3(256), 0, st, g.p, have, e.p, want, f.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipMemcpyAsync(g.p, f.p, want * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        have = want;
+    }
+    // NTT image of g mod x^K at the size the per-proof product uses
+    q.t_rinv_ntt.alloc(size);
+    ZK_HIP(hipMemsetAsync(q.t_rinv_ntt.p, 0, size * sizeof(Fr), st));
+    ZK_HIP(hipMemcpyAsync(q.t_rinv_ntt.p, g.p, K * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dif(ctx, q.t_rinv_ntt.p, log_size, false, false);
+    ZK_HIP(hipStreamSynchronize(st));
+    q.tinv_log = log_size;
+}
+
+// quotient (K = len_r - d coefficients, natural order) of P = r[0 .. len_r) by t into out[0 .. K); `work` has 2^log_size elements
+void poly_divide_newton(zk_ctx* ctx, const zk_qap& q, const Fr* r, size_t len_r, unsigned log_size, Fr* work, Fr* out) {
+    const size_t K = len_r - q.t_degree, size = (size_t)1 << log_size;
+    ProfScope ps(ctx, "qap_poly_divide", 32.0 * (len_r + 3 * size));
+    reverse_prefix(ctx, r, len_r, K, work, size);                    // rev_K(P), zero padded
+    ntt_dif(ctx, work, log_size, false, false);
+    fr_pointwise_mul(ctx, work, q.t_rinv_ntt.p, work, size);
+    ntt_dit(ctx, work, log_size, true, true, nullptr);               // (rev_K(P) * rev(t)^-1), first K coefficients are rev_K(q)
+    reverse_prefix(ctx, work, K, K, out, K);
+}
+
 }  // namespace zk

@@ -10,4 +10,6 @@ void fr_scale_to_canonical(zk_ctx*, const Fr* in, Fr k, Fr* out, size_t n);
 void fr_lincomb_to_canonical(zk_ctx*, const Fr* a, Fr ka, const Fr* b, Fr kb, Fr* out, size_t n);
 void fr_sub_inplace(zk_ctx*, Fr* a, const Fr* b, size_t n);
 void poly_divide(zk_ctx*, Fr* r, size_t len_r, const Fr* t, size_t d, const Fr* cinv, Fr* q);
+void qap_ensure_tinv(zk_ctx*, zk_qap& q, size_t K, unsigned log_size);
+void poly_divide_newton(zk_ctx*, const zk_qap& q, const Fr* r, size_t len_r, unsigned log_size, Fr* work, Fr* out);
 }  // namespace zk
