@@ -259,19 +259,37 @@ __global__ void k_lagrange_at(const SetupConsts* __restrict__ cs, Fr w, Fr* __re
 }
 
 // comb[i] = (beta*u_i(x) + alpha*v_i(x) + w_i(x)) / (i <= l ? gamma : delta)   (mod.rs:147-164)
-__global__ void k_setup_comb_sparse(const SetupConsts* __restrict__ cs, const Fr* __restrict__ L,
+// One workgroup per COMB_ROWS wires; a wire's entries are walked by the whole wave it belongs to when it has
+// many of them (a wire that feeds every gate, like x in the chain circuit, has n entries: one lane took a second
+// for it at 2^20), so rows are processed wave-cooperatively: 64 lanes stride over the entries, then a shuffle tree.
+__device__ __forceinline__ Fr wave_sum(Fr v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Fr o;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) o.l[l] = __shfl_down(v.l[l], off);
+        v = v + o;
+    }
+    return v;   // valid in lane 0
+}
+__global__ __launch_bounds__(256) void k_setup_comb_sparse(const SetupConsts* __restrict__ cs, const Fr* __restrict__ L,
                                     const uint32_t* up, const uint32_t* ug, const Fr* uv,
                                     const uint32_t* vp, const uint32_t* vg, const Fr* vv,
                                     const uint32_t* wp, const uint32_t* wg, const Fr* wv,
                                     size_t m, size_t input, Fr* __restrict__ comb) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per wire
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= m) return;
     Fr ux = Fr::zero(), vx = Fr::zero(), wx = Fr::zero();
-    for (uint32_t k = up[i]; k < up[i + 1]; ++k) ux = ux + uv[k] * L[ug[k]];
-    for (uint32_t k = vp[i]; k < vp[i + 1]; ++k) vx = vx + vv[k] * L[vg[k]];
-    for (uint32_t k = wp[i]; k < wp[i + 1]; ++k) wx = wx + wv[k] * L[wg[k]];
-    Fr c = cs->beta * ux + cs->alpha * vx + wx;
-    comb[i] = c * (i <= input ? cs->gamma_inv : cs->delta_inv);
+    for (uint32_t k = up[i] + lane; k < up[i + 1]; k += 64) ux = ux + uv[k] * L[ug[k]];
+    for (uint32_t k = vp[i] + lane; k < vp[i + 1]; k += 64) vx = vx + vv[k] * L[vg[k]];
+    for (uint32_t k = wp[i] + lane; k < wp[i + 1]; k += 64) wx = wx + wv[k] * L[wg[k]];
+    ux = wave_sum(ux); vx = wave_sum(vx); wx = wave_sum(wx);
+    if (lane == 0) {
+        Fr c = cs->beta * ux + cs->alpha * vx + wx;
+        comb[i] = c * (i <= input ? cs->gamma_inv : cs->delta_inv);
+    }
 }
 __global__ void k_setup_comb_dense(const SetupConsts* __restrict__ cs, const Fr* __restrict__ U, const Fr* __restrict__ V,
                                    const Fr* __restrict__ W, size_t m, size_t n, size_t input, Fr* __restrict__ comb) {
@@ -349,7 +367,7 @@ zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
     } else {
         DevBuf<Fr> L(n);
         hipLaunchKernelGGL(k_lagrange_at, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, host_root_of_unity(q.log_n), L.p, n);
-        hipLaunchKernelGGL(k_setup_comb_sparse, dim3(ceil_div(m, 256)), dim3(256), 0, st, cs.p, L.p,
+        hipLaunchKernelGGL(k_setup_comb_sparse, dim3(ceil_div(m * 64, 256)), dim3(256), 0, st, cs.p, L.p,
                            q.u_wire.ptr.p, q.u_wire.idx.p, q.u_wire.val.p, q.v_wire.ptr.p, q.v_wire.idx.p, q.v_wire.val.p,
                            q.w_wire.ptr.p, q.w_wire.idx.p, q.w_wire.val.p, m, l, comb.p);
         ZK_HIP(hipGetLastError());
