@@ -200,6 +200,37 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     assert got[1] == ctx.prove(crs, inst["qap"], inst["weights"], inst["s"], inst["r"])
 
 
+def test_two_contexts_interleaved(orc):
+    """Two contexts on one device (separate streams, slots and tables) proving in an interleaved, pipelined way,
+    then destroyed and re-created: same bytes as a lone context."""
+    torch = pytest.importorskip("torch")
+    want = {}
+    for round_ in range(2):
+        ctxs = [zk.Context(0), zk.Context(0)]
+        jobs = []
+        for k, c in enumerate(ctxs):
+            inst = chain_instance(c, 9 + k, 640 + k)
+            crs = c.setup(inst["qap"], inst["td"])
+            dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
+            jobs.append((c, crs, inst, dw))
+        tickets = []
+        for rep in range(3):
+            for c, crs, inst, dw in jobs:
+                tickets.append((c, c.prove_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]), inst["log_n"]))
+            if rep:   # keep two in flight per context
+                for _ in range(len(jobs)):
+                    c, t, key = tickets.pop(0)
+                    got = c.prove_wait(t)
+                    assert want.setdefault(key, got) == got
+        for c, t, key in tickets:
+            got = c.prove_wait(t)
+            assert want.setdefault(key, got) == got
+        for c, crs, inst, dw in jobs:
+            assert c.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"]) == want[inst["log_n"]]
+            assert want[inst["log_n"]] == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
+        del jobs, ctxs
+
+
 def test_crs_file_round_trip(ctx, orc, tmp_path):
     """zk_crs_save / zk_crs_load: same arrays, same proof bytes; altered, truncated and
     missing files are refused with ZK_ERR_IO, out-of-range coordinates with ZK_ERR_RANGE."""
