@@ -15,6 +15,7 @@
 // pipeline never runs a separate bit-reversal pass (the CRS is stored in matching order).
 // The inter-pass twiddles, the coset factors and 1/n are fused into the tile load/store.
 #include "kernels.hpp"
+#include "lazy29.cuh"
 
 namespace zk {
 
@@ -123,8 +124,37 @@ void ntt_ensure_coset_tables(zk_ctx* ctx, NttTables& t) {
 }
 
 // ---- the tile kernel ---------------------------------------------------------------------
+// Inside a tile the elements live in the multiplier's own radix (lazy29.cuh: 9 signed 29-bit limbs,
+// not reduced): a butterfly's add / sub are 9 independent 32-bit operations instead of two carry
+// chains with a conditional correction, and its multiply needs no 8x32 <-> 9x29 conversion.  Each
+// lane holds 2^K elements and runs K butterfly stages on them in registers between two visits to
+// LDS.  Shipped: K = 2 with 512-lane workgroups (4 elements per lane, 92 VGPRs, 4 waves/SIMD; 11 stages
+// = 2+2+2+2+2+1 rounds); K = 3 with 256 lanes (8 elements per lane, 245 VGPRs in the DIT kernel, 2
+// waves/SIMD because a 75 KB tile allows two workgroups per CU either way) measured 7 % slower
+// stand-alone.  Elements are converted on the tile load and brought back to the canonical 8 x 32 form
+// on the tile store, so HBM never sees the lazy form.
+//
+// Bounds (p = r, "fresh" = a Montgomery output, value in (-0.3p, 1.3p), limbs in normal form):
+//  * DIF (x, y) -> (x + y, (x - y) w): the sum path doubles per stage.  Sums are re-normalised
+//    (carry propagation) where two un-normalised sums would meet, element 0 of every round -- the only
+//    one that is a sum of sums over the whole round -- is reduced modulo p (fr_reduce), so that a
+//    round's inputs are below 5.6p, its values below 45p (top limb < 2^28) and every multiplicand
+//    x - y has |limb| < 2^30, which is what FpR::mont needs for its 64-bit columns.
+//  * DIT (x, y) -> (x + w y, x - w y): values grow by at most 1.3p per stage (< 16p over the 11
+//    stages of a tile); limbs are re-normalised before the third multiplication of a round and at
+//    its end.
 constexpr int TILE = 1 << NTT_MAX_LOCAL_LOG;  // elements per LDS tile
-constexpr int NTT_THREADS = 256;
+#ifndef ZK_NTT_THREADS
+#define ZK_NTT_THREADS 512
+#endif
+#ifndef ZK_NTT_KMAX
+#define ZK_NTT_KMAX 2
+#endif
+constexpr int NTT_THREADS = ZK_NTT_THREADS;
+constexpr int LDS_PLANE = TILE + (TILE >> 6);  // limb-planar, one pad word per 64 elements (stride-8 rounds stay conflict free)
+constexpr size_t NTT_LDS_BYTES = (size_t)LDS_PLANE * 9 * sizeof(int32_t);
+
+typedef FpR<FrParams> FrL;
 
 struct NttPass {
     unsigned log_rows, log_cols;
@@ -136,23 +166,115 @@ struct NttPass {
     int has_post;
 };
 
-__device__ __forceinline__ Fr lds_get(const uint32_t* lds, int e) {
-    Fr r;
+__device__ __forceinline__ FrL lds_get(const int32_t* lds, int e) {
+    const int a = e + (e >> 6);
+    FrL r;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) r.l[l] = lds[l * TILE + e];
+    for (int l = 0; l < 9; ++l) r.v[l] = lds[l * LDS_PLANE + a];
     return r;
 }
-__device__ __forceinline__ void lds_put(uint32_t* lds, int e, const Fr& v) {
+__device__ __forceinline__ void lds_put(int32_t* lds, int e, const FrL& v) {
+    const int a = e + (e >> 6);
 #pragma unroll
-    for (int l = 0; l < 8; ++l) lds[l * TILE + e] = v.l[l];
+    for (int l = 0; l < 9; ++l) lds[l * LDS_PLANE + a] = v.v[l];
+}
+
+// value - q p with q ~ floor(value / p) estimated from the top limb: any limbs within int32 and
+// |value| < 2^9 p in, normal form with value in (-p - eps, 2p) out (eps = 2^-12 p: the low limbs of q p).
+__device__ __forceinline__ FrL fr_reduce(const FrL& a) {
+    const int32_t q = (int32_t)floorf((float)a.v[8] * (1.0f / (float)FrParams::P29[8]));
+    FrL r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t t = (int64_t)a.v[i] - (int64_t)q * (int32_t)FrParams::P29[i] + c;
+        r.v[i] = (int32_t)((uint32_t)t & (uint32_t)FrL::M29);
+        c = t >> 29;
+    }
+    r.v[8] = a.v[8] - q * (int32_t)FrParams::P29[8] + (int32_t)c;
+    return r;
+}
+// canonical 8 x 32 form of any tile value
+__device__ __forceinline__ Fr fr_store_exact(const FrL& a) {
+    const FrL t = fr_reduce(a);   // (-p - eps, 2p): one of t + p, t, t - p is the residue
+    FrL d, s;
+    int32_t bd = 0, cs = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int32_t x = t.v[i] - (int32_t)FrParams::P29[i] + bd;
+        d.v[i] = x & FrL::M29;
+        bd = x >> 29;
+        int32_t y = t.v[i] + (int32_t)FrParams::P29[i] + cs;
+        s.v[i] = y & FrL::M29;
+        cs = y >> 29;
+    }
+    d.v[8] = t.v[8] - (int32_t)FrParams::P29[8] + bd;
+    s.v[8] = t.v[8] + (int32_t)FrParams::P29[8] + cs;
+    const bool neg = t.v[8] < 0, ge = d.v[8] >= 0;   // normal form: the sign of the value is the sign of the top limb
+    uint32_t u[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u[i] = (uint32_t)(neg ? s.v[i] : (ge ? d.v[i] : t.v[i]));
+    Fr o;
+    Fr::from29(u, o.l);
+    return o;
+}
+
+// K butterfly stages (stage numbers s .. s+K-1 of a 2^L-point transform) on the 2^K elements of one unit
+template <bool DIT, int K>
+__device__ __forceinline__ void ntt_round(int32_t* lds, const Fr* __restrict__ tw, int col_base, unsigned L, unsigned s, int u, unsigned tw_shift) {
+    constexpr int Q = 1 << K;
+    FrL x[Q];
+    int row0, qshift, j;
+    if (!DIT) {
+        qshift = (int)(L - s) - K;                 // element q sits at row0 + (q << qshift)
+        j = u & ((1 << qshift) - 1);
+        row0 = ((u >> qshift) << (L - s)) | j;
+    } else {
+        qshift = (int)s;
+        j = u & ((1 << s) - 1);
+        row0 = ((u >> s) << (s + K)) | j;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[q] = lds_get(lds, col_base + row0 + (q << qshift));
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const int half = DIT ? (1 << t) : (1 << (K - 1 - t));
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (q & half) continue;
+            if (!DIT) {
+                // decimation in frequency: (x, y) -> (x + y, (x - y) w),  w = w_{2^(L-s-t)}^pos
+                const int pos = ((q & (half - 1)) << qshift) | j;
+                const FrL w = FrL::load(tw[((size_t)pos << (s + t)) << tw_shift]);
+                FrL sum = x[q] + x[q + half];
+                if (t == 1) sum = sum.norm();
+                x[q + half] = (x[q] - x[q + half]) * w;
+                x[q] = sum;
+            } else {
+                // decimation in time: (x, y) -> (x + w y, x - w y),  w = w_{2^(s+t+1)}^pos
+                const int pos = ((q & (half - 1)) << qshift) | j;
+                const FrL w = FrL::load(tw[((size_t)pos << (L - 1 - s - t)) << tw_shift]);
+                const FrL y = (t == 2 ? x[q + half].norm() : x[q + half]) * w;
+                x[q + half] = x[q] - y;
+                x[q] = x[q] + y;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (DIT) x[q] = x[q].norm();
+        else if (q == 0) x[q] = fr_reduce(x[q]);
+        else if (K == 3 && !(q & 1)) x[q] = x[q].norm();
+        lds_put(lds, col_base + row0 + (q << qshift), x[q]);
+    }
 }
 
 template <bool DIT>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data, NttPass p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const unsigned log_rows = p.log_rows, log_cols = p.log_cols;
-    const int rows = 1 << log_rows, cols = 1 << log_cols;
-    const int elems = rows << log_cols;
+    const int cols = 1 << log_cols;
+    const int elems = 1 << (log_rows + log_cols);
     Fr* base = data + (size_t)blockIdx.x * p.tile_stride;
     const Fr* pre = p.pre ? p.pre + (size_t)blockIdx.x * p.tile_stride : nullptr;
     const Fr* mid = p.mid ? p.mid + (size_t)blockIdx.x * p.tile_stride : nullptr;
@@ -161,52 +283,42 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
         int row = idx >> log_cols, col = idx & (cols - 1);
         size_t g = (size_t)row * p.row_stride + col;
-        Fr v = base[g];
-        if (pre) v = v * pre[g];
+        FrL v = FrL::load(base[g]);
+        if (pre) v = v * FrL::load(pre[g]);
         lds_put(lds, (col << log_rows) + row, v);
     }
     __syncthreads();
 
-    const int half_rows = rows >> 1;
     const unsigned tw_shift = NTT_MAX_LOCAL_LOG - log_rows;
-    for (unsigned s = 0; s < log_rows; ++s) {
-        for (int b = threadIdx.x; b < (elems >> 1); b += NTT_THREADS) {
-            int col = b >> (log_rows - 1), t = b & (half_rows - 1);
-            if (!DIT) {
-                // decimation in frequency: (x, y) -> (x + y, (x - y) * w)
-                unsigned lh = log_rows - 1 - s;  // log2(half)
-                int k = t & ((1 << lh) - 1), grp = t >> lh;
-                int i = (col << log_rows) + (grp << (lh + 1)) + k, j = i + (1 << lh);
-                Fr w = p.tw[((size_t)k << s) << tw_shift];
-                Fr x = lds_get(lds, i), y = lds_get(lds, j);
-                lds_put(lds, i, x + y);
-                lds_put(lds, j, (x - y) * w);
-            } else {
-                // decimation in time: (x, y) -> (x + w y, x - w y)
-                int k = t & ((1 << s) - 1), grp = t >> s;
-                int i = (col << log_rows) + (grp << (s + 1)) + k, j = i + (1 << s);
-                Fr w = p.tw[((size_t)k << (log_rows - 1 - s)) << tw_shift];
-                Fr x = lds_get(lds, i), y = lds_get(lds, j) * w;
-                lds_put(lds, i, x + y);
-                lds_put(lds, j, x - y);
-            }
+    for (unsigned s = 0; s < log_rows;) {
+        const unsigned left = log_rows - s;
+        const unsigned k = ZK_NTT_KMAX >= 3 && left >= 3 && left != 4 ? 3 : (left >= 2 ? 2 : 1);   // 4 = 2 + 2
+        const int units = elems >> k;
+        const unsigned log_upc = log_rows - k;   // units per column
+        for (int u = threadIdx.x; u < units; u += NTT_THREADS) {
+            const int col_base = (u >> log_upc) << log_rows, uu = u & ((1 << log_upc) - 1);
+            if (k == 3) ntt_round<DIT, 3>(lds, p.tw, col_base, log_rows, s, uu, tw_shift);
+            else if (k == 2) ntt_round<DIT, 2>(lds, p.tw, col_base, log_rows, s, uu, tw_shift);
+            else ntt_round<DIT, 1>(lds, p.tw, col_base, log_rows, s, uu, tw_shift);
         }
+        s += k;
         __syncthreads();
     }
 
+    const FrL post = FrL::load(p.post);
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
         int row = idx >> log_cols, col = idx & (cols - 1);
         size_t g = (size_t)row * p.row_stride + col;
-        Fr v = lds_get(lds, (col << log_rows) + row);
-        if (mid) v = v * mid[g];
-        if (p.has_post) v = v * p.post;
-        base[g] = v;
+        FrL v = lds_get(lds, (col << log_rows) + row);
+        if (mid) v = v * FrL::load(mid[g]);
+        if (p.has_post) v = v * post;
+        base[g] = fr_store_exact(v);
     }
 }
 
 static void launch_pass(zk_ctx* ctx, bool dit, Fr* d, const NttPass& p, size_t tiles, const char* name, double bytes) {
     ProfScope ps(ctx, name, bytes);
-    size_t lds_bytes = (size_t)TILE * 32;
+    size_t lds_bytes = NTT_LDS_BYTES;
     if (dit) hipLaunchKernelGGL(k_ntt_tile<true>, dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, p);
     else hipLaunchKernelGGL(k_ntt_tile<false>, dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, p);
     ZK_HIP(hipGetLastError());
@@ -215,8 +327,8 @@ static void launch_pass(zk_ctx* ctx, bool dit, Fr* d, const NttPass& p, size_t t
 static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre) {
     static bool attr_set = false;
     if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE * 32));
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE * 32));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
         attr_set = true;
     }
     auto tabs = ntt_get_tables(ctx, log_n);
