@@ -129,7 +129,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
+    ap.add_argument("--mode", choices=["exchange", "shard", "replicas"], default="exchange",
+                    help="N > 1: exchange = every proof's inner products sharded over the ranks by point ranges, the SpMV/NTT stage done "
+                         "once per proof by its owner rank, scalars and partial sums moved by all-to-all (a step is one round of N "
+                         "proofs); shard = the latency form (one proof at a time, every rank repeats the NTT stage, one all-gather); "
+                         "replicas = independent provers")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -180,13 +184,34 @@ def main():
     inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness)
     d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
     m = inst["m"]
-    shard = world > 1 and args.mode == "shard"
+    exchange = world > 1 and args.mode == "exchange"
+    if exchange:
+        from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
+        xprover = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
+    shard = shard_mode = world > 1 and args.mode == "shard"
     if shard:
         from zksnark_rs_amd.distributed import GpuProver, prove_sharded, prove_sharded_stream
         prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
         bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
 
     depth = args.depth or (4 if (shard or args.emulate_world > 1) else 2)
+    if args.emulate_world and world == 1 and args.mode == "exchange":
+        # rank 0's work in rounds of W proofs: one SpMV/NTT stage + W sets of inner products over 1/W of the points;
+        # the all-to-alls are local copies of the same size, so the proofs are NOT valid -- timing only
+        from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
+        W = args.emulate_world
+        xp = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
+        for _ in prove_exchange_stream(xp, None, 0, W, [(inst["r"], inst["s"])] * args.warmup):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in prove_exchange_stream(xp, None, 0, W, [(inst["r"], inst["s"])] * args.steps):
+            pass
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"diagnostic": "rank 0 of a %d-way scalar-exchange prover (local copies instead of the all-to-alls)" % W,
+                          "ms_per_round_per_rank": round(dt * 1e3, 3), "implied_proofs_per_s_at_%d_gpus" % W: round(W / dt, 2)}))
+        return
     if args.emulate_world and world == 1:
         from zksnark_rs_amd.distributed import GpuProver, prove_sharded_stream
         prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
@@ -208,8 +233,11 @@ def main():
                           "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
         return
 
-    def run(k, shard=shard):
-        """k proofs, all submitted and completed inside this call; returns their bytes."""
+    def run(k, local=False):
+        """k steps, all submitted and completed inside this call; returns the proof bytes (local: independent provers)."""
+        shard = shard_mode and not local
+        if exchange and not local:
+            return list(prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k))   # k rounds = k * world proofs
         if shard and depth == 1:
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
         if shard:
@@ -248,12 +276,12 @@ def main():
     # beside the window-sharded line (north_star, configs[4]): the same K steps as independent provers, one
     # per GPU, no collective -- the throughput mode.  Reported as a secondary object, never as `value`.
     replicas = None
-    if shard:
-        run(args.warmup, shard=False)
+    if shard or exchange:
+        run(args.warmup, local=True)
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
-        rep_out = run(args.steps, shard=False)
+        rep_out = run(args.steps, local=True)
         torch.cuda.synchronize()
         dist.barrier()
         e2 = time.perf_counter() - t1
@@ -267,7 +295,7 @@ def main():
         assert proof is None or p == proof, "non-deterministic proof bytes"
         proof = p
 
-    proofs = args.steps * (world if (world > 1 and not shard) else 1)
+    proofs = args.steps * (world if (world > 1 and not shard) else 1)   # exchange / replicas: a step is `world` proofs
     value = proofs / elapsed
     if rank == 0:
         total_kernel_ms = sum(e["total_ms"] for e in prof.values()) or 1.0
@@ -304,11 +332,13 @@ def main():
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if shard or world == 1 else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
+            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
             "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d)" % (args.witness, args.seed),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM"
                                    % (args.log_n, m),
                        "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("point-range" if args.shard == "points" else "window", world)) if shard
+                                      else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums; "
+                                            "a step = one round of %d proofs" % (world, world)) if exchange
                                       else ("replicas x%d" % world),
                        "proofs_in_flight": depth, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,

@@ -226,6 +226,24 @@ int zk_prove_combine(zk_ctx* ctx, const zk_crs* crs, const void* d_partials, int
 int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                             const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out, int* ticket);
 
+/* Multi-GPU, scalar exchange (roots-of-unity QAP form only).  Instead of repeating the SpMV / NTT
+ * stage on every rank, the ranks take turns: in a round of `world` proofs rank j runs that stage for proof j
+ * (zk_prove_scalars_submit) and writes the scalars of the four inner products (groth16/mod.rs:255-290: L over
+ * sum_delta, V over [x^i]_2, U over [x^i]_1, h | r v + s u over [x^i t/delta]_1 | [x^i]_1) as `world` equal
+ * chunks each -- chunk g multiplies the points rank g owns, [g c, (g+1) c) with c = ceil(count / world), zero
+ * scalars behind the last point.  One all-to-all per array (RCCL, equal splits) hands every rank its chunk of
+ * every proof of the round; zk_prove_msm_submit accumulates them over the rank's points (partial sums of proof j
+ * at d_partials_out + j * ZK_PARTIAL_BYTES), a second all-to-all returns the blobs to the proofs' owners, and
+ * zk_prove_combine finishes.  Each array has elems_out[k] elements of 32 bytes (k = L, V, U, H). */
+int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]);
+int zk_prove_scalars_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                            const uint64_t r[4], const uint64_t s[4], int world,
+                            void* d_l, void* d_v, void* d_u, void* d_h, int* ticket);
+/* d_l .. d_h: `sets` chunks each, as delivered by the all-to-all (chunk j = proof j's scalars for this rank's points).
+ * One ticket for the batch; finish with zk_prove_wait(ctx, ticket, NULL). */
+int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int sets, int rank, int world,
+                        const void* d_l, const void* d_v, const void* d_u, const void* d_h, void* d_partials_out, int* ticket);
+
 /* ------------------------------------------------------------------------------------------
  * verify  (groth16::verify, groth16/mod.rs:299-320) -- host code, as in the reference
  * ---------------------------------------------------------------------------------------- */

@@ -1,6 +1,6 @@
 """-m gpu: bench.py's contract line at a small size, for N = 1 and for the N = 2 code path (two ranks on ONE
-GPU over gloo: a functional check of the window/point-sharded prover, its pipelined driver and the replicas
-leg; RCCL itself needs one GPU per rank and is exercised by the driver's multi-GPU runs)."""
+GPU over gloo: a functional check of the scalar-exchange and the window/point-sharded provers, their pipelined drivers
+and the replicas leg -- bench.py asserts that all of them give the same proof bytes; RCCL itself needs one GPU per rank and is exercised by the driver's multi-GPU runs)."""
 import json
 import os
 import subprocess
@@ -31,15 +31,15 @@ def test_bench_line_single_gpu():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
 
 
-@pytest.mark.parametrize("shard", ["points", "windows"])
-def test_bench_line_two_ranks_on_one_gpu(shard):
+@pytest.mark.parametrize("mode,shard", [("exchange", "points"), ("shard", "points"), ("shard", "windows")])
+def test_bench_line_two_ranks_on_one_gpu(mode, shard):
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--log-n", "12", "--backend", "gloo", "--shard", shard]
+           "--log-n", "12", "--backend", "gloo", "--mode", mode, "--shard", shard]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     d = last_json_line(res.stdout)
     assert KEYS <= set(d)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if mode == "shard" else "weak") and d["value"] > 0
     assert d["replicas"]["value"] > 0 and d["replicas"]["scaling"] == "weak"

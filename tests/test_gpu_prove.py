@@ -200,6 +200,53 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     assert got[1] == ctx.prove(crs, inst["qap"], inst["weights"], inst["s"], inst["r"])
 
 
+@pytest.mark.parametrize("log_n", [1, 3, 10, 13])
+def test_scalar_exchange_on_one_gpu(ctx, orc, log_n):
+    """zk_prove_scalars_submit -> (all-to-all) -> zk_prove_msm_submit on every rank -> (all-to-all) -> zk_prove_combine
+    == zk_prove, with all ranks of worlds 1..8 played by one device and the two all-to-alls done by slicing.  Two
+    proofs with different witnesses and (r, s) per round check the routing of the chunks."""
+    torch = pytest.importorskip("torch")
+    inst = chain_instance(ctx, log_n, 77 + log_n)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    rng = SplitMix64(5 + log_n)
+    w2 = chain_weights(log_n, rng.fr(), [rng.fr() for _ in range(inst["n"])])
+    # the second proof's witness is truncated (zip semantics, mod.rs:233-253) when the circuit is large enough
+    w2 = w2[:inst["m"] - 3] if log_n >= 3 else w2
+    proofs = [(inst["weights"], inst["r"], inst["s"]), (w2, inst["s"], inst["r"])]
+    want = [ctx.prove(crs, inst["qap"], w, r, s) for w, r, s in proofs]
+    dws = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w, _, _ in proofs]
+    for world in (1, 2, 3, 8):
+        elems = ctx.prove_exchange_elems(inst["qap"], world)
+        assert all(e % world == 0 for e in elems) and elems[1] >= inst["n"] and elems[3] >= 2 * inst["n"]
+        # send[j][k]: array k of the proof owned by "rank" j (only ranks 0 and 1 own a proof here)
+        send = [[torch.zeros(32 * e, dtype=torch.uint8, device="cuda") for e in elems] for _ in proofs]
+        for j, (w, r, s) in enumerate(proofs):
+            t = ctx.prove_scalars_submit(crs, inst["qap"], dws[j].data_ptr(), w.shape[0], r, s, world, [x.data_ptr() for x in send[j]])
+            ctx.prove_wait(t, partial=True)
+        # rank g receives chunk g of every array of every proof and returns one blob per proof
+        blobs = [[None] * world for _ in proofs]
+        for g in range(world):
+            recv = []
+            for k, e in enumerate(elems):
+                c = 32 * e // world
+                recv.append(torch.cat([send[j][k][g * c:(g + 1) * c] for j in range(len(proofs))]))
+            part = torch.zeros(len(proofs) * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            t = ctx.prove_msm_submit(crs, inst["qap"], len(proofs), g, world, [x.data_ptr() for x in recv], part.data_ptr())
+            ctx.prove_wait(t, partial=True)
+            for j in range(len(proofs)):
+                blobs[j][g] = part[j * zk.PARTIAL_BYTES:(j + 1) * zk.PARTIAL_BYTES].clone()
+        for j, (w, r, s) in enumerate(proofs):
+            gathered = torch.cat(blobs[j])
+            assert ctx.prove_combine(crs, gathered.data_ptr(), world, r, s) == want[j], (world, j)
+    # the pipelined driver with local exchanges (world 1): five rounds through the two-deep software pipeline
+    from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
+    prover = GpuExchangeProver(ctx, crs, inst["qap"], dws[0], inst["m"])
+    jobs = [(inst["r"], inst["s"]), (inst["s"], inst["r"])] * 2 + [(inst["r"], inst["s"])]
+    got = list(prove_exchange_stream(prover, None, 0, 1, jobs))
+    alt = ctx.prove(crs, inst["qap"], inst["weights"], inst["s"], inst["r"])
+    assert got == [want[0], alt, want[0], alt, want[0]]
+
+
 def test_two_contexts_interleaved(orc):
     """Two contexts on one device (separate streams, slots and tables) proving in an interleaved, pipelined way,
     then destroyed and re-created: same bytes as a lone context."""

@@ -353,6 +353,29 @@ class Context:
         s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
         self._check(self.lib.zk_prove_partial(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, rank, world, C.c_void_p(d_partial_ptr)))
 
+    # ---- multi-GPU scalar exchange (zkgpu.h: zk_prove_scalars_submit / zk_prove_msm_submit) ----
+    def prove_exchange_elems(self, qap, world):
+        """Element counts (32-byte Fr) of the four exchange arrays L, V, U, H for `world` ranks."""
+        out = (C.c_size_t * 4)()
+        self._check(self.lib.zk_prove_exchange_elems(qap.ptr, world, out))
+        return [int(x) for x in out]
+
+    def prove_scalars_submit(self, crs, qap, d_weights_ptr, m, r, s, world, d_ptrs):
+        """SpMV / NTT stage of one proof; the scalars of the four inner products go to d_ptrs = (L, V, U, H)."""
+        r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)
+        s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
+        t = C.c_int(-1)
+        self._check(self.lib.zk_prove_scalars_submit(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, world,
+                                                     *[C.c_void_p(p) for p in d_ptrs], C.byref(t)))
+        return t.value
+
+    def prove_msm_submit(self, crs, qap, sets, rank, world, d_ptrs, d_partials_ptr):
+        """Inner products of `sets` proofs over this rank's points from the exchanged chunks d_ptrs = (L, V, U, H)."""
+        t = C.c_int(-1)
+        self._check(self.lib.zk_prove_msm_submit(self.ptr, crs.ptr, qap.ptr, sets, rank, world, *[C.c_void_p(p) for p in d_ptrs],
+                                                 C.c_void_p(d_partials_ptr), C.byref(t)))
+        return t.value
+
     def prove_combine(self, crs, d_partials_ptr, world, r, s):
         r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)
         s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)

@@ -85,6 +85,11 @@ SIGNATURES = {
     "zk_prove_partial_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(C.c_int)]),
     "zk_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p]),
+    "zk_prove_exchange_elems": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    "zk_prove_scalars_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "zk_prove_msm_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
     "zk_verify": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u8p, C.POINTER(C.c_int)]),
     "zk_pairing": (C.c_int, [u64p, u64p, u64p]),

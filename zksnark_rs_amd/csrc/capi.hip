@@ -201,6 +201,29 @@ int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, c
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || !ticket || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
     return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, rank, world, d_partial_out); });
 }
+int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]) {
+    if (!qap || world < 1 || !elems_out) return ZK_ERR_ARG;
+    if (qap->dense) return ZK_ERR_UNSUPPORTED;
+    prove_exchange_elems(*qap, world, elems_out);
+    return ZK_OK;
+}
+int zk_prove_scalars_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                            const uint64_t r[4], const uint64_t s[4], int world,
+                            void* d_l, void* d_v, void* d_u, void* d_h, int* ticket) {
+    if (!ctx || !crs || !qap || !d_weights || !r || !s || world < 1 || !d_l || !d_v || !d_u || !d_h || !ticket) return ZK_ERR_ARG;
+    return guarded(ctx, [&] {
+        Fr* xout[4] = {(Fr*)d_l, (Fr*)d_v, (Fr*)d_u, (Fr*)d_h};
+        *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, 0, world, nullptr, xout);
+    });
+}
+int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int sets, int rank, int world,
+                        const void* d_l, const void* d_v, const void* d_u, const void* d_h, void* d_partials_out, int* ticket) {
+    if (!ctx || !crs || !qap || sets < 0 || world < 1 || rank < 0 || rank >= world || !d_l || !d_v || !d_u || !d_h || !d_partials_out || !ticket)
+        return ZK_ERR_ARG;
+    return guarded(ctx, [&] {
+        *ticket = prove_msm_submit(ctx, *crs, *qap, sets, rank, world, (const Fr*)d_l, (const Fr*)d_v, (const Fr*)d_u, (const Fr*)d_h, d_partials_out);
+    });
+}
 int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
     if (!ctx) return ZK_ERR_ARG;
     return guarded(ctx, [&] { prove_wait(ctx, ticket, proof_out); });

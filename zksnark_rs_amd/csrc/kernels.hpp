@@ -71,9 +71,18 @@ void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<
 // `acc_wait` (may be null): event the bucket accumulation waits for; `acc_done` (may be null): event
 // recorded right after it.  The accumulation kernels each fill every SIMD, so the pipeline chains
 // them in a chosen order instead of letting them thrash each other's caches.
+// Grouped form: `groups` independent products over the SAME bases in one pass (the proofs of one scalar-exchange
+// round): the scalars of group j are d_scalars[j glen .. j glen + valid), its result goes to (bytes) d_out + j out_stride;
+// n_used is ignored.  Each group has its own 2^(c-1) buckets in one sorted list, so the sort, the accumulation and the
+// reduction tails run once per round instead of once per proof.
+struct MsmGroups {
+    int groups = 1;
+    size_t glen = 0, valid = 0, out_stride = 0;
+};
 template <class F>
 void msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0);
+             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0,
+             const MsmGroups& grp = MsmGroups());
 template <class F>
 void msm_host(zk_ctx*, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine);
 

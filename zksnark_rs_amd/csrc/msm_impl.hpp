@@ -173,16 +173,21 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uin
 }
 
 // hist[chunk][bin] = number of digits of the chunk whose bucket falls into the bin
+// Grouped form (several independent products over the same bases in one pass): scalar i belongs to group i / glen and
+// multiplies point i % glen (scalars at or behind gvalid are ignored); group g owns the bins [g bins_pg, (g+1) bins_pg).
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
-                                                           int first, int step, int sub_bits, uint32_t* __restrict__ hist) {
+                                                           int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int bins = 1 << (c - 1 - sub_bits);
+    const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
+        if (il >= gvalid) continue;
         Fr k = scalars[i];
-        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, (mag - 1) >> sub_bits); });
+        const uint32_t bin0 = grp * (uint32_t)bins_pg;
+        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
     }
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * bins;
@@ -239,21 +244,24 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 // position taken from the bin's LDS counter.  (An LDS-staged form that writes the records in runs, like level 2 below,
 // was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                                     int first, int step, int sub_bits, const uint32_t* __restrict__ prefix,
-                                                                     uint64_t* __restrict__ records) {
+                                                                     int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups,
+                                                                     const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int bins = 1 << (c - 1 - sub_bits);
+    const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
     const uint32_t sub_mask = (1u << sub_bits) - 1;
     const uint32_t* row = prefix + (size_t)blockIdx.x * bins;
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = row[b];
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+        const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
+        if (il >= gvalid) continue;
         Fr k = scalars[i];
+        const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
-            uint32_t pos = lds_inc(lds, b >> sub_bits);
-            records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + i) << 1) | neg);
+            uint32_t pos = lds_inc(lds, bin0 + (b >> sub_bits));
+            records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + il) << 1) | neg);
         });
     }
 }
@@ -375,11 +383,11 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
 }
 
 #else
-__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, int, uint32_t*);
+__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, uint32_t*);
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, const uint32_t*, uint64_t*);
+__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
 constexpr int BINS_THREADS = 512;
 constexpr int BIN_STAGE = 8192;
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, int, int, uint32_t*);
@@ -514,9 +522,10 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uin
     }
 }
 
-// segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} b * S_b
+// segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} weight(b) * S_b, weight = the bucket's number within
+// its group of bpg buckets (1-based; bpg = buckets for a single product; segments never straddle groups)
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restrict__ bkt, int buckets, int segs, Jac<F>* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restrict__ bkt, int buckets, int segs, int bpg, Jac<F>* __restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= segs) return;
     int lo = t * MSM_SEG + 1, hi = min(buckets, lo + MSM_SEG - 1);
@@ -526,15 +535,19 @@ __global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restri
         running = add_lazy(running, jacr_load(wb[b]));
         acc = add_lazy(acc, running);
     }
-    if (lo > 1) acc = add_lazy(acc, mul_small_lazy(running, (uint32_t)(lo - 1)));
+    const int lo_local = (lo - 1) % bpg + 1;
+    if (lo_local > 1) acc = add_lazy(acc, mul_small_lazy(running, (uint32_t)(lo_local - 1)));
     out[t] = jacr_store(acc);
 }
 
 // sums points: workgroup g of G adds in[g], in[g + G], ... (256 lanes, tree over LDS in the 8 x 32 form) -> out[g]
+// blockIdx.y = group: its `count` inputs start at in + y count, its gridDim.x outputs at (bytes) out + y out_stride
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
+    in += (size_t)blockIdx.y * count;
+    out = reinterpret_cast<Jac<F>*>(reinterpret_cast<uint8_t*>(out) + (size_t)blockIdx.y * out_stride);
     JacR<F> acc = jacr_load(Jac<F>::infinity());
     for (int k = blockIdx.x * 256 + threadIdx.x; k < count; k += 256 * gridDim.x) acc = add_lazy(acc, jacr_load(in[k]));
     sh[threadIdx.x] = jacr_store(acc);
@@ -548,23 +561,32 @@ __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict
 
 template <class F>
 void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset) {
+             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp) {
     const bool g2 = sizeof(F) > sizeof(Fq);
-    const int c = tab.c, windows = tab.windows, buckets = 1 << (c - 1);
+    const int c = tab.c, windows = tab.windows, bpg = 1 << (c - 1);
     const size_t n = tab.n;
-    ZK_REQUIRE(point_offset <= n && n_used <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
+    // grouped: `groups` products over the same bases [point_offset, point_offset + valid), scalars of group j at
+    // d_scalars + j glen, result j at (bytes) d_out + j out_stride; bucket (group, |digit|) = group * 2^(c-1) + |digit| - 1
+    const int groups = grp.groups;
+    const size_t glen = groups > 1 ? grp.glen : std::max<size_t>(n_used, 1), gvalid = groups > 1 ? grp.valid : n_used;
+    if (groups > 1) n_used = (size_t)groups * glen;
+    ZK_REQUIRE(groups >= 1 && (groups == 1 || (bpg % MSM_SEG == 0 && gvalid <= glen)), ZK_ERR_ARG, "msm: bad grouping");
+    ZK_REQUIRE(point_offset <= n && gvalid <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
+    ZK_REQUIRE(n_used < ((size_t)1 << 32) && (size_t)groups * bpg <= ((size_t)1 << 24), ZK_ERR_SIZE, "msm: too many scalars or buckets");
+    const int buckets = bpg * groups;
     int owned = 0;
     for (int w = rank; w < windows; w += world) ++owned;
-    if (n_used == 0 || owned == 0) {
+    if (gvalid == 0 || owned == 0) {
         static const Jac<F> inf = Jac<F>::infinity();
-        ZK_HIP(hipMemcpyAsync(d_out, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
+        for (int j = 0; j < groups; ++j)
+            ZK_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_out) + (size_t)j * grp.out_stride, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
         return;
     }
     // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
     // 2^8 bins (more only to keep the sub-bucket level at 2^11 counters at most)
-    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = 1 << (c - 1 - sub_bits);
+    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = (1 << (c - 1 - sub_bits)) * groups;
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
@@ -594,7 +616,8 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
 
     {
         ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
-        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits, ws.hist.p);
+        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
+                           (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p);
     }
     {
         ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
@@ -605,7 +628,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     {
         ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
         hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
-                           sub_bits, ws.hist.p, ws.records.p);
+                           sub_bits, (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p, ws.records.p);
     }
     {
         ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
@@ -633,19 +656,20 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
         const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 16u;
         hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
-        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, d_seg);
-        // one workgroup while each lane has at most ~16 additions, otherwise two levels
-        const int groups = std::min(256, (segs + 4095) / 4096);
-        if (groups > 1) {
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_bsum);   // bucket sums are dead by now
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_bsum, groups, d_out);
+        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, bpg, d_seg);
+        // per group: one workgroup while each lane has at most ~16 additions, otherwise two levels
+        const int segs_pg = segs / groups;
+        const int wgs = std::min(256, (segs_pg + 4095) / 4096);
+        if (wgs > 1) {
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(wgs, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs_pg, d_bsum, (size_t)wgs * sizeof(Jac<F>));   // bucket sums are dead by now
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_bsum, wgs, d_out, grp.out_stride);
         } else {
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs, d_out);
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs_pg, d_out, grp.out_stride);
         }
     }
     ZK_HIP(hipGetLastError());
 }
-template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t);
+template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&);
 
 
 #ifdef ZK_MSM_COMMON

@@ -81,7 +81,12 @@ void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, 
 void prove_dev(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
                uint8_t* proof_out, int rank, int world, void* d_partial_out);
 int prove_submit(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
-                 int rank, int world, void* d_partial_out);
+                 int rank, int world, void* d_partial_out, Fr* const* xout = nullptr);
+// scalar exchange: element counts of the four exchange arrays (L | V | U | H,k), and the inner products of `sets`
+// proofs over this rank's points from the chunks an all-to-all delivered
+void prove_exchange_elems(const zk_qap&, int world, size_t out[4]);
+int prove_msm_submit(zk_ctx*, const zk_crs&, const zk_qap&, int sets, int rank, int world,
+                     const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out);
 void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
 void prove_combine(zk_ctx*, const zk_crs&, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
 

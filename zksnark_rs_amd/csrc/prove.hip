@@ -209,18 +209,35 @@ static ProveState& prove_state(zk_ctx* ctx) {
     return *ctx->prove_state;
 }
 
+// ---- scalar exchange (multi-GPU) ---------------------------------------------------
+// Rank g owns the points [g c, (g+1) c) of every inner product, c = ceil(count / world).  The owner of a proof
+// computes its scalars once (prove_submit with xout) into `world` chunks of c scalars per product; after an
+// all-to-all every rank holds, for each proof of the round, the chunk that multiplies its own points.
+struct ExchangeDims { size_t cl, cn, ch; };
+static ExchangeDims exchange_dims(const zk_qap& q, int world) {
+    const size_t w = (size_t)world, nl = q.m > q.input + 1 ? q.m - q.input - 1 : 0;
+    return ExchangeDims{(nl + w - 1) / w, (q.n + w - 1) / w, (2 * q.n + w - 1) / w};
+}
+void prove_exchange_elems(const zk_qap& q, int world, size_t out[4]) {
+    const ExchangeDims xd = exchange_dims(q, world);
+    out[0] = xd.cl * world; out[1] = out[2] = xd.cn * world; out[3] = xd.ch * world;
+}
+
 static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
     hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
     ZK_HIP(hipGetLastError());
 }
 
 // Enqueues one proof (or one rank's partial sums) and returns without waiting.  ticket = slot index.
+// xout != nullptr: "scalars only" -- the SpMV / NTT stage of one proof, no inner products; the scalars of the four
+// products are written to xout[0..3] = L | V | U | H,k in the exchange layout of prove_exchange_elems(world).
 int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr* d_weights, size_t m_in, const uint64_t* r, const uint64_t* s,
-                 int rank, int world, void* d_partial_out) {
+                 int rank, int world, void* d_partial_out, Fr* const* xout) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);   // lazily built tables only
     const zk_qap& q = qap_c;
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(d_partial_out || world == 1, ZK_ERR_ARG, "prove: world > 1 needs a partial output buffer");
+    ZK_REQUIRE(d_partial_out || world == 1 || xout, ZK_ERR_ARG, "prove: world > 1 needs a partial output buffer");
+    ZK_REQUIRE(!xout || !qap_c.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     ZK_REQUIRE(!q.dense || !q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
@@ -236,7 +253,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
         qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
     }
-    if (!d_partial_out) crs_ensure_fixed_tables(ctx, crs);
+    if (!d_partial_out && !xout) crs_ensure_fixed_tables(ctx, crs);
 
     const size_t n = q.n, m = q.m, l = q.input;
     const size_t a_len = std::min(m_in, m);   // zip(weights) truncates (mod.rs:233-253)
@@ -249,14 +266,14 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
-    S.partial = d_partial_out != nullptr;
+    S.partial = d_partial_out != nullptr || xout != nullptr;
 
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
     S.a_mont.ensure(std::max<size_t>(a_len, 1));
     fr_to_mont(ctx, d_weights, S.a_mont.p, a_len, S.flag.p);
 
     // the r/s-only fixed-base multiplications run on the side stream beside everything below
-    if (!d_partial_out) {
+    if (!d_partial_out && !xout) {
         hipStream_t pre_st = ctx->opt_serialize ? st : ctx->side;
         launch_pre(ctx, crs, pre_st, rc, sc, S.as.p);
         ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
@@ -269,6 +286,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
+        if (xout) return;
         hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
@@ -287,7 +305,22 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         S.ue.ensure(n); S.ve.ensure(n); S.x0.ensure(n); S.y0.ensure(n); S.ug.ensure(n); S.vg.ensure(n);
-        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+        Fr *vc_can, *uc_can, *hb_can;
+        if (xout) {
+            // exchange layout: `world` equal chunks per product, zero scalars behind the last point
+            const ExchangeDims xd = exchange_dims(q, world);
+            vc_can = xout[1]; uc_can = xout[2]; hb_can = xout[3];
+            ZK_HIP(hipMemsetAsync(xout[0], 0, xd.cl * world * sizeof(Fr), st));
+            if (n_l) ZK_HIP(hipMemcpyAsync(xout[0], d_weights + l + 1, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            if (xd.cn * world > n) {
+                ZK_HIP(hipMemsetAsync(vc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+                ZK_HIP(hipMemsetAsync(uc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+            }
+            if (xd.ch * world > 2 * n) ZK_HIP(hipMemsetAsync(hb_can + 2 * n, 0, (xd.ch * world - 2 * n) * sizeof(Fr), st));
+        } else {
+            S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+            vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
+        }
         // accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
         // ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);  // L: sum a_i * sum_delta_i
@@ -295,13 +328,13 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.ve.p);
         fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n);                 // U.V on <w>
         ntt_dif(ctx, S.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
-        fr_from_mont(ctx, S.ve.p, S.vc_can.p, n);
-        launch(0, 1, crs.t_xi2, S.vc_can.p, n, &ms->b2);                  // B in G2
+        fr_from_mont(ctx, S.ve.p, vc_can, n);
+        launch(0, 1, crs.t_xi2, vc_can, n, &ms->b2);                  // B in G2
         ntt_dif(ctx, S.ue.p, q.log_n, true, true);                        // U coefficients
-        fr_from_mont(ctx, S.ue.p, S.uc_can.p, n);
-        launch(2, 0, crs.t_xi1, S.uc_can.p, n, &ms->a);                   // A
+        fr_from_mont(ctx, S.ue.p, uc_can, n);
+        launch(2, 0, crs.t_xi1, uc_can, n, &ms->a);                   // A
         // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-        fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, S.hb_can.p + n, n);
+        fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, hb_can + n, n);
         ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
@@ -310,9 +343,9 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ntt_dif(ctx, S.x0.p, q.log_n, true, true);                        // lo + hi
         ntt_dif(ctx, S.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
         Fr half = host_fr_from_u64(2).inv();
-        h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, S.hb_can.p, n);
+        h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, hb_can, n);
         // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
-        launch(4, 2, crs.t_hb1, S.hb_can.p, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
+        launch(4, 2, crs.t_hb1, hb_can, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
     } else {
         unsigned lc = 1;
         while (((size_t)1 << lc) < 2 * n) ++lc;
@@ -353,13 +386,19 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }
 
-    // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof
-    hipStream_t fin = ctx->finish;
-    ZK_HIP(hipEventRecord(S.fork_evt, st));
-    ZK_HIP(hipStreamWaitEvent(fin, S.fork_evt, 0));
-    for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k)
-        if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
-    if (d_partial_out) {
+    // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof.  A
+    // scalars-only ticket completes on its own main stream: the finish stream may hold the join of an earlier ticket's
+    // inner products, which would delay this one's completion by a whole round.
+    hipStream_t fin = xout ? st : ctx->finish;
+    if (!xout) {
+        ZK_HIP(hipEventRecord(S.fork_evt, st));
+        ZK_HIP(hipStreamWaitEvent(fin, S.fork_evt, 0));
+        for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k)
+            if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
+    }
+    if (xout) {
+        // nothing to assemble: the ticket completes when the scalars are written
+    } else if (d_partial_out) {
         ZK_HIP(hipMemsetAsync(d_partial_out, 0, ZK_PARTIAL_BYTES, fin));
         ZK_HIP(hipMemcpyAsync(d_partial_out, ms, sizeof(MsmResults), hipMemcpyDeviceToDevice, fin));
     } else {
@@ -371,6 +410,73 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
     }
+    ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
+    ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.busy = true;
+    ctx->cur_slot = -1;
+    ps.next = (ticket + 1) % ProveState::SLOTS;
+    return ticket;
+}
+
+// The inner products of `sets` proofs over this rank's points: d_l / d_vc / d_uc / d_hb hold `sets` chunks each (what
+// the all-to-all delivered: chunk j = the scalars of proof j for the points of `rank`); the partial sums of proof j go
+// to d_partials_out + j ZK_PARTIAL_BYTES.  One ticket for the whole batch: the sets follow each other on the same
+// five MSM streams, so one slot's workspaces serve them all.
+int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets, int rank, int world,
+                     const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out) {
+    zk_crs& crs = const_cast<zk_crs&>(crs_c);
+    ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
+    ProveState& ps = prove_state(ctx);
+    const int ticket = ps.next;
+    ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
+    crs_ensure_tables(ctx, crs, true, q.log_n);
+    struct StreamSwap {
+        zk_ctx* c; hipStream_t saved;
+        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
+    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
+    hipStream_t st = ctx->stream;
+    ctx->cur_slot = ticket;
+    S.partial = true;
+    const ExchangeDims xd = exchange_dims(q, world);
+    const size_t n = q.n, nl = q.m > q.input + 1 ? q.m - q.input - 1 : 0, g = (size_t)rank;
+    auto range = [&](size_t c, size_t count, size_t* lo) {   // this rank's points of a product: [lo, lo + returned count)
+        *lo = std::min(g * c, count);
+        return std::min(c, count - *lo);
+    };
+    ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
+    ZK_HIP(hipMemsetAsync(d_partials_out, 0, (size_t)sets * ZK_PARTIAL_BYTES, st));
+    // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
+    // reduction tails (group j = proof j with its own 2^(c-1) buckets); chain L -> B2 -> A -> H as in a whole proof
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out) {
+        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];
+        ZK_HIP(hipEventRecord(S.fork_evt, st));
+        ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
+        hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
+        size_t lo;
+        const size_t valid = range(chunk, count, &lo);
+        MsmGroups grp;
+        grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
+        if (sets == 1) msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo);
+        else msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
+        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        ps.last_acc = S.acc_evt[k];
+    };
+    if (sets > 0) {
+        MsmResults* ms = reinterpret_cast<MsmResults*>(d_partials_out);
+        launch(1, -1, crs.t_sum_delta1, d_l, xd.cl, nl, &ms->l);
+        launch(0, 1, crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
+        launch(2, 0, crs.t_xi1, d_uc, xd.cn, n, &ms->a);
+        launch(4, 2, crs.t_hb1, d_hb, xd.ch, 2 * n, &ms->hb);
+    }
+    hipStream_t fin = ctx->finish;
+    ZK_HIP(hipEventRecord(S.fork_evt, st));
+    ZK_HIP(hipStreamWaitEvent(fin, S.fork_evt, 0));
+    if (sets > 0)
+        for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k)
+            if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
     S.busy = true;
@@ -393,7 +499,7 @@ void prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
 
 void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
                uint8_t* proof_out, int rank, int world, void* d_partial_out) {
-    int t = prove_submit(ctx, crs, qap, d_weights, m, r, s, rank, world, d_partial_out);
+    int t = prove_submit(ctx, crs, qap, d_weights, m, r, s, rank, world, d_partial_out, nullptr);
     prove_wait(ctx, t, proof_out);
 }
 
@@ -410,8 +516,9 @@ void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     crs_ensure_fixed_tables(ctx, crs);
     ProveState& ps = prove_state(ctx);
-    // on the finish stream: a pipelined caller has the next proof's stages queued on the main stream already
-    hipStream_t st = ctx->finish;
+    // on the side stream: a pipelined caller has the next proofs' stages queued on the main streams already, and the
+    // finish stream holds their joins (it would make this proof's assembly wait for the NEXT proof's inner products)
+    hipStream_t st = ctx->side;
     launch_pre(ctx, crs, st, rc, sc, ps.comb_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, ps.comb_ms.p);
     hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.comb_proof.p);
