@@ -5,10 +5,12 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one groth16::prove of the 2^20-gate chain circuit (SURVEY.md 8d: m = 2n+2 wires,
-l = 2, roots w^j) with CRS, QAP and witness already resident in HBM.  At N > 1 the Pippenger
-windows of the five inner products are sharded over the ranks (rank g owns windows w = g mod N),
-every rank recomputes the NTT stage, the 768-byte partial sums are all-gathered over RCCL and
-combined (--mode shard, scaling "strong"); --mode replicas runs one independent prover per GPU.
+l = 2, roots w^j) per GPU, with CRS, QAP and witness already resident in HBM.  At N > 1 (--mode exchange, the
+default) a step is one ROUND of N proofs: rank j runs the SpMV / NTT stage of proof j, RCCL all-to-alls hand every
+rank the scalars that multiply its own point range of the four inner products, the rank accumulates them for all N
+proofs in grouped MSMs, a second all-to-all returns the 768-byte partial sums to the owners (scaling "weak": per-GPU
+work per step does not depend on N).  --mode shard is the latency form (one proof at a time, every rank repeats
+the NTT stage, one all-gather; scaling "strong"); --mode replicas runs one independent prover per GPU.
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel, HIP-event
 timed inside the library over the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle's

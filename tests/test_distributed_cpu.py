@@ -1,5 +1,6 @@
-"""-m "not gpu": the N > 1 path (partial sums -> all-gather of byte blobs -> combine) exercised
-with world_size 2 over the gloo backend on CPU.  The per-rank compute is a stand-in built on the
+"""-m "not gpu": the N > 1 paths -- the scalar exchange (scalars -> all-to-all -> inner products over the rank's
+points -> all-to-all of partial sums -> combine; every rank owns a different proof per round) and the latency form
+(partial sums -> all-gather of byte blobs -> combine) -- exercised with world_size 2 over the gloo backend on CPU.  The per-rank compute is a stand-in built on the
 CPU oracle (each rank sums the terms i = rank mod world of the five inner products); what is under
 test is the protocol in zksnark_rs_amd/distributed.py that bench.py runs over RCCL."""
 import os
@@ -94,11 +95,86 @@ def _worker(rank, world, port, q):
             c = pyref.g1_add(c, pyref.g1_neg(pyref.g1_mul(s1["delta"], F.mul(r, s))))
             return pyref.enc_proof(a, b, c)
 
+    class CpuExchangeProver:
+        """Stand-in for GpuExchangeProver: scalars of a proof as `world` chunks per product (32-byte big-endian
+        integers), inner products over this rank's point range, blob = enc(A) | enc(HB) | enc(L) | enc(B2)."""
+        def __init__(self, my_wts):
+            self.wts = my_wts
+            nl = len(s1["sum_delta"])
+            self.counts = [nl, n, n, 2 * n - 1]
+            self.chunk = [-(-c // world) for c in self.counts]
+
+        def exchange_buffers(self, world):
+            z = lambda nb: torch.zeros(nb, dtype=torch.uint8)
+            return ([z(32 * c * world) for c in self.chunk], [z(32 * c * world) for c in self.chunk], z(world * PARTIAL_BYTES), z(world * PARTIAL_BYTES))
+
+        def scalars_submit(self, r, s, world, send):
+            sw = lambda polys: pyref.poly_sum(F, [pyref.poly_scale(F, p, a) for p, a in zip(polys, self.wts)])
+            Uc, Vc, Wc = sw(qap["u"]), sw(qap["v"]), sw(qap["w"])
+            hq, _ = pyref.poly_divmod(F, pyref.poly_sub(F, pyref.poly_mul(F, Uc, Vc), Wc), qap["t"])
+            pad = lambda v, k: (list(v) + [0] * k)[:k]
+            hk = pad(hq, n - 1) + [(r * v + s * u) % pyref.R for u, v in zip(pad(Uc, n), pad(Vc, n))]
+            arrays = [list(self.wts[l + 1:]), pad(Vc, n), pad(Uc, n), hk]
+            for buf, arr, c in zip(send, arrays, self.chunk):
+                raw = b"".join(int(x).to_bytes(32, "big") for x in pad(arr, c * world))
+                buf.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            return 0
+
+        def wait(self, ticket):
+            pass
+
+        def msm_submit(self, sets, rank, world, recv, part_send):
+            bases = [s1["sum_delta"], s2["xi"], s1["xi"], list(s1["xi_t"])[:n - 1] + list(s1["xi"])]
+            out = b""
+            for j in range(sets):
+                pts = []
+                for k, (buf, c, cnt) in enumerate(zip(recv, self.chunk, self.counts)):
+                    raw = bytes(buf.numpy().tobytes())[32 * c * j:32 * c * (j + 1)]
+                    sc = [int.from_bytes(raw[32 * i:32 * i + 32], "big") for i in range(c)]
+                    lo = min(rank * c, cnt)
+                    hi = min(lo + c, cnt)
+                    assert all(x == 0 for x in sc[hi - lo:])
+                    msm = pyref.msm_g2 if k == 1 else pyref.msm_g1
+                    pts.append(msm(bases[k][lo:hi], sc[:hi - lo]))
+                blob = enc_pt(pts[2]) + enc_pt(pts[3]) + enc_pt(pts[0]) + enc_pt(pts[1], True)
+                out += blob + bytes(PARTIAL_BYTES - len(blob))
+            part_send.copy_(torch.frombuffer(bytearray(out), dtype=torch.uint8))
+            return 0
+
+        def comm_done(self):
+            pass
+
+        def combine_own(self, part_recv, world, r, s):
+            raw = bytes(part_recv.numpy().tobytes())
+            acc = [None] * 4
+            for g in range(world):
+                b = raw[g * PARTIAL_BYTES:(g + 1) * PARTIAL_BYTES]
+                for k in range(3):
+                    acc[k] = pyref.g1_add(acc[k], dec_g1(b[65 * k:65 * k + 65]))
+                acc[3] = pyref.g2_add(acc[3], dec_g2(b[195:324]))
+            a_g1, hb, ll, b_g2 = acc
+            a = pyref.g1_add(pyref.g1_add(a_g1, s1["alpha"]), pyref.g1_mul(s1["delta"], r))
+            b = pyref.g2_add(pyref.g2_add(b_g2, s2["beta"]), pyref.g2_mul(s2["delta"], s))
+            # c = [H + r B1 + s A] + L + s alpha + r beta + (r s) delta   (prove.hip k_assemble; mod.rs:274-293)
+            c = pyref.g1_add(hb, ll)
+            c = pyref.g1_add(c, pyref.g1_mul(s1["alpha"], s))
+            c = pyref.g1_add(c, pyref.g1_mul(s1["beta"], r))
+            c = pyref.g1_add(c, pyref.g1_mul(s1["delta"], F.mul(r, s)))
+            return pyref.enc_proof(a, b, c)
+
+    # scalar exchange: every rank owns a DIFFERENT proof per round (own witness, own r, s): four rounds
+    from zksnark_rs_amd.distributed import prove_exchange_stream
+    rng2 = SplitMix64(700 + rank)
+    my_wts = pyref.chain_weights(n, rng2.fr(), [rng2.fr() for _ in range(n)])
+    my_jobs = [(rng2.fr(), rng2.fr()) for _ in range(4)]
+    my_want = [pyref.enc_proof(*pyref.prove_with_rs(qap, s1, s2, my_wts, rr, ss)) for rr, ss in my_jobs]
+    exchanged = list(prove_exchange_stream(CpuExchangeProver(my_wts), dist, rank, world, my_jobs))
+
     got = prove_sharded(CpuProver(), dist, rank, world, r, s)
     # pipelined driver: three proofs in a row through the two-deep pipeline, same bytes each
     from zksnark_rs_amd.distributed import prove_sharded_stream
     streamed = list(prove_sharded_stream(CpuProver(), dist, rank, world, [(r, s)] * 3))
-    q.put((rank, got == want and streamed == [want] * 3))
+    q.put((rank, got == want and streamed == [want] * 3 and exchanged == my_want))
     dist.destroy_process_group()
 
 
