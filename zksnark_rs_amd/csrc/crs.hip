@@ -108,9 +108,10 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
     if (c.tables_kind == (brev ? 1 : 0) && c.tables_c == ctx->opt_window_bits) return;
     if (brev) crs_ensure_brev(ctx, c, log_n);
     // msm_window_bits: 0 = automatic, c = the same window for every table, 100*big + small = `big` for tables of
-    // 2^21 points and more and `small` below (tuning sweeps)
+    // 2^21 points and more and `small` below, + 10000*g2 = its own window for the G2 table (tuning sweeps)
+    const long o_all = ctx->opt_window_bits, o_g2 = o_all / 10000;
     auto pick = [&](size_t count) {
-        const long o = ctx->opt_window_bits;
+        const long o = o_all % 10000;
         if (o <= 0) return msm_auto_window(count);
         if (o < 100) return (int)o;
         return (int)(count >= ((size_t)1 << 21) - 8 ? o / 100 : o % 100);
@@ -127,7 +128,7 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
     msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
-    msm_build_table<Fq2>(ctx, brev ? c.xi2_br.p : c.xi2.p, n, pick(n), c.t_xi2);
+    msm_build_table<Fq2>(ctx, brev ? c.xi2_br.p : c.xi2.p, n, o_g2 > 0 ? (int)o_g2 : pick(n), c.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables now hold the permuted points
         c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();
