@@ -632,7 +632,8 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     {
         ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
-        const int subs = 1 << sub_bits, parts = std::max(1, std::min(8, 2048 / subs));
+        // workgroups per bin: ~2048 level-2 workgroups in all (a grouped product has `groups` times the bins, each with 1 / groups of the records)
+        const int subs = 1 << sub_bits, parts = std::max(1, std::min(8, 2048 / subs) / groups);
         ws.bin_cnt.ensure((size_t)bins * parts * subs);
         hipLaunchKernelGGL(k_msm_bin_hist, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits, ws.bin_cnt.p);
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, bins, parts, sub_bits, ws.start.p);
