@@ -160,6 +160,8 @@ def main():
     import zksnark_rs_amd as zk
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        args.warmup = max(args.warmup, 1)   # the first collectives (RCCL set-up) never fall into the timed region
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -235,8 +237,11 @@ def main():
                           "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
         return
 
+    state = {"degraded": None}
+
     def run(k, local=False):
         """k steps, all submitted and completed inside this call; returns the proof bytes (local: independent provers)."""
+        local = local or state["degraded"] is not None
         shard = shard_mode and not local
         if exchange and not local:
             return list(prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k))   # k rounds = k * world proofs
@@ -256,8 +261,25 @@ def main():
         return out
 
     proof = None
-    for p in run(args.warmup):
-        proof = p
+    # The collectives of the sharded protocols have only ever run over gloo before the driver's multi-GPU runs.  If the
+    # warm-up fails on any rank (a collective RCCL refuses), every rank falls back to independent provers and the
+    # line says so ("degraded") instead of the job producing no number at all.
+    err = None
+    try:
+        for p in run(args.warmup):
+            proof = p
+    except Exception as e:   # noqa: BLE001 -- reported in the JSON line
+        if not dist:
+            raise
+        err = "%s: %s" % (type(e).__name__, str(e)[:300])
+    if dist:
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            state["degraded"] = err or "another rank failed in the warm-up of --mode %s" % args.mode
+            torch.cuda.synchronize()
+            for p in run(args.warmup):
+                proof = p
     ctx.set_option("profile", 1)
     ctx.profile_reset()
     torch.cuda.synchronize()
@@ -278,6 +300,8 @@ def main():
     # beside the window-sharded line (north_star, configs[4]): the same K steps as independent provers, one
     # per GPU, no collective -- the throughput mode.  Reported as a secondary object, never as `value`.
     replicas = None
+    if state["degraded"] is not None:
+        shard = exchange = False
     if shard or exchange:
         run(args.warmup, local=True)
         torch.cuda.synchronize()
@@ -345,6 +369,7 @@ def main():
                        "proofs_in_flight": depth, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             **({"replicas": replicas} if replicas else {}),
+            **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
