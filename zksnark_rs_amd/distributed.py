@@ -63,6 +63,7 @@ def prove_sharded(prover, dist, rank, world, r, s, buffers=None):
     (identical on every rank)."""
     if buffers is None:
         buffers = (prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES))
+        prover.gather_done()
     part, gathered = buffers
     prover.partial(rank, world, r, s, part)
     if world > 1:
@@ -77,6 +78,7 @@ def prove_sharded_stream(prover, dist, rank, world, jobs, depth=4):
     before proof k's all-gather and final assembly, so the GPU never idles on the collective or on the
     latency-bound tail.  `depth` proofs are in flight (the C ABI allows ZK_MAX_IN_FLIGHT = 4).  Yields the proof bytes in order."""
     bufs = [(prover.new_buffer(PARTIAL_BYTES), prover.new_buffer(world * PARTIAL_BYTES)) for _ in range(depth)]
+    prover.gather_done()   # torch zero-fills the new buffers on its own stream; the library writes them on others
     inflight = []
 
     def finish(item):
@@ -143,6 +145,7 @@ def prove_exchange_stream(prover, dist, rank, world, jobs):
     are local copies."""
     rounds = len(jobs)
     bufs = [prover.exchange_buffers(world) for _ in range(2)]
+    prover.comm_done()   # torch zero-fills the new buffers on its own stream; the library writes them on others
     single = world == 1 or dist is None
 
     def exchange(outs, ins):
