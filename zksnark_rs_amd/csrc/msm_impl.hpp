@@ -400,7 +400,10 @@ __global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, int, int, co
 // waves; the G2 body (XYZZ over Fq2: 72 accumulator limbs + the affine point before any temporary)
 // fits 2 with 16 dwords of scratch.
 template <class F> struct AccWaves { static constexpr int value = 3; };
-template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
+#ifndef ZK_G2_ACC_WAVES
+#define ZK_G2_ACC_WAVES 2
+#endif
+template <> struct AccWaves<Fq2> { static constexpr int value = ZK_G2_ACC_WAVES; };
 
 // register image of an accumulator as it is parked in HBM between accumulate and merge
 template <class F>
