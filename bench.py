@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--depth", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="proofs in flight per GPU (zk_prove_submit/zk_prove_wait); 1 = synchronous zk_prove_dev; "
                          "0 = 2 for whole proofs, 4 for the per-rank shares of a sharded proof")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
+                         "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -249,6 +252,17 @@ def main():
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
         if shard:
             return list(prove_sharded_stream(prover, dist, rank, world, [(inst["r"], inst["s"])] * k, depth))
+        if args.batch > 1:
+            out, inflight, left = [], [], k
+            while left or inflight:
+                if left and len(inflight) < 2:
+                    g = min(args.batch, left)
+                    inflight.append((ctx.prove_batch_submit(inst["crs"], inst["qap"], [d_w.data_ptr()] * g, [m] * g, [inst["r"]] * g, [inst["s"]] * g), g))
+                    left -= g
+                else:
+                    t, g = inflight.pop(0)
+                    out.extend(ctx.prove_batch_wait(t, g))
+            return out
         if depth == 1:
             return [ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
         out, inflight = [], []
@@ -366,7 +380,7 @@ def main():
                                       else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums; "
                                             "a step = one round of %d proofs" % (world, world)) if exchange
                                       else ("replicas x%d" % world),
-                       "proofs_in_flight": depth, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
+                       "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             **({"replicas": replicas} if replicas else {}),
             **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),

@@ -211,6 +211,18 @@ int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const voi
                     const uint64_t r[4], const uint64_t s[4], int* ticket);
 int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out /* ZK_PROOF_BYTES; may be NULL for a partial ticket */);
 
+/* Batches (roots-of-unity QAP form): `count` proofs over the same CRS / QAP with their own witnesses and (r, s) as one
+ * unit of work -- the SpMV / NTT stages follow each other, the inner products of all proofs run as one grouped MSM per
+ * product, two launches assemble them.  For circuits of 2^16 gates and fewer a single proof is bound by the latency
+ * of its ~100 dependent launches; a batch spreads that chain over `count` proofs (2^16 gates: 2.6 ms per proof alone).
+ * d_weights[j]: device pointer to proof j's witness (m[j] x 4 words, canonical); r, s: count x 4 words;
+ * proofs_out: count x ZK_PROOF_BYTES.  A batch ticket counts as one proof in flight; a witness element >= r fails
+ * the whole batch (ZK_ERR_RANGE from zk_prove_batch_wait). */
+#define ZK_MAX_BATCH 64
+int zk_prove_batch_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int count, const void* const* d_weights, const size_t* m,
+                          const uint64_t* r, const uint64_t* s, int* ticket);
+int zk_prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out);
+
 /* Multi-GPU: every rank holds the CRS and recomputes the NTT stage; rank g owns
  * Pippenger windows w = g (mod world) of each inner product and writes its partial sums
  * (Jacobian, device Montgomery limbs) to d_partial_out (ZK_PARTIAL_BYTES).  The caller all-gathers

@@ -247,6 +247,38 @@ def test_scalar_exchange_on_one_gpu(ctx, orc, log_n):
     assert got == [want[0], alt, want[0], alt, want[0]]
 
 
+@pytest.mark.parametrize("log_n", [0, 2, 6, 12])
+def test_prove_batch(ctx, orc, log_n):
+    """zk_prove_batch_*: several proofs with their own witnesses / (r, s) as one grouped unit == zk_prove one by one
+    (also a truncated and an all-zero witness in the batch; batches of 1, 3 and 5; two batches in flight)."""
+    torch = pytest.importorskip("torch")
+    inst = chain_instance(ctx, log_n, 900 + log_n)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    rng = SplitMix64(31 + log_n)
+    wits = [inst["weights"]]
+    for k in range(4):
+        wits.append(chain_weights(log_n, rng.fr(), [rng.fr() for _ in range(inst["n"])]))
+    wits[2] = wits[2][:max(1, inst["m"] - 2)]
+    wits[3] = np.zeros_like(wits[3])
+    rs = [rng.fr() for _ in wits]
+    ss = [rng.fr() for _ in wits]
+    want = [ctx.prove(crs, inst["qap"], w, r, s) for w, r, s in zip(wits, rs, ss)]
+    dws = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w in wits]
+    torch.cuda.synchronize()
+    for count in (1, 3, 5):
+        t = ctx.prove_batch_submit(crs, inst["qap"], [d.data_ptr() for d in dws[:count]], [w.shape[0] for w in wits[:count]], rs[:count], ss[:count])
+        assert ctx.prove_batch_wait(t, count) == want[:count], count
+    t1 = ctx.prove_batch_submit(crs, inst["qap"], [d.data_ptr() for d in dws[:2]], [w.shape[0] for w in wits[:2]], rs[:2], ss[:2])
+    t2 = ctx.prove_batch_submit(crs, inst["qap"], [d.data_ptr() for d in dws[2:]], [w.shape[0] for w in wits[2:]], rs[2:], ss[2:])
+    assert ctx.prove_batch_wait(t1, 2) == want[:2] and ctx.prove_batch_wait(t2, 3) == want[2:]
+    # a single proof still works after batches, and a batch ticket is refused by the single-proof wait
+    assert ctx.prove(crs, inst["qap"], wits[1], rs[1], ss[1]) == want[1]
+    t = ctx.prove_batch_submit(crs, inst["qap"], [dws[0].data_ptr()], [wits[0].shape[0]], rs[:1], ss[:1])
+    with pytest.raises(zk.ZkError):
+        ctx.prove_wait(t)
+    assert ctx.prove_batch_wait(t, 1) == want[:1]
+
+
 def test_two_contexts_interleaved(orc):
     """Two contexts on one device (separate streams, slots and tables) proving in an interleaved, pipelined way,
     then destroyed and re-created: same bytes as a lone context."""

@@ -353,6 +353,25 @@ class Context:
         s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
         self._check(self.lib.zk_prove_partial(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, rank, world, C.c_void_p(d_partial_ptr)))
 
+    # ---- batches (zkgpu.h: zk_prove_batch_submit / zk_prove_batch_wait) ----
+    def prove_batch_submit(self, crs, qap, d_weight_ptrs, ms, rs, ss):
+        """Enqueue len(rs) proofs over one CRS / QAP as a batch (own witness pointer, length and (r, s) each)."""
+        count = len(rs)
+        ptrs = (C.c_void_p * count)(*[C.c_void_p(p) for p in d_weight_ptrs])
+        lens = (C.c_size_t * count)(*ms)
+        r_ = np.ascontiguousarray(np.stack([fr_to_limbs(x) if isinstance(x, int) else np.asarray(x, dtype=np.uint64) for x in rs]).reshape(-1), dtype=np.uint64)
+        s_ = np.ascontiguousarray(np.stack([fr_to_limbs(x) if isinstance(x, int) else np.asarray(x, dtype=np.uint64) for x in ss]).reshape(-1), dtype=np.uint64)
+        t = C.c_int(-1)
+        self._check(self.lib.zk_prove_batch_submit(self.ptr, crs.ptr, qap.ptr, count, ptrs, lens, r_.ctypes.data_as(_lib.u64p),
+                                                   s_.ctypes.data_as(_lib.u64p), C.byref(t)))
+        return t.value
+
+    def prove_batch_wait(self, ticket, count):
+        out = np.zeros(count * PROOF_BYTES, dtype=np.uint8)
+        self._check(self.lib.zk_prove_batch_wait(self.ptr, ticket, count, out.ctypes.data_as(_lib.u8p)))
+        raw = out.tobytes()
+        return [raw[k * PROOF_BYTES:(k + 1) * PROOF_BYTES] for k in range(count)]
+
     # ---- multi-GPU scalar exchange (zkgpu.h: zk_prove_scalars_submit / zk_prove_msm_submit) ----
     def prove_exchange_elems(self, qap, world):
         """Element counts (32-byte Fr) of the four exchange arrays L, V, U, H for `world` ranks."""

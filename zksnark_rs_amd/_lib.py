@@ -85,6 +85,9 @@ SIGNATURES = {
     "zk_prove_partial_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(C.c_int)]),
     "zk_prove_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p]),
+    "zk_prove_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), u64p, u64p,
+                                        C.POINTER(C.c_int)]),
+    "zk_prove_batch_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u8p]),
     "zk_prove_exchange_elems": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "zk_prove_scalars_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

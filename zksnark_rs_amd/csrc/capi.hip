@@ -201,6 +201,15 @@ int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, c
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || !ticket || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
     return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, rank, world, d_partial_out); });
 }
+int zk_prove_batch_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int count, const void* const* d_weights, const size_t* m,
+                          const uint64_t* r, const uint64_t* s, int* ticket) {
+    if (!ctx || !crs || !qap || !d_weights || !m || !r || !s || !ticket) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { *ticket = prove_batch_submit(ctx, *crs, *qap, count, d_weights, m, r, s); });
+}
+int zk_prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out) {
+    if (!ctx || !proofs_out) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { prove_batch_wait(ctx, ticket, count, proofs_out); });
+}
 int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]) {
     if (!qap || world < 1 || !elems_out) return ZK_ERR_ARG;
     if (qap->dense) return ZK_ERR_UNSUPPORTED;

@@ -34,10 +34,11 @@ std::shared_ptr<NttTables> ntt_get_tables(zk_ctx*, unsigned log_n);
 void ntt_ensure_coset_tables(zk_ctx*, NttTables&);
 
 // natural order in -> bit-reversed order out.  inverse: use w^-1; scale_n_inv: multiply by 1/n.
-void ntt_dif(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv);
+// batch: d_data holds `batch` transforms of 2^log_n elements back to back, transformed in the same launches
+void ntt_dif(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, size_t batch = 1);
 // bit-reversed order in -> natural order out.  d_pre (optional): element-wise multiplier applied
 // to the input (in its bit-reversed order) as it is loaded.
-void ntt_dit(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, const Fr* d_pre);
+void ntt_dit(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, const Fr* d_pre, size_t batch = 1);
 void bitrev_permute(zk_ctx*, const Fr* d_in, Fr* d_out, unsigned log_n);
 // out[i] = a[i] * b[i]
 void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);

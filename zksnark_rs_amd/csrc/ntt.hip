@@ -158,6 +158,8 @@ typedef FpR<FrParams> FrL;
 
 struct NttPass {
     unsigned log_rows, log_cols;
+    unsigned log_tiles;   // tiles per transform; workgroup b * tiles + t is tile t of transform b (batches: data = [batch][n])
+    size_t n;             // transform length
     size_t row_stride, tile_stride;
     const Fr* tw;    // w_2048^(+-k), k < 1024
     const Fr* mid;   // applied on store (data layout) or nullptr
@@ -275,9 +277,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     const unsigned log_rows = p.log_rows, log_cols = p.log_cols;
     const int cols = 1 << log_cols;
     const int elems = 1 << (log_rows + log_cols);
-    Fr* base = data + (size_t)blockIdx.x * p.tile_stride;
-    const Fr* pre = p.pre ? p.pre + (size_t)blockIdx.x * p.tile_stride : nullptr;
-    const Fr* mid = p.mid ? p.mid + (size_t)blockIdx.x * p.tile_stride : nullptr;
+    const unsigned tile = blockIdx.x & ((1u << p.log_tiles) - 1);
+    Fr* base = data + (size_t)(blockIdx.x >> p.log_tiles) * p.n + (size_t)tile * p.tile_stride;
+    const Fr* pre = p.pre ? p.pre + (size_t)tile * p.tile_stride : nullptr;
+    const Fr* mid = p.mid ? p.mid + (size_t)tile * p.tile_stride : nullptr;
 
     // load: consecutive lanes walk the `cols` contiguous elements of a row, then the next row
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
@@ -324,7 +327,7 @@ static void launch_pass(zk_ctx* ctx, bool dit, Fr* d, const NttPass& p, size_t t
     ZK_HIP(hipGetLastError());
 }
 
-static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre) {
+static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch) {
     static bool attr_set = false;
     if (!attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
@@ -334,19 +337,20 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     auto tabs = ntt_get_tables(ctx, log_n);
     size_t n = (size_t)1 << log_n;
     const Fr* tw = inverse ? tabs->tw_inv.p : tabs->tw_fwd.p;
-    double pass_bytes = 64.0 * n;  // read + write of every element
+    double pass_bytes = 64.0 * n * batch;  // read + write of every element
+    if (!batch) return;
     if (log_n <= NTT_MAX_LOCAL_LOG) {
-        NttPass p{log_n, 0, 1, n, tw, nullptr, d_pre, tabs->n_inv, scale ? 1 : 0};
-        launch_pass(ctx, dit, d, p, 1, "ntt_tile", pass_bytes);
+        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, tabs->n_inv, scale ? 1 : 0};
+        launch_pass(ctx, dit, d, p, batch, "ntt_tile", pass_bytes);
         return;
     }
     unsigned a = log_n - NTT_MAX_LOCAL_LOG;                 // column transform size 2^a
     unsigned log_c = NTT_MAX_LOCAL_LOG > a ? NTT_MAX_LOCAL_LOG - a : 0;  // columns per tile
     size_t r2 = (size_t)1 << NTT_MAX_LOCAL_LOG;
     const Fr* mid = inverse ? tabs->mid_inv.p : tabs->mid_fwd.p;
-    NttPass col{a, log_c, r2, (size_t)1 << log_c, tw, nullptr, nullptr, tabs->n_inv, 0};
-    NttPass row{NTT_MAX_LOCAL_LOG, 0, 1, r2, tw, nullptr, nullptr, tabs->n_inv, 0};
-    size_t col_tiles = r2 >> log_c, row_tiles = (size_t)1 << a;
+    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, nullptr, nullptr, tabs->n_inv, 0};
+    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, tabs->n_inv, 0};
+    size_t col_tiles = (r2 >> log_c) * batch, row_tiles = ((size_t)1 << a) * batch;
     if (!dit) {
         col.mid = mid;
         row.has_post = scale ? 1 : 0;
@@ -361,8 +365,8 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     }
 }
 
-void ntt_dif(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale) { ntt_core(ctx, false, d, log_n, inverse, scale, nullptr); }
-void ntt_dit(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre) { ntt_core(ctx, true, d, log_n, inverse, scale, d_pre); }
+void ntt_dif(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, size_t batch) { ntt_core(ctx, false, d, log_n, inverse, scale, nullptr, batch); }
+void ntt_dit(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch) { ntt_core(ctx, true, d, log_n, inverse, scale, d_pre, batch); }
 
 __global__ void k_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, unsigned log_n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -88,6 +88,9 @@ void prove_exchange_elems(const zk_qap&, int world, size_t out[4]);
 int prove_msm_submit(zk_ctx*, const zk_crs&, const zk_qap&, int sets, int rank, int world,
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out);
 void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
+int prove_batch_submit(zk_ctx*, const zk_crs&, const zk_qap&, int count, const void* const* d_weights, const size_t* m,
+                       const uint64_t* r, const uint64_t* s);
+void prove_batch_wait(zk_ctx*, int ticket, int count, uint8_t* proofs_out);
 void prove_combine(zk_ctx*, const zk_crs&, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
 
 }  // namespace zk

@@ -14,7 +14,9 @@
 //   a, b, c assembly with r, s            :274-293   one small kernel; scalar mults by r, s
 //
 // (r, s) are injected: the reference draws them from thread_rng (mod.rs:231).
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
 
@@ -120,6 +122,40 @@ __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__
     if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
 }
 
+// batch forms (zk_prove_batch_*): workgroup j serves proof j; (r, s) pairs and partial-sum blobs in device memory
+__global__ __launch_bounds__(320) void k_assemble_pre_batch(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
+                                                            const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
+                                                            const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
+    __shared__ G1J sh1[4][64];
+    __shared__ G2J sh2[64];
+    __shared__ G1J res[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Fr r = rs[2 * blockIdx.x], s = rs[2 * blockIdx.x + 1];
+    out += blockIdx.x;
+    Fr rsp = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
+    if (wave == 0) fixed_base_mul_wave<Fq>(ft_delta1, r, sh1[0], lane, &res[0]);
+    else if (wave == 1) fixed_base_mul_wave<Fq>(ft_alpha1, s, sh1[1], lane, &res[1]);
+    else if (wave == 2) fixed_base_mul_wave<Fq>(ft_beta1, r, sh1[2], lane, &res[2]);
+    else if (wave == 3) fixed_base_mul_wave<Fq>(ft_delta1, rsp, sh1[3], lane, &res[3]);
+    else fixed_base_mul_wave<Fq2>(ft_delta2, s, sh2, lane, &out->s_delta2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->r_delta = res[0];
+        out->fixed_c = jac_add_ni(jac_add_ni(res[1], res[2]), res[3]);
+    }
+}
+__global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre,
+                                                        const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proofs) {
+    const MsmResults* ms = reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES);
+    pre += blockIdx.x;
+    uint8_t* proof = proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES;
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x & 63) return;
+    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
+    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
+}
+
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
     int which = threadIdx.x >> 6;
     if ((threadIdx.x & 63) || which > 4) return;
@@ -161,6 +197,13 @@ struct ProveSlot {
     DevBuf<int> flag;
     uint8_t* h_proof = nullptr;    // pinned
     int* h_flag = nullptr;         // pinned
+    // batch form: scalars of the four products for `batch` proofs, their partial sums / (r, s) / proofs
+    DevBuf<Fr> bx_l, bx_v, bx_u, bx_h, b_rs;
+    DevBuf<uint8_t> b_partials, b_proofs;
+    DevBuf<AssemblePre> b_pre;
+    uint8_t* h_b_proofs = nullptr; // pinned, ZK_MAX_BATCH proofs
+    Fr* h_b_rs = nullptr;          // pinned
+    int batch = 0;
     hipEvent_t fork_evt = nullptr, pre_evt = nullptr, done_evt = nullptr;
     hipEvent_t msm_done[zk_ctx::MSM_STREAMS] = {}, acc_evt[zk_ctx::MSM_STREAMS] = {};
     bool busy = false, partial = false;
@@ -179,6 +222,8 @@ struct ProveSlot {
     ~ProveSlot() {
         if (h_proof) (void)hipHostFree(h_proof);
         if (h_flag) (void)hipHostFree(h_flag);
+        if (h_b_proofs) (void)hipHostFree(h_b_proofs);
+        if (h_b_rs) (void)hipHostFree(h_b_rs);
         for (hipEvent_t e : {fork_evt, pre_evt, done_evt}) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
             if (msm_done[k]) (void)hipEventDestroy(msm_done[k]);
@@ -226,6 +271,42 @@ void prove_exchange_elems(const zk_qap& q, int world, size_t out[4]) {
 static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
     hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
     ZK_HIP(hipGetLastError());
+}
+
+// SpMV / NTT stage of one proof in the roots-of-unity form: the scalars of the inner products B2 (vc), A (uc) and
+// H + r B1 + s A (hb: h | r v + s u) from the Montgomery-form witness in S.a_mont.  `launch(k, after, scalars, count)`
+// is called as soon as the scalars of product k exist (k = MSM stream: 1 L, 0 B2, 2 A, 4 HB).
+// accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
+// ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
+template <class Launch>
+static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttTables& tabs_ref, const Fr* d_weights, size_t a_len, size_t n_l,
+                                const Fr& r_mont, const Fr& s_mont, Fr* vc_can, Fr* uc_can, Fr* hb_can, Launch&& launch) {
+    const size_t n = q.n, l = q.input;
+    NttTables* tabs = &tabs_ref;
+    hipStream_t st = ctx->stream;
+    launch(1, -1, d_weights + l + 1, n_l);
+    spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.ue.p);
+    spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.ve.p);
+    fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n);                 // U.V on <w>
+    ntt_dif(ctx, S.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
+    fr_from_mont(ctx, S.ve.p, vc_can, n);
+    launch(0, 1, vc_can, n);
+    ntt_dif(ctx, S.ue.p, q.log_n, true, true);                        // U coefficients
+    fr_from_mont(ctx, S.ue.p, uc_can, n);
+    launch(2, 0, uc_can, n);
+    // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
+    fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, hb_can + n, n);
+    ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
+    ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p);
+    fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n);                 // U.V on g<w>
+    ntt_dif(ctx, S.x0.p, q.log_n, true, true);                        // lo + hi
+    ntt_dif(ctx, S.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
+    Fr half = host_fr_from_u64(2).inv();
+    h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, hb_can, n);
+    // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
+    launch(4, 2, hb_can, 2 * n);
 }
 
 // Enqueues one proof (or one rank's partial sums) and returns without waiting.  ticket = slot index.
@@ -321,31 +402,13 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
             vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
         }
-        // accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
-        // ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
-        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);  // L: sum a_i * sum_delta_i
-        spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.ue.p);
-        spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.ve.p);
-        fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n);                 // U.V on <w>
-        ntt_dif(ctx, S.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
-        fr_from_mont(ctx, S.ve.p, vc_can, n);
-        launch(0, 1, crs.t_xi2, vc_can, n, &ms->b2);                  // B in G2
-        ntt_dif(ctx, S.ue.p, q.log_n, true, true);                        // U coefficients
-        fr_from_mont(ctx, S.ue.p, uc_can, n);
-        launch(2, 0, crs.t_xi1, uc_can, n, &ms->a);                   // A
-        // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-        fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, hb_can + n, n);
-        ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
-        ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p);
-        fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n);                 // U.V on g<w>
-        ntt_dif(ctx, S.x0.p, q.log_n, true, true);                        // lo + hi
-        ntt_dif(ctx, S.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
-        Fr half = host_fr_from_u64(2).inv();
-        h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, hb_can, n);
-        // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
-        launch(4, 2, crs.t_hb1, hb_can, 2 * n, &ms->hb);              // H + r B1 + s A: last in the chain
+        sparse_scalar_stage(ctx, S, q, *tabs, d_weights, a_len, n_l, r_mont, s_mont, vc_can, uc_can, hb_can,
+                            [&](int k, int after, const Fr* scalars, size_t count) {
+                                if (k == 1) launch(1, after, crs.t_sum_delta1, scalars, count, &ms->l);    // L: sum a_i * sum_delta_i
+                                else if (k == 0) launch(0, after, crs.t_xi2, scalars, count, &ms->b2);     // B in G2
+                                else if (k == 2) launch(2, after, crs.t_xi1, scalars, count, &ms->a);      // A
+                                else launch(4, after, crs.t_hb1, scalars, count, &ms->hb);                // H + r B1 + s A: last in the chain
+                            });
     } else {
         unsigned lc = 1;
         while (((size_t)1 << lc) < 2 * n) ++lc;
@@ -485,11 +548,153 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     return ticket;
 }
 
+// `count` whole proofs over the same CRS / QAP as one batch: the SpMV / NTT stages follow each other on the main
+// stream (one slot's scratch serves them all), the inner products run as ONE grouped MSM per product (proof j = group j)
+// and two launches assemble all proofs.  For circuits of 2^16 gates and fewer a proof is bound by the latency of its
+// ~100 dependent launches, not by arithmetic: batching spreads that chain over `count` proofs.
+int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int count, const void* const* d_weights, const size_t* m_in,
+                       const uint64_t* r, const uint64_t* s) {
+    zk_crs& crs = const_cast<zk_crs&>(crs_c);
+    ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: batches need the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(count >= 1 && count <= ZK_MAX_BATCH, ZK_ERR_ARG, "prove: batch size out of range");
+    ProveState& ps = prove_state(ctx);
+    const int ticket = ps.next;
+    ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
+    crs_ensure_tables(ctx, crs, true, q.log_n);
+    crs_ensure_fixed_tables(ctx, crs);
+    if (!S.h_b_proofs) {
+        ZK_HIP(hipHostMalloc((void**)&S.h_b_proofs, (size_t)ZK_MAX_BATCH * ZK_PROOF_BYTES));
+        ZK_HIP(hipHostMalloc((void**)&S.h_b_rs, (size_t)ZK_MAX_BATCH * 2 * sizeof(Fr)));
+    }
+    for (int j = 0; j < count; ++j) {
+        Fr rc = fr_from_words64(r + 4 * j), sc = fr_from_words64(s + 4 * j);
+        ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
+        ZK_REQUIRE(d_weights[j], ZK_ERR_ARG, "prove: null witness");
+        S.h_b_rs[2 * j] = rc; S.h_b_rs[2 * j + 1] = sc;
+    }
+    struct StreamSwap {
+        zk_ctx* c; hipStream_t saved;
+        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
+    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
+    hipStream_t st = ctx->stream;
+    ctx->cur_slot = ticket;
+    S.partial = false;
+    S.batch = count;
+    const size_t n = q.n, m = q.m, l = q.input, nl = m > l + 1 ? m - l - 1 : 0, cl = std::max<size_t>(nl, 1);
+    S.bx_l.ensure(cl * count); S.bx_v.ensure(n * count); S.bx_u.ensure(n * count); S.bx_h.ensure(2 * n * count);
+    S.b_rs.ensure(2 * ZK_MAX_BATCH); S.b_pre.ensure(ZK_MAX_BATCH);
+    S.b_partials.ensure((size_t)ZK_MAX_BATCH * ZK_PARTIAL_BYTES); S.b_proofs.ensure((size_t)ZK_MAX_BATCH * ZK_PROOF_BYTES);
+    ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
+    ZK_HIP(hipMemsetAsync(S.b_partials.p, 0, (size_t)count * ZK_PARTIAL_BYTES, st));
+    // r/s-only fixed-base multiplications of all proofs on the side stream
+    {
+        hipStream_t pre_st = ctx->opt_serialize ? st : ctx->side;
+        ZK_HIP(hipMemcpyAsync(S.b_rs.p, S.h_b_rs, (size_t)count * 2 * sizeof(Fr), hipMemcpyHostToDevice, pre_st));
+        hipLaunchKernelGGL(k_assemble_pre_batch, dim3(count), dim3(320), 0, pre_st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p,
+                           S.b_rs.p, S.b_pre.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
+    }
+    MsmResults* ms = reinterpret_cast<MsmResults*>(S.b_partials.p);
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t glen, size_t valid, auto* out) {
+        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];
+        ZK_HIP(hipEventRecord(S.fork_evt, st));
+        ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
+        hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
+        MsmGroups grp;
+        grp.groups = count; grp.glen = glen; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
+        if (count == 1) msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k]);
+        else msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
+        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        ps.last_acc = S.acc_evt[k];
+    };
+    // L needs only the witnesses (zip truncation, mod.rs:233-253: zero scalars behind a short witness)
+    ZK_HIP(hipMemsetAsync(S.bx_l.p, 0, cl * count * sizeof(Fr), st));
+    std::vector<size_t> a_len(count), n_l(count);
+    for (int j = 0; j < count; ++j) {
+        a_len[j] = std::min(m_in[j], m);
+        n_l[j] = a_len[j] > l + 1 ? std::min(a_len[j] - l - 1, m - l - 1) : 0;
+        if (n_l[j]) ZK_HIP(hipMemcpyAsync(S.bx_l.p + (size_t)j * cl, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    }
+    launch(1, -1, crs.t_sum_delta1, S.bx_l.p, cl, nl, &ms->l);
+    auto tabs = ntt_get_tables(ctx, q.log_n);
+    ntt_ensure_coset_tables(ctx, *tabs);
+    // the stage of sparse_scalar_stage with a batch dimension: scratch vectors are [count][n], the element-wise kernels and
+    // the six transforms cover all proofs in one launch each; what depends on a proof's own witness or (r, s) (conversion,
+    // SpMV, r v + s u, h) is launched per proof: 5 count + 22 launches instead of 26 count
+    const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
+    S.ue.ensure(n * cnt); S.ve.ensure(n * cnt); S.x0.ensure(n * cnt); S.y0.ensure(n * cnt); S.ug.ensure(n * cnt); S.vg.ensure(n * cnt);
+    S.a_mont.ensure(amax * cnt);
+    for (size_t j = 0; j < cnt; ++j) {
+        Fr* a_mont = S.a_mont.p + j * amax;
+        fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
+        spmv(ctx, q.u_gate, a_mont, a_len[j], S.ue.p + j * n);
+        spmv(ctx, q.v_gate, a_mont, a_len[j], S.ve.p + j * n);
+    }
+    fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n * cnt);                 // U.V on <w>
+    ntt_dif(ctx, S.ve.p, q.log_n, true, true, cnt);                         // V coefficients (bit-reversed order)
+    fr_from_mont(ctx, S.ve.p, S.bx_v.p, n * cnt);
+    launch(0, 1, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
+    ntt_dif(ctx, S.ue.p, q.log_n, true, true, cnt);                         // U coefficients
+    fr_from_mont(ctx, S.ue.p, S.bx_u.p, n * cnt);
+    launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
+    for (size_t j = 0; j < cnt; ++j)
+        fr_lincomb_to_canonical(ctx, S.ve.p + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), S.ue.p + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+                                S.bx_h.p + j * 2 * n + n, n);
+    ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p, cnt);   // U on g<w>
+    ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, cnt);
+    fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n * cnt);                 // U.V on g<w>
+    ntt_dif(ctx, S.x0.p, q.log_n, true, true, cnt);                         // lo + hi
+    ntt_dif(ctx, S.y0.p, q.log_n, true, true, cnt);                         // (lo - hi)_i * g^i
+    const Fr half = host_fr_from_u64(2).inv();
+    for (size_t j = 0; j < cnt; ++j)
+        h_combine(ctx, S.x0.p + j * n, S.y0.p + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
+    launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n, &ms->hb);
+
+    hipStream_t fin = ctx->finish;
+    ZK_HIP(hipEventRecord(S.fork_evt, st));
+    ZK_HIP(hipStreamWaitEvent(fin, S.fork_evt, 0));
+    for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k)
+        if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
+    ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
+    {
+        ProfScope pscope(ctx, "assemble", 0, fin);
+        hipLaunchKernelGGL(k_assemble_batch, dim3(count), dim3(192), 0, fin, S.b_partials.p, S.b_pre.p, crs.alpha1.p, crs.beta2.p, S.b_proofs.p);
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(S.h_b_proofs, S.b_proofs.p, (size_t)count * ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
+    ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
+    ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.busy = true;
+    ctx->cur_slot = -1;
+    ps.next = (ticket + 1) % ProveState::SLOTS;
+    return ticket;
+}
+
+void prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out) {
+    ProveState& ps = prove_state(ctx);
+    ZK_REQUIRE(ticket >= 0 && ticket < ProveState::SLOTS && ps.slot[ticket].busy, ZK_ERR_ARG, "prove_wait: no proof in flight for this ticket");
+    ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(S.batch == count, ZK_ERR_ARG, "prove_batch_wait: the ticket belongs to a batch of a different size");
+    S.busy = false;
+    S.batch = 0;
+    ZK_HIP(hipEventSynchronize(S.done_evt));
+    ctx->resolve_profile(ticket);
+    ZK_REQUIRE(!*S.h_flag, ZK_ERR_RANGE, "prove: witness element >= r");
+    std::memcpy(proofs_out, S.h_b_proofs, (size_t)count * ZK_PROOF_BYTES);
+}
+
 // Waits for a submitted proof; proof_out may be null for partial submissions.
 void prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
     ProveState& ps = prove_state(ctx);
     ZK_REQUIRE(ticket >= 0 && ticket < ProveState::SLOTS && ps.slot[ticket].busy, ZK_ERR_ARG, "prove_wait: no proof in flight for this ticket");
     ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(S.batch == 0, ZK_ERR_ARG, "prove_wait: batch ticket (use zk_prove_batch_wait)");
     S.busy = false;
     ZK_HIP(hipEventSynchronize(S.done_evt));
     ctx->resolve_profile(ticket);
