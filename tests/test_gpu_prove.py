@@ -277,6 +277,11 @@ def test_prove_batch(ctx, orc, log_n):
     with pytest.raises(zk.ZkError):
         ctx.prove_wait(t)
     assert ctx.prove_batch_wait(t, 1) == want[:1]
+    # a refused batch size leaves the context usable
+    big = zk.MAX_BATCH + 1
+    with pytest.raises(zk.ZkError):
+        ctx.prove_batch_submit(crs, inst["qap"], [dws[0].data_ptr()] * big, [wits[0].shape[0]] * big, [rs[0]] * big, [ss[0]] * big)
+    assert ctx.prove(crs, inst["qap"], wits[0], rs[0], ss[0]) == want[0]
 
 
 def test_two_contexts_interleaved(orc):

@@ -17,13 +17,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PROOF_BYTES, PARTIAL_BYTES, MAX_IN_FLIGHT
+from ._lib import PROOF_BYTES, PARTIAL_BYTES, MAX_IN_FLIGHT, MAX_BATCH
 
 R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 Q_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
 __all__ = ["Context", "ZkError", "fr_to_limbs", "limbs_to_int", "ints_to_limbs", "limbs_to_ints",
-           "PROOF_BYTES", "PARTIAL_BYTES", "MAX_IN_FLIGHT", "R_MODULUS", "Q_MODULUS", "SplitMix64", "pairing"]
+           "PROOF_BYTES", "PARTIAL_BYTES", "MAX_IN_FLIGHT", "MAX_BATCH", "R_MODULUS", "Q_MODULUS", "SplitMix64", "pairing"]
 
 
 class ZkError(RuntimeError):

@@ -14,6 +14,7 @@ ZK_ERR_ARG, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_SIZE, ZK_ERR_DIV_BY_ZERO, ZK_ER
 PROOF_BYTES = 259
 PARTIAL_BYTES = 768
 MAX_IN_FLIGHT = 4      # ZK_MAX_IN_FLIGHT
+MAX_BATCH = 64          # ZK_MAX_BATCH
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

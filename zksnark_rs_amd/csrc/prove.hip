@@ -347,6 +347,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
+    S.batch = 0;
     S.partial = d_partial_out != nullptr || xout != nullptr;
 
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
@@ -502,6 +503,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
+    S.batch = 0;
     S.partial = true;
     const ExchangeDims xd = exchange_dims(q, world);
     const size_t n = q.n, nl = q.m > q.input + 1 ? q.m - q.input - 1 : 0, g = (size_t)rank;
@@ -582,7 +584,6 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.partial = false;
-    S.batch = count;
     const size_t n = q.n, m = q.m, l = q.input, nl = m > l + 1 ? m - l - 1 : 0, cl = std::max<size_t>(nl, 1);
     S.bx_l.ensure(cl * count); S.bx_v.ensure(n * count); S.bx_u.ensure(n * count); S.bx_h.ensure(2 * n * count);
     S.b_rs.ensure(2 * ZK_MAX_BATCH); S.b_pre.ensure(ZK_MAX_BATCH);
@@ -670,6 +671,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ZK_HIP(hipMemcpyAsync(S.h_b_proofs, S.b_proofs.p, (size_t)count * ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.batch = count;
     S.busy = true;
     ctx->cur_slot = -1;
     ps.next = (ticket + 1) % ProveState::SLOTS;
