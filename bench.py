@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--depth", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="proofs in flight per GPU (zk_prove_submit/zk_prove_wait); 1 = synchronous zk_prove_dev; "
                          "0 = 2 for whole proofs, 4 for the per-rank shares of a sharded proof")
+    ap.add_argument("--witness-from", choices=["hbm", "pinned", "pageable"], default="hbm",
+                    help="N = 1: where each proof's witness is when the proof is submitted.  hbm (the metric: inputs resident); pinned / "
+                         "pageable = host memory handed to zk_prove_submit_host (the PCIe-inclusive rate quoted in DESIGN.md)")
     ap.add_argument("--batch", type=int, default=1,
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
@@ -241,6 +244,10 @@ def main():
         return
 
     state = {"degraded": None}
+    host_w = None
+    if args.witness_from != "hbm" and world == 1:
+        host_w = ctx.host_alloc(inst["weights"].shape) if args.witness_from == "pinned" else np.empty_like(inst["weights"])
+        host_w[...] = inst["weights"]
 
     def run(k, local=False):
         """k steps, all submitted and completed inside this call; returns the proof bytes (local: independent provers)."""
@@ -262,6 +269,15 @@ def main():
                 else:
                     t, g = inflight.pop(0)
                     out.extend(ctx.prove_batch_wait(t, g))
+            return out
+        if host_w is not None:
+            out, inflight = [], []
+            for _ in range(k):
+                if len(inflight) == depth:
+                    out.append(ctx.prove_wait(inflight.pop(0)))
+                inflight.append(ctx.prove_submit_host(inst["crs"], inst["qap"], host_w.ctypes.data, m, inst["r"], inst["s"]))
+            while inflight:
+                out.append(ctx.prove_wait(inflight.pop(0)))
             return out
         if depth == 1:
             return [ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
@@ -380,7 +396,7 @@ def main():
                                       else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums; "
                                             "a step = one round of %d proofs" % (world, world)) if exchange
                                       else ("replicas x%d" % world),
-                       "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
+                       "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             **({"replicas": replicas} if replicas else {}),
             **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),

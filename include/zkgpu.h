@@ -210,6 +210,15 @@ int zk_prove_dev(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* 
 int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                     const uint64_t r[4], const uint64_t s[4], int* ticket);
 int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out /* ZK_PROOF_BYTES; may be NULL for a partial ticket */);
+/* zk_prove_submit with the witness in HOST memory (what a caller of groth16::prove holds, mod.rs:213-217): the 32 m
+ * bytes are copied into a device buffer owned by the ticket, on the stream the proof starts on.  With page-locked
+ * memory from zk_host_alloc the copy is asynchronous and the transfer of one proof overlaps the inner products of the
+ * previous one (PCIe-inclusive rate of a stream of proofs = resident rate); with pageable memory the call blocks for
+ * the copy.  The buffer must stay valid and unmodified until the matching zk_prove_wait. */
+int zk_prove_submit_host(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+                         const uint64_t r[4], const uint64_t s[4], int* ticket);
+int zk_host_alloc(size_t bytes, void** out);   /* page-locked host memory (hipHostMalloc) */
+void zk_host_free(void* p);
 
 /* Batches (roots-of-unity QAP form): `count` proofs over the same CRS / QAP with their own witnesses and (r, s) as one
  * unit of work -- the SpMV / NTT stages follow each other, the inner products of all proofs run as one grouped MSM per

@@ -284,6 +284,25 @@ def test_prove_batch(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], wits[0], rs[0], ss[0]) == want[0]
 
 
+def test_prove_submit_host(ctx, orc):
+    """zk_prove_submit_host (witness in pageable and in page-locked host memory, two in flight) == zk_prove."""
+    inst = chain_instance(ctx, 11, 321)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    want = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
+    want2 = ctx.prove(crs, inst["qap"], inst["weights"][:inst["m"] - 5], inst["s"], inst["r"])
+    pinned = ctx.host_alloc(inst["weights"].shape)
+    pinned[...] = inst["weights"]
+    pageable = np.ascontiguousarray(inst["weights"])
+    t1 = ctx.prove_submit_host(crs, inst["qap"], pinned.ctypes.data, inst["m"], inst["r"], inst["s"])
+    t2 = ctx.prove_submit_host(crs, inst["qap"], pageable.ctypes.data, inst["m"] - 5, inst["s"], inst["r"])
+    assert ctx.prove_wait(t1) == want and ctx.prove_wait(t2) == want2
+    # more elements than the circuit has wires are ignored (zip, mod.rs:233-253)
+    longer = np.concatenate([pageable, pageable[:3]])
+    t3 = ctx.prove_submit_host(crs, inst["qap"], longer.ctypes.data, longer.shape[0], inst["r"], inst["s"])
+    assert ctx.prove_wait(t3) == want
+    ctx.host_free(pinned)
+
+
 def test_two_contexts_interleaved(orc):
     """Two contexts on one device (separate streams, slots and tables) proving in an interleaved, pipelined way,
     then destroyed and re-created: same bytes as a lone context."""

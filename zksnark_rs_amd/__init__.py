@@ -332,6 +332,32 @@ class Context:
         self._check(self.lib.zk_prove_submit(self.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, C.byref(t)))
         return t.value
 
+    def prove_submit_host(self, crs, qap, weights_host_ptr, m, r, s):
+        """zk_prove_submit_host: the witness (m x 4 words) is in host memory at `weights_host_ptr` (page-locked memory from
+        host_alloc makes the transfer asynchronous); it must stay valid until prove_wait."""
+        r_, rp = _u64(fr_to_limbs(r) if isinstance(r, int) else r)
+        s_, sp = _u64(fr_to_limbs(s) if isinstance(s, int) else s)
+        t = C.c_int(-1)
+        self._check(self.lib.zk_prove_submit_host(self.ptr, crs.ptr, qap.ptr, C.c_void_p(weights_host_ptr), m, rp, sp, C.byref(t)))
+        return t.value
+
+    def host_alloc(self, shape, dtype=np.uint64):
+        """Page-locked host array (zk_host_alloc); free with host_free(arr) when no transfer from it is pending."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        if self.lib.zk_host_alloc(nbytes, C.byref(p)) != 0:
+            raise ZkError(-3)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self.lib.zk_host_free(C.c_void_p(p))
+
     def prove_wait(self, ticket, partial=False):
         if partial:
             self._check(self.lib.zk_prove_wait(self.ptr, ticket, None))

@@ -82,6 +82,9 @@ SIGNATURES = {
     "zk_crs_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "zk_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
     "zk_prove_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
+    "zk_prove_submit_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.POINTER(C.c_int)]),
+    "zk_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zk_host_free": (None, [C.c_void_p]),
     "zk_prove_wait": (C.c_int, [C.c_void_p, C.c_int, u8p]),
     "zk_prove_partial_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(C.c_int)]),

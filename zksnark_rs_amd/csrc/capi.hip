@@ -196,6 +196,19 @@ int zk_prove_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const voi
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !ticket) return ZK_ERR_ARG;
     return guarded(ctx, [&] { *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, 0, 1, nullptr); });
 }
+int zk_prove_submit_host(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+                         const uint64_t r[4], const uint64_t s[4], int* ticket) {
+    if (!ctx || !crs || !qap || (!weights && m) || !r || !s || !ticket) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { *ticket = prove_submit_host(ctx, *crs, *qap, weights, m, r, s); });
+}
+int zk_host_alloc(size_t bytes, void** out) {
+    if (!out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? ZK_OK : ZK_ERR_HIP;
+}
+void zk_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
 int zk_prove_partial_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                             const uint64_t r[4], const uint64_t s[4], int rank, int world, void* d_partial_out, int* ticket) {
     if (!ctx || !crs || !qap || !d_weights || !r || !s || !d_partial_out || !ticket || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;

@@ -201,6 +201,7 @@ struct ProveSlot {
     DevBuf<Fr> bx_l, bx_v, bx_u, bx_h, b_rs;
     DevBuf<uint8_t> b_partials, b_proofs;
     DevBuf<AssemblePre> b_pre;
+    DevBuf<Fr> d_wit;              // witness of a proof submitted with a host pointer
     uint8_t* h_b_proofs = nullptr; // pinned, ZK_MAX_BATCH proofs
     Fr* h_b_rs = nullptr;          // pinned
     int batch = 0;
@@ -710,11 +711,24 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_we
     prove_wait(ctx, t, proof_out);
 }
 
+// The witness is in HOST memory: it is copied into the slot's own device buffer on the stream the proof's first
+// kernels run on, so with page-locked memory (zk_host_alloc) the transfer of proof k+1 overlaps the inner products of
+// proof k and the PCIe-inclusive rate of a stream of proofs is the resident rate.  Pageable memory works too (the
+// runtime stages it; the call then blocks for the duration of the copy).
+int prove_submit_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s) {
+    ProveState& ps = prove_state(ctx);
+    ProveSlot& S = ps.slot[ps.next];
+    ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
+    const size_t mm = std::min(m, qap.m);   // zip truncation (mod.rs:233-253): elements behind m_qap are never read
+    S.d_wit.ensure(std::max<size_t>(mm, 1));
+    hipStream_t st = (ps.next & 1) ? ctx->main_alt : ctx->stream;
+    if (mm) ZK_HIP(hipMemcpyAsync(S.d_wit.p, weights, mm * sizeof(Fr), hipMemcpyHostToDevice, st));
+    return prove_submit(ctx, crs, qap, S.d_wit.p, mm, r, s, 0, 1, nullptr);
+}
+
 void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
-    DevBuf<Fr> dw(std::max<size_t>(m, 1));
-    if (m) ZK_HIP(hipMemcpyAsync(dw.p, weights, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(hipStreamSynchronize(ctx->stream));   // the proof may run on the other main stream
-    prove_dev(ctx, crs, qap, dw.p, m, r, s, proof_out, 0, 1, nullptr);
+    int t = prove_submit_host(ctx, crs, qap, weights, m, r, s);
+    prove_wait(ctx, t, proof_out);
 }
 
 void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
