@@ -262,7 +262,7 @@ static ProveState& prove_state(zk_ctx* ctx) {
 struct ExchangeDims { size_t cl, cn, ch; };
 static ExchangeDims exchange_dims(const zk_qap& q, int world) {
     const size_t w = (size_t)world, nl = q.m > q.input + 1 ? q.m - q.input - 1 : 0;
-    return ExchangeDims{(nl + w - 1) / w, (q.n + w - 1) / w, (2 * q.n + w - 1) / w};
+    return ExchangeDims{std::max<size_t>((nl + w - 1) / w, 1), (q.n + w - 1) / w, (2 * q.n + w - 1) / w};   // never an empty array
 }
 void prove_exchange_elems(const zk_qap& q, int world, size_t out[4]) {
     const ExchangeDims xd = exchange_dims(q, world);
