@@ -284,6 +284,30 @@ def test_prove_batch(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], wits[0], rs[0], ss[0]) == want[0]
 
 
+@pytest.mark.parametrize("window_bits", [4, 7, 12, 18])
+def test_prove_batch_window_sizes(orc, window_bits):
+    """Grouped inner products (batches) with forced Pippenger windows from 4 to 18 bits: 2^3 .. 2^17 buckets per group,
+    sub-bucket levels of the sort from empty to 2^9; batches of 2 and 5 == zk_prove with the automatic window."""
+    torch = pytest.importorskip("torch")
+    ref = zk.Context(0)
+    inst = chain_instance(ref, 9, 4242)
+    crs = ref.setup(inst["qap"], inst["td"])
+    rng = SplitMix64(window_bits)
+    wits = [inst["weights"]] + [chain_weights(9, rng.fr(), [rng.next() & 1 for _ in range(inst["n"])]) for _ in range(2)] + \
+           [chain_weights(9, rng.fr(), [rng.fr() for _ in range(inst["n"])]) for _ in range(2)]
+    rs, ss = [rng.fr() for _ in wits], [rng.fr() for _ in wits]
+    want = [ref.prove(crs, inst["qap"], w, r, s) for w, r, s in zip(wits, rs, ss)]
+    c = zk.Context(0)
+    c.set_option("msm_window_bits", window_bits)
+    qap = c.qap_sparse(9, inst["m"], inst["l"], *chain_rows(9)[2:])
+    crs_c = c.setup(qap, inst["td"])
+    dws = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w in wits]
+    torch.cuda.synchronize()
+    for count in (2, 5):
+        t = c.prove_batch_submit(crs_c, qap, [d.data_ptr() for d in dws[:count]], [w.shape[0] for w in wits[:count]], rs[:count], ss[:count])
+        assert c.prove_batch_wait(t, count) == want[:count], (window_bits, count)
+
+
 def test_prove_submit_host(ctx, orc):
     """zk_prove_submit_host (witness in pageable and in page-locked host memory, two in flight) == zk_prove."""
     inst = chain_instance(ctx, 11, 321)
