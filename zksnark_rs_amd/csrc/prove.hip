@@ -57,9 +57,8 @@ __device__ void fixed_base_mul_wave(const Aff<F>* __restrict__ ft, const Fr& k, 
 
 // Everything that depends only on (r, s) and single CRS points; runs on the side stream while the
 // five inner products execute.  One wave per fixed-base multiplication.
-__global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
-                                                      const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
-                                                      Fr r, Fr s, AssemblePre* __restrict__ out) {
+__device__ __forceinline__ void assemble_pre_body(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1, const G1A* __restrict__ ft_delta1,
+                                                  const G2A* __restrict__ ft_delta2, const Fr& r, const Fr& s, AssemblePre* __restrict__ out) {
     __shared__ G1J sh1[4][64];
     __shared__ G2J sh2[64];
     __shared__ G1J res[4];
@@ -76,6 +75,17 @@ __global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft
         out->r_delta = res[0];
         out->fixed_c = jac_add_ni(jac_add_ni(res[1], res[2]), res[3]);
     }
+}
+__global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
+                                                      const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
+                                                      Fr r, Fr s, AssemblePre* __restrict__ out) {
+    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, r, s, out);
+}
+// batch form (zk_prove_batch_*): workgroup j serves proof j; (r, s) pairs in device memory
+__global__ __launch_bounds__(320) void k_assemble_pre_batch(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
+                                                            const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
+                                                            const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
+    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, rs[2 * blockIdx.x], rs[2 * blockIdx.x + 1], out + blockIdx.x);
 }
 
 __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
@@ -113,47 +123,24 @@ __device__ void encode_g2(const G2J& p, uint8_t* out) {
 //   = [H + r B1 + s A] + L + [s alpha + r beta + (r s) delta]
 // where H + r B1 + s A comes out of ONE inner product: scalars h_i over xi_t and (r v_i + s u_i) over
 // xi.  No scalar multiplication with a run-time base is left.
+__device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const G1A* __restrict__ alpha1,
+                                              const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
+    const int wave = threadIdx.x >> 6;
+    if (threadIdx.x & 63) return;
+    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
+    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
+}
 __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
                                                   const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x & 63) return;
-    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
-    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
+    assemble_body(ms, pre, alpha1, beta2, proof);
 }
 
-// batch forms (zk_prove_batch_*): workgroup j serves proof j; (r, s) pairs and partial-sum blobs in device memory
-__global__ __launch_bounds__(320) void k_assemble_pre_batch(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
-                                                            const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
-                                                            const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
-    __shared__ G1J sh1[4][64];
-    __shared__ G2J sh2[64];
-    __shared__ G1J res[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const Fr r = rs[2 * blockIdx.x], s = rs[2 * blockIdx.x + 1];
-    out += blockIdx.x;
-    Fr rsp = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
-    if (wave == 0) fixed_base_mul_wave<Fq>(ft_delta1, r, sh1[0], lane, &res[0]);
-    else if (wave == 1) fixed_base_mul_wave<Fq>(ft_alpha1, s, sh1[1], lane, &res[1]);
-    else if (wave == 2) fixed_base_mul_wave<Fq>(ft_beta1, r, sh1[2], lane, &res[2]);
-    else if (wave == 3) fixed_base_mul_wave<Fq>(ft_delta1, rsp, sh1[3], lane, &res[3]);
-    else fixed_base_mul_wave<Fq2>(ft_delta2, s, sh2, lane, &out->s_delta2);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out->r_delta = res[0];
-        out->fixed_c = jac_add_ni(jac_add_ni(res[1], res[2]), res[3]);
-    }
-}
+// batch form: workgroup j assembles proof j from blob j of the partial sums
 __global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre,
                                                         const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proofs) {
-    const MsmResults* ms = reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES);
-    pre += blockIdx.x;
-    uint8_t* proof = proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES;
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x & 63) return;
-    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
-    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
+    assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, alpha1, beta2,
+                  proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES);
 }
 
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
@@ -250,6 +237,14 @@ struct ProveState {
     ~ProveState() { if (comb_h_proof) (void)hipHostFree(comb_h_proof); }
 };
 
+// consecutive tickets alternate between two main streams, so that the SpMV / NTT stage of one proof does not queue
+// behind the (contended, ~25 kernel) stage of the previous one; every helper launches on ctx->stream
+struct StreamSwap {
+    zk_ctx* c; hipStream_t saved;
+    StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
+};
+
 static ProveState& prove_state(zk_ctx* ctx) {
     if (!ctx->prove_state) ctx->prove_state = std::make_shared<ProveState>();
     return *ctx->prove_state;
@@ -341,11 +336,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     const size_t a_len = std::min(m_in, m);   // zip(weights) truncates (mod.rs:233-253)
     // consecutive proofs alternate between two main streams, so that the SpMV / NTT stage of proof k+1 does not
     // queue behind the (contended, ~25 kernel) stage of proof k; every helper launches on ctx->stream
-    struct StreamSwap {
-        zk_ctx* c; hipStream_t saved;
-        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
-        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
-    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
+    StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.batch = 0;
@@ -497,11 +488,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     crs_ensure_tables(ctx, crs, true, q.log_n);
-    struct StreamSwap {
-        zk_ctx* c; hipStream_t saved;
-        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
-        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
-    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
+    StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.batch = 0;
@@ -577,11 +564,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         ZK_REQUIRE(d_weights[j], ZK_ERR_ARG, "prove: null witness");
         S.h_b_rs[2 * j] = rc; S.h_b_rs[2 * j + 1] = sc;
     }
-    struct StreamSwap {
-        zk_ctx* c; hipStream_t saved;
-        StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
-        ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
-    } swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
+    StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.partial = false;
