@@ -176,7 +176,11 @@ struct AssembleScratch {
 // Several slots let zk_prove_submit enqueue proof k+1 (its sorting / NTT stage / first accumulation)
 // while the latency-bound tail of proof k (reductions, assembly, copy-out) is still running.
 struct ProveSlot {
-    DevBuf<Fr> a_mont, ue, ve, x0, y0, ug, vg, uc_can, vc_can, hb_can, wc, prod_a, prod_b, div_work;
+    DevBuf<Fr> a_mont, ue, ve, uc_can, vc_can, hb_can, wc, prod_a, prod_b, div_work;
+    // roots-of-unity form: pairs of vectors that are transformed together sit back to back (one batched NTT launch per
+    // pass for both): uv = V | U evaluations / coefficients, uvg = V | U on the coset, xy = U.V on <w> | on g<w>; each half
+    // holds `count` vectors of n elements (count = 1 outside batches)
+    DevBuf<Fr> uv, uvg, xy;
     MsmWorkspace ws[zk_ctx::MSM_STREAMS];
     DevBuf<MsmResults> ms;
     DevBuf<AssembleScratch> as;
@@ -280,27 +284,24 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     const size_t n = q.n, l = q.input;
     NttTables* tabs = &tabs_ref;
     hipStream_t st = ctx->stream;
+    Fr *ve = S.uv.p, *ue = S.uv.p + n, *x0 = S.xy.p, *y0 = S.xy.p + n, *vg = S.uvg.p, *ug = S.uvg.p + n;
     launch(1, -1, d_weights + l + 1, n_l);
-    spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.ue.p);
-    spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.ve.p);
-    fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n);                 // U.V on <w>
-    ntt_dif(ctx, S.ve.p, q.log_n, true, true);                        // V coefficients (bit-reversed order)
-    fr_from_mont(ctx, S.ve.p, vc_can, n);
+    spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
+    spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
+    fr_pointwise_mul(ctx, ue, ve, x0, n);                             // U.V on <w>
+    ntt_dif(ctx, S.uv.p, q.log_n, true, true, 2);                     // V, U coefficients (bit-reversed order), one launch per pass
+    fr_from_mont(ctx, ve, vc_can, n);
     launch(0, 1, vc_can, n);
-    ntt_dif(ctx, S.ue.p, q.log_n, true, true);                        // U coefficients
-    fr_from_mont(ctx, S.ue.p, uc_can, n);
+    fr_from_mont(ctx, ue, uc_can, n);
     launch(2, 0, uc_can, n);
     // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-    fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, hb_can + n, n);
-    ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p);   // U on g<w>
-    ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p);
-    fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n);                 // U.V on g<w>
-    ntt_dif(ctx, S.x0.p, q.log_n, true, true);                        // lo + hi
-    ntt_dif(ctx, S.y0.p, q.log_n, true, true);                        // (lo - hi)_i * g^i
+    fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + n, n);
+    ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w>
+    fr_pointwise_mul(ctx, ug, vg, y0, n);                             // U.V on g<w>
+    ntt_dif(ctx, S.xy.p, q.log_n, true, true, 2);                     // lo + hi | (lo - hi)_i * g^i
     Fr half = host_fr_from_u64(2).inv();
-    h_combine(ctx, S.x0.p, S.y0.p, tabs->coset_inv_brev_half.p, half, hb_can, n);
+    h_combine(ctx, x0, y0, tabs->coset_inv_brev_half.p, half, hb_can, n);
     // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
     launch(4, 2, hb_can, 2 * n);
 }
@@ -378,7 +379,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     if (!q.dense) {
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
-        S.ue.ensure(n); S.ve.ensure(n); S.x0.ensure(n); S.y0.ensure(n); S.ug.ensure(n); S.vg.ensure(n);
+        S.uv.ensure(2 * n); S.uvg.ensure(2 * n); S.xy.ensure(2 * n);
         Fr *vc_can, *uc_can, *hb_can;
         if (xout) {
             // exchange layout: `world` equal chunks per product, zero scalars behind the last point
@@ -609,36 +610,33 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ntt_ensure_coset_tables(ctx, *tabs);
     // the stage of sparse_scalar_stage with a batch dimension: scratch vectors are [count][n], the element-wise kernels and
     // the six transforms cover all proofs in one launch each; what depends on a proof's own witness or (r, s) (conversion,
-    // SpMV, r v + s u, h) is launched per proof: 5 count + 22 launches instead of 26 count
+    // SpMV, r v + s u, h) is launched per proof: 5 count + 13 launches instead of 17 count
     const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
-    S.ue.ensure(n * cnt); S.ve.ensure(n * cnt); S.x0.ensure(n * cnt); S.y0.ensure(n * cnt); S.ug.ensure(n * cnt); S.vg.ensure(n * cnt);
+    S.uv.ensure(2 * n * cnt); S.uvg.ensure(2 * n * cnt); S.xy.ensure(2 * n * cnt);
     S.a_mont.ensure(amax * cnt);
+    Fr *ve = S.uv.p, *ue = S.uv.p + n * cnt, *x0 = S.xy.p, *y0 = S.xy.p + n * cnt, *vg = S.uvg.p, *ug = S.uvg.p + n * cnt;
     for (size_t j = 0; j < cnt; ++j) {
         Fr* a_mont = S.a_mont.p + j * amax;
         fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
-        spmv(ctx, q.u_gate, a_mont, a_len[j], S.ue.p + j * n);
-        spmv(ctx, q.v_gate, a_mont, a_len[j], S.ve.p + j * n);
+        spmv(ctx, q.u_gate, a_mont, a_len[j], ue + j * n);
+        spmv(ctx, q.v_gate, a_mont, a_len[j], ve + j * n);
     }
-    fr_pointwise_mul(ctx, S.ue.p, S.ve.p, S.x0.p, n * cnt);                 // U.V on <w>
-    ntt_dif(ctx, S.ve.p, q.log_n, true, true, cnt);                         // V coefficients (bit-reversed order)
-    fr_from_mont(ctx, S.ve.p, S.bx_v.p, n * cnt);
+    fr_pointwise_mul(ctx, ue, ve, x0, n * cnt);                             // U.V on <w>
+    ntt_dif(ctx, S.uv.p, q.log_n, true, true, 2 * cnt);                     // V, U coefficients (bit-reversed order)
+    fr_from_mont(ctx, ve, S.bx_v.p, n * cnt);
     launch(0, 1, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
-    ntt_dif(ctx, S.ue.p, q.log_n, true, true, cnt);                         // U coefficients
-    fr_from_mont(ctx, S.ue.p, S.bx_u.p, n * cnt);
+    fr_from_mont(ctx, ue, S.bx_u.p, n * cnt);
     launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
     for (size_t j = 0; j < cnt; ++j)
-        fr_lincomb_to_canonical(ctx, S.ve.p + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), S.ue.p + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+        fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
                                 S.bx_h.p + j * 2 * n + n, n);
-    ZK_HIP(hipMemcpyAsync(S.ug.p, S.ue.p, n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ZK_HIP(hipMemcpyAsync(S.vg.p, S.ve.p, n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ntt_dit(ctx, S.ug.p, q.log_n, false, false, tabs->coset_fwd_brev.p, cnt);   // U on g<w>
-    ntt_dit(ctx, S.vg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, cnt);
-    fr_pointwise_mul(ctx, S.ug.p, S.vg.p, S.y0.p, n * cnt);                 // U.V on g<w>
-    ntt_dif(ctx, S.x0.p, q.log_n, true, true, cnt);                         // lo + hi
-    ntt_dif(ctx, S.y0.p, q.log_n, true, true, cnt);                         // (lo - hi)_i * g^i
+    ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2 * cnt);   // V, U on g<w>
+    fr_pointwise_mul(ctx, ug, vg, y0, n * cnt);                             // U.V on g<w>
+    ntt_dif(ctx, S.xy.p, q.log_n, true, true, 2 * cnt);                     // lo + hi | (lo - hi)_i * g^i
     const Fr half = host_fr_from_u64(2).inv();
     for (size_t j = 0; j < cnt; ++j)
-        h_combine(ctx, S.x0.p + j * n, S.y0.p + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
+        h_combine(ctx, x0 + j * n, y0 + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
     launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n, &ms->hb);
 
     hipStream_t fin = ctx->finish;
