@@ -308,6 +308,11 @@ def main():
         if int(flag.item()):
             state["degraded"] = err or "another rank failed in the warm-up of --mode %s" % args.mode
             torch.cuda.synchronize()
+            for t in range(zk.MAX_IN_FLIGHT):   # tickets the failed protocol left in flight
+                try:
+                    ctx.prove_wait(t, partial=True)
+                except zk.ZkError:
+                    pass
             for p in run(args.warmup):
                 proof = p
     ctx.set_option("profile", 1)
