@@ -254,6 +254,8 @@ def main():
         local = local or state["degraded"] is not None
         shard = shard_mode and not local
         if exchange and not local:
+            if os.environ.get("ZK_BENCH_TEST_FAIL_EXCHANGE"):   # tests/test_gpu_bench.py: exercises the fallback below
+                raise RuntimeError("injected failure of the exchange protocol")
             return list(prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k))   # k rounds = k * world proofs
         if shard and depth == 1:
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]

@@ -43,3 +43,16 @@ def test_bench_line_two_ranks_on_one_gpu(mode, shard):
     assert KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if mode == "shard" else "weak") and d["value"] > 0
     assert d["replicas"]["value"] > 0 and d["replicas"]["scaling"] == "weak"
+
+
+def test_bench_falls_back_to_independent_provers():
+    """A sharded protocol that fails in the warm-up (injected on both ranks) degrades to replicas and says so."""
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--log-n", "10", "--backend", "gloo"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, ZK_BENCH_TEST_FAIL_EXCHANGE="1"))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    d = last_json_line(res.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "injected failure" in d["degraded"] and d["config"]["parallelism"] == "replicas x2" and "replicas" not in d
