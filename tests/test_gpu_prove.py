@@ -284,6 +284,37 @@ def test_prove_batch(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], wits[0], rs[0], ss[0]) == want[0]
 
 
+def test_scalar_exchange_full_size_2_20(ctx, orc):
+    """BASELINE size: one round of the 8-rank scalar exchange played on one device (rank g = chunk g of every array,
+    two proofs per round so that the grouped inner products run) == the closed-form trapdoor proof == zk_prove."""
+    torch = pytest.importorskip("torch")
+    log_n, world = 20, 8
+    inst = chain_instance(ctx, log_n, 2020)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    want = [orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"]),
+            orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["s"], inst["r"])]
+    dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
+    assert ctx.prove_dev(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"]) == want[0]
+    elems = ctx.prove_exchange_elems(inst["qap"], world)
+    rs = [(inst["r"], inst["s"]), (inst["s"], inst["r"])]
+    send = [[torch.zeros(32 * e, dtype=torch.uint8, device="cuda") for e in elems] for _ in rs]
+    torch.cuda.synchronize()
+    for j, (r, s) in enumerate(rs):
+        ctx.prove_wait(ctx.prove_scalars_submit(crs, inst["qap"], dw.data_ptr(), inst["m"], r, s, world, [x.data_ptr() for x in send[j]]), partial=True)
+    blobs = [[None] * world for _ in rs]
+    for g in range(world):
+        recv = [torch.cat([send[j][k][g * (32 * e // world):(g + 1) * (32 * e // world)] for j in range(2)]) for k, e in enumerate(elems)]
+        part = torch.zeros(2 * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.prove_wait(ctx.prove_msm_submit(crs, inst["qap"], 2, g, world, [x.data_ptr() for x in recv], part.data_ptr()), partial=True)
+        for j in range(2):
+            blobs[j][g] = part[j * zk.PARTIAL_BYTES:(j + 1) * zk.PARTIAL_BYTES].clone()
+    for j, (r, s) in enumerate(rs):
+        gathered = torch.cat(blobs[j])
+        torch.cuda.synchronize()
+        assert ctx.prove_combine(crs, gathered.data_ptr(), world, r, s) == want[j], j
+
+
 @pytest.mark.parametrize("window_bits", [4, 7, 12, 18])
 def test_prove_batch_window_sizes(orc, window_bits):
     """Grouped inner products (batches) with forced Pippenger windows from 4 to 18 bits: 2^3 .. 2^17 buckets per group,
