@@ -380,16 +380,20 @@ def main():
                         "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
                         "note": "integer-ALU-bound kernel (254-bit modular multiply); HBM fraction is low by construction, see DESIGN.md"}
             # the bound that actually binds: VALU issue.  Algorithmic bytes per addition = 4 B index + 64 B point + the lane's
-            # share of its 160 B parked image (G1); 2650 = VALU instructions of one mixed addition in this build's ISA
-            # (DESIGN.md 4c); 39.3e12 = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
+            # share of its 160 B parked image (G1).  2242 wave-instructions per addition is the SQ_INSTS_VALU counter of this
+            # kernel divided by its additions (profiles/r1_pmc_valu.txt); 85 % of them are 64-bit / multiply class
+            # (v_mad_u64_u32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64), which tools/ubench_valu.hip measures at 483 G
+            # wave-instructions/s on the whole chip, the rest 32-bit class at 832 G/s: blended issue peak 515 G/s.
             if name == "msm_accumulate_g1":
                 adds = bytes_per_launch / (4.0 + 64.0 + 160.0 / 32.0)
                 rate = adds / (avg_ms * 1e-3)
+                winst, peak = 2242.0, 1.0 / (0.85 / 483.0 + 0.15 / 832.0)
                 roofline["alu"] = {"additions_per_launch": round(adds), "G_additions_per_s": round(rate / 1e9, 2),
-                                   "valu_instr_per_addition": 2650, "valu_issue_peak_T_per_s": 39.3,
-                                   "valu_issue_frac": round(rate * 2650 / 39.3e12, 3),
+                                   "valu_wave_instr_per_addition": winst, "G_wave_instr_per_s": round(rate / 64.0 * winst / 1e9, 1),
+                                   "valu_issue_peak_G_wave_instr_per_s": round(peak, 1),
+                                   "valu_issue_frac": round(rate / 64.0 * winst / 1e9 / peak, 3),
                                    "note": "measured while sort / NTT / merge kernels of neighbouring products share the SIMDs; "
-                                           "stand-alone (--serialize --depth 1) the same kernel reaches 0.92"}
+                                           "stand-alone (--serialize --depth 1) the same kernel reaches 0.93"}
         n = inst["n"]
         out = {
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
