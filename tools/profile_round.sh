@@ -5,6 +5,8 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
+# the bench line first: after a minute of continuous profiling the GPU clocks sag by ~4 %
+cd $REPO && python bench.py --steps 30 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 12 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $CMD > $OUT/prof_stats.log 2>&1
@@ -17,10 +19,5 @@ find $OUT/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv
 # the raw per-dispatch traces are large; keep only the summaries
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
 find $OUT/prof_stats -name "*kernel_trace.csv" -delete
-python bench.py --steps 30 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
-tail -c 600 $OUT/bench_line.json
-# multi-GPU protocols timed as rank 0's share on this one GPU (local copies in place of the collectives).  Run this block in a
-# gpurun call of its own: after the ~70 s of continuous profiling above the GPU clocks sag and the rounds come out 5 % slower.
-python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'same_box_single_gpu_proofs_per_s': d['value'], 'ms_per_proof': d['ms_per_step']}))" > $OUT/emulation.jsonl
-for W in 2 4 8; do python bench.py --no-cpu-baseline --steps 16 --warmup 4 --emulate-world $W --mode exchange 2>/dev/null | tail -1 >> $OUT/emulation.jsonl; done
-for W in 2 4 8; do python bench.py --no-cpu-baseline --steps 32 --warmup 8 --emulate-world $W --mode shard 2>/dev/null | tail -1 >> $OUT/emulation.jsonl; done
+# the multi-GPU emulation block lives in tools/profile_emulation.sh: run it in a gpurun call of its own (after the ~70 s of
+# continuous profiling above the GPU clocks sag and the rounds come out 5 % slower)
