@@ -30,6 +30,12 @@ extern "C" {
     fn zk_prove(ctx: *mut ZkCtx, crs: *const ZkCrs, qap: *const ZkQap, weights: *const u64, m: usize,
                 r: *const u64, s: *const u64, proof_out: *mut u8) -> c_int;
     fn zk_last_error(ctx: *const ZkCtx) -> *const std::os::raw::c_char;
+    // a stream of proofs: witnesses in page-locked host memory, two tickets in flight (zkgpu.h)
+    fn zk_host_alloc(bytes: usize, out: *mut *mut std::os::raw::c_void) -> c_int;
+    fn zk_host_free(p: *mut std::os::raw::c_void);
+    fn zk_prove_submit_host(ctx: *mut ZkCtx, crs: *const ZkCrs, qap: *const ZkQap, weights: *const u64, m: usize,
+                            r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
+    fn zk_prove_wait(ctx: *mut ZkCtx, ticket: c_int, proof_out: *mut u8) -> c_int;
 }
 
 fn check(ctx: *mut ZkCtx, rc: c_int) {
@@ -84,6 +90,43 @@ impl GpuProver {
         unsafe { check(self.ctx, zk_prove(self.ctx, self.crs, self.qap, w.as_ptr(), weights.len(),
                                           fr_to_words(&r).as_ptr(), fr_to_words(&s).as_ptr(), bytes.as_mut_ptr())); }
         Proof { a: g1_from_bytes(&bytes[0..65]), b: g2_from_bytes(&bytes[65..194]), c: g1_from_bytes(&bytes[194..259]) }
+    }
+}
+impl GpuProver {
+    /// Many proofs over one circuit: the 32 m-byte transfer of witness k+1 overlaps the inner products of proof k
+    /// (zk_prove_submit_host / zk_prove_wait with two tickets in flight and page-locked staging buffers).
+    pub fn prove_stream<'a, I>(&self, jobs: I) -> Vec<Proof<G1Local, G2Local>>
+    where I: IntoIterator<Item = (&'a [FrLocal], FrLocal, FrLocal)> {
+        let mut out = Vec::new();
+        let mut inflight: std::collections::VecDeque<(c_int, usize)> = Default::default();
+        let mut staging: [*mut std::os::raw::c_void; 2] = [std::ptr::null_mut(); 2];
+        let mut cap = [0usize; 2];
+        let mut finish = |t: c_int, out: &mut Vec<Proof<G1Local, G2Local>>| {
+            let mut bytes = [0u8; 259];
+            unsafe { check(self.ctx, zk_prove_wait(self.ctx, t, bytes.as_mut_ptr())); }
+            out.push(Proof { a: g1_from_bytes(&bytes[0..65]), b: g2_from_bytes(&bytes[65..194]), c: g1_from_bytes(&bytes[194..259]) });
+        };
+        for (k, (weights, r, s)) in jobs.into_iter().enumerate() {
+            if inflight.len() == 2 { let (t, _) = inflight.pop_front().unwrap(); finish(t, &mut out); }
+            let slot = k % 2;            // the buffer of the proof waited for two submissions ago
+            let need = weights.len() * 32;
+            unsafe {
+                if cap[slot] < need {
+                    if !staging[slot].is_null() { zk_host_free(staging[slot]); }
+                    assert_eq!(zk_host_alloc(need, &mut staging[slot]), 0);
+                    cap[slot] = need;
+                }
+                let dst = std::slice::from_raw_parts_mut(staging[slot] as *mut u64, weights.len() * 4);
+                for (i, c) in weights.iter().enumerate() { dst[4 * i..4 * i + 4].copy_from_slice(&fr_to_words(c)); }
+                let mut t: c_int = -1;
+                check(self.ctx, zk_prove_submit_host(self.ctx, self.crs, self.qap, staging[slot] as *const u64, weights.len(),
+                                                     fr_to_words(&r).as_ptr(), fr_to_words(&s).as_ptr(), &mut t));
+                inflight.push_back((t, slot));
+            }
+        }
+        while let Some((t, _)) = inflight.pop_front() { finish(t, &mut out); }
+        unsafe { for p in staging.iter() { if !p.is_null() { zk_host_free(*p); } } }
+        out
     }
 }
 impl Drop for GpuProver {
