@@ -57,7 +57,7 @@ struct MsmTable {
     int c = 0, windows = 0;
 };
 struct MsmWorkspace {
-    DevBuf<uint32_t> hist, total, bin_start, bin_cnt, start, sorted, heavy;
+    DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy;
     DevBuf<uint64_t> records;
     DevBuf<uint8_t> partial, bucket_sums, seg_sums;
 };

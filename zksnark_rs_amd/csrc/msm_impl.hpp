@@ -268,19 +268,42 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
 
 // level 2: counting sort by sub-bucket inside every bin, `parts` workgroups per bin (a bin that holds a
 // heavy bucket can be a large share of all records), positions by a per-bin prefix over (sub-bucket, part)
-__device__ __forceinline__ void bin_slice(const uint32_t* bin_start, int parts, uint32_t& lo, uint32_t& hi) {
-    const int bin = blockIdx.x / parts, part = blockIdx.x % parts;
-    const uint32_t s = bin_start[bin], len = bin_start[bin + 1] - s;
+// Level-2 workgroups are dealt to the bins in proportion to their record counts (part_start[b] = first workgroup of bin b): a
+// top window of few bits puts ALL its digits into bin 0, a boolean-heavy witness puts them into one bucket; with the same number of
+// workgroups for every bin such a bin serialised level 2.  Returns false for surplus workgroups of the (upper-bound) grid.
+__device__ __forceinline__ bool bin_slice(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ part_start, int bins, uint32_t& lo, uint32_t& hi) {
+    const uint32_t g = blockIdx.x;
+    if (g >= part_start[bins]) return false;
+    int l = 0, h = bins;   // part_start[l] <= g < part_start[h]
+    while (h - l > 1) {
+        const int mid = (l + h) >> 1;
+        if (part_start[mid] <= g) l = mid; else h = mid;
+    }
+    const uint32_t parts = part_start[l + 1] - part_start[l], part = g - part_start[l];
+    const uint32_t s = bin_start[l], len = bin_start[l + 1] - s;
     lo = s + (uint32_t)((uint64_t)len * part / parts);
     hi = s + (uint32_t)((uint64_t)len * (part + 1) / parts);
+    return true;
 }
 
-__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
-                                                                uint32_t* __restrict__ cnt) {
+// part_start[b] = exclusive scan of ceil(len_b / target) (at least one workgroup per bin); one workgroup
+__global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restrict__ bin_start, int bins, uint32_t target, uint32_t* __restrict__ part_start) {
+    __shared__ uint32_t scratch[1024];
+    for (int b = threadIdx.x; b < bins; b += 1024) {
+        const uint32_t len = bin_start[b + 1] - bin_start[b];
+        part_start[b] = max(1u, (len + target - 1) / target);
+    }
+    __syncthreads();
+    const uint32_t total = block_exclusive_scan<1024>(part_start, part_start, bins, scratch);
+    if (threadIdx.x == 0) part_start[bins] = total;
+}
+
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                const uint32_t* __restrict__ part_start, int bins, int sub_bits, uint32_t* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int subs = 1 << sub_bits;
     uint32_t lo, hi;
-    bin_slice(bin_start, parts, lo, hi);
+    if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
     for (int b = threadIdx.x; b < subs; b += SORT2_THREADS) lds[b] = 0;
     __syncthreads();
     // four records in flight per lane: a bin holding a heavy bucket makes this loop long and latency-bound
@@ -298,12 +321,13 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* 
 }
 
 // one workgroup per bin: cnt[bin][part][sub] -> first position of that (part, sub); start[bucket]
-__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_start, int bins, int parts, int sub_bits,
-                                                                   uint32_t* __restrict__ start) {
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ part_start,
+                                                                   int bins, int sub_bits, uint32_t* __restrict__ start) {
     __shared__ uint32_t part_sum[SORT2_THREADS];
     const int subs = 1 << sub_bits;
     const int bin = blockIdx.x;
-    uint32_t* rows = cnt + (size_t)bin * parts * subs;
+    const int parts = (int)(part_start[bin + 1] - part_start[bin]);
+    uint32_t* rows = cnt + (size_t)part_start[bin] * subs;
     const int per = (subs + SORT2_THREADS - 1) / SORT2_THREADS;
     const int lo = min((int)threadIdx.x * per, subs), hi = min(lo + per, subs);
     uint32_t sum = 0;
@@ -334,7 +358,8 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
 constexpr int BINS_THREADS = 512;
 constexpr int BIN_STAGE = 8192;
 constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start, int parts, int sub_bits,
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                  const uint32_t* __restrict__ part_start, int bins, int sub_bits,
                                                                   const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t scratch[BINS_THREADS];
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
     uint32_t* lstart = cnt + subs;
     uint32_t* pos = lstart + subs;     // running write position per sub-bucket for this (bin, part)
     uint32_t lo, hi;
-    bin_slice(bin_start, parts, lo, hi);
+    if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
     const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
     for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] = row[b];
     for (uint32_t base = lo; base < hi; base += BIN_STAGE) {
@@ -390,9 +415,10 @@ __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
 constexpr int BINS_THREADS = 512;
 constexpr int BIN_STAGE = 8192;
-__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, int, int, uint32_t*);
-__global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, int, int, int, uint32_t*);
-__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
+__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
 // ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
@@ -639,13 +665,17 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     {
         ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
-        // workgroups per bin: ~2048 level-2 workgroups in all (a grouped product has `groups` times the bins, each with 1 / groups of the records)
-        const int subs = 1 << sub_bits, parts = std::max(1, std::min(8, 2048 / subs) / groups);
-        ws.bin_cnt.ensure((size_t)bins * parts * subs);
-        hipLaunchKernelGGL(k_msm_bin_hist, dim3(bins * parts), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, parts, sub_bits, ws.bin_cnt.p);
-        hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, bins, parts, sub_bits, ws.start.p);
-        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(bins * parts), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, parts, sub_bits,
-                           ws.bin_cnt.p, ws.sorted.p);
+        // ~2048 level-2 workgroups in all, dealt to the bins in proportion to their records (at least BIN_STAGE records each)
+        const int subs = 1 << sub_bits;
+        const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries + 2047) / 2048);
+        const unsigned grid2 = (unsigned)(entries / target + 1) + (unsigned)bins;   // >= sum_b max(1, ceil(len_b / target))
+        ws.bin_cnt.ensure((size_t)grid2 * subs);
+        ws.part_start.ensure((size_t)bins + 1);
+        hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
+        hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
+        hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
+        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
+                           sub_bits, ws.bin_cnt.p, ws.sorted.p);
     }
     {
         // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
