@@ -692,7 +692,9 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         // heavy buckets are outliers when the average bucket spans few lanes (a small grid that mostly finds nothing
         // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
-        const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 16u;
+        // (a narrow top window makes 2^(top bits) buckets heavy at once -- 64..128 at c = 19 -- so the small grid is not THAT small:
+        // surplus workgroups read the count and leave)
+        const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
         hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
         hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, bpg, d_seg);
         // per group: one workgroup while each lane has at most ~16 additions, otherwise two levels
