@@ -217,11 +217,12 @@ int zk_prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out /* ZK_PROOF_BYTES;
  * the copy.  The buffer must stay valid and unmodified until the matching zk_prove_wait. */
 int zk_prove_submit_host(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
                          const uint64_t r[4], const uint64_t s[4], int* ticket);
-int zk_host_alloc(size_t bytes, void** out);   /* page-locked host memory (hipHostMalloc) */
+int zk_host_alloc(size_t bytes, void** out);   /* page-locked host memory (hipHostMalloc); no counterpart in the reference, whose
+                                                * weights live in a Vec<FrLocal> (lib.rs:107) */
 void zk_host_free(void* p);
 
-/* Batches (roots-of-unity QAP form): `count` proofs over the same CRS / QAP with their own witnesses and (r, s) as one
- * unit of work -- the SpMV / NTT stages follow each other, the inner products of all proofs run as one grouped MSM per
+/* Batches (roots-of-unity QAP form): what `count` calls of groth16::prove (groth16/mod.rs:213-296) over the same QAP and
+ * CRS compute -- `count` proofs with their own witnesses and (r, s) -- as one unit of work -- the SpMV / NTT stages follow each other, the inner products of all proofs run as one grouped MSM per
  * product, two launches assemble them.  For circuits of 2^16 gates and fewer a single proof is bound by the latency
  * of its ~100 dependent launches; a batch spreads that chain over `count` proofs (2^16 gates: 2.6 ms per proof alone).
  * d_weights[j]: device pointer to proof j's witness (m[j] x 4 words, canonical); r, s: count x 4 words;
