@@ -91,6 +91,19 @@ int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
  * FrLocal Add/Sub/Mul/Div: fr.rs:18-71 */
 int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* The lazy radix-2^29 form of the same field arithmetic (what `Fr * Fr`, fr.rs:44-48, and bn's Fq multiply become inside
+ * the bucket accumulation and the NTT tiles: csrc/lazy29.cuh, csrc/ntt.hip) on caller-supplied limb patterns, so that the
+ * bounds the kernels rely on can be tested at their extremes.  Every operand is 9 signed 32-bit limbs per element, value =
+ * sum v[k] 2^(29 k) (not reduced).  field: 0 = Fr, 1 = Fq.  out: canonical residues (4 words each) of the result;
+ * raw_out (may be null): the result's 9 limbs before the final reduction.
+ *   ZK_LAZY_MONT       a b 2^-261          (|a limbs| <= 2^30, |b limbs| < 2^29)
+ *   ZK_LAZY_SQR        a a 2^-261          (|limbs| < 2^29)
+ *   ZK_LAZY_MONT_DIFF  (a b - c d) 2^-261  (all |limbs| < 2^29)
+ *   ZK_LAZY_NORM       a after carry propagation; ZK_LAZY_STORE  a itself        (|value| < 8 p)
+ *   ZK_LAZY_FR_REDUCE  fr_reduce(a) of the NTT tiles (|value| < 2^9 r); ZK_LAZY_FR_STORE  fr_store_exact(a)   (Fr only) */
+enum { ZK_LAZY_MONT = 0, ZK_LAZY_SQR = 1, ZK_LAZY_MONT_DIFF = 2, ZK_LAZY_NORM = 3, ZK_LAZY_STORE = 4, ZK_LAZY_FR_REDUCE = 5, ZK_LAZY_FR_STORE = 6 };
+int zk_lazy29_batch(zk_ctx* ctx, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n,
+                    uint64_t* out, int32_t* raw_out);
 /* out[i] = scalars[i] * points[i]  (exp_encrypted_g1 / exp_encrypted_g2, fr.rs:114-119) */
 int zk_g1_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
 int zk_g2_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
@@ -270,12 +283,15 @@ int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int s
  * verify  (groth16::verify, groth16/mod.rs:299-320) -- host code, as in the reference
  * ---------------------------------------------------------------------------------------- */
 /* *ok = 1 iff e(alpha,beta) e(sum_i x_i sum_gamma_i, gamma) e(C,delta) == e(A,B) with x = (1, inputs...).
- * inputs: n_inputs Fr values (the `verify` wires, without the leading 1).  A malformed or off-curve
- * proof gives *ok = 0. */
+ * inputs: n_inputs Fr values (the `verify` wires, without the leading 1).  A malformed proof gives *ok = 0: the
+ * decoder accepts exactly one byte string per point (tag 0x00 followed by zeros only = infinity; tag 0x04 + coordinates
+ * < q on the curve, never (0, 0)) and B must lie in the order-r subgroup G2 of the twist ([r]B = infinity is checked:
+ * the twist's cofactor has small factors and the pairing is bilinear only on G2). */
 int zk_verify(zk_ctx* ctx, const zk_crs* crs, const uint64_t* inputs, size_t n_inputs, const uint8_t proof[ZK_PROOF_BYTES], int* ok);
 /* EllipticEncryptable::pairing (fr.rs:120-122): the optimal ate pairing e(P, Q) as 12 Fq coefficients
  * (48 words) in the order c0.a0.c0, c0.a0.c1, c0.a1.c0, ..., c1.a2.c1 of the tower
- * Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (9+i)).  Host only; needs no context. */
+ * Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (9+i)).  Host only; needs no context.  ZK_ERR_RANGE when a coordinate
+ * is >= q, a point is off its curve or g2 is outside the order-r subgroup. */
 int zk_pairing(const uint64_t g1[ZK_G1_WORDS], const uint64_t g2[ZK_G2_WORDS], uint64_t out[48]);
 
 /* ------------------------------------------------------------------------------------------

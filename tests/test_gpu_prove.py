@@ -426,8 +426,25 @@ def test_crs_file_round_trip(ctx, orc, tmp_path):
         h = ((h ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
     big[32:40] = h.to_bytes(8, "little")
     refused(bytes(big), RANGE)
+    # a point that is in range but NOT on the curve (x + 1 of xi_g1[0], checksum recomputed): refused as well -- an
+    # off-curve base would leak witness scalars through the inner products; the FNV checksum only detects
+    # corruption, not tampering
+    off = bytearray(raw); off[40 + 64 * 3] ^= 1
+    h = 0xcbf29ce484222325
+    for byte in off[40:]:
+        h = ((h ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    off[32:40] = h.to_bytes(8, "little")
+    refused(bytes(off), RANGE)
     with pytest.raises(zk.ZkError):
         ctx.crs_load(tmp_path / "does-not-exist.zkcrs")
+    # the same through zk_crs_upload: every array is checked (G1 and the twist)
+    arrs = ctx.crs_download(crs)
+    for key in ("xi_g1", "sum_delta_g1", "xi_t_g1", "xi_g2", "delta_g2"):
+        bad = {k: (None if v is None else np.array(v, copy=True)) for k, v in arrs.items()}
+        bad[key].reshape(-1)[0] ^= np.uint64(1)
+        with pytest.raises(zk.ZkError) as e:
+            ctx.crs_upload(n, m, l, bad)
+        assert e.value.status == RANGE, (key, e.value.status)
 
 
 def test_pipelined_submit_wait(ctx, orc):

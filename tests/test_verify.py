@@ -46,6 +46,98 @@ def test_pairing_bilinear_and_degenerate():
         zk.pairing(ints_to_limbs([1, 3]).reshape(8), g2_words(pyref.G2_GEN))      # (1,3) is not on the curve
 
 
+def _fq_sqrt(a):
+    import pyref
+    s = pow(a, (pyref.Q + 1) // 4, pyref.Q)
+    return s if s * s % pyref.Q == a % pyref.Q else None
+
+
+def _fq2_sqrt(a):
+    """square root in Fq[i]/(i^2+1) by the norm method (q = 3 mod 4); None for non-residues"""
+    import pyref
+    q = pyref.Q
+    if a[1] == 0:
+        s = _fq_sqrt(a[0])
+        if s is not None:
+            return (s, 0)
+        s = _fq_sqrt(-a[0] % q)
+        return None if s is None else (0, s)
+    n = _fq_sqrt((a[0] * a[0] + a[1] * a[1]) % q)
+    if n is None:
+        return None
+    inv2 = pow(2, q - 2, q)
+    for sg in (n, -n):
+        x0 = _fq_sqrt((a[0] + sg) * inv2 % q)
+        if x0:
+            return (x0, a[1] * pow(2 * x0, q - 2, q) % q)
+    return None
+
+
+def g2_mul_raw(P, k):
+    """k * P on the twist WITHOUT reducing k modulo r (pyref.g2_mul reduces: it is only meant for G2)"""
+    import pyref
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = pyref.g2_add(acc, acc)
+        if bit == "1":
+            acc = pyref.g2_add(acc, P)
+    return acc
+
+
+def twist_point_outside_g2(seed):
+    """a point of E'(Fq2): y^2 = x^3 + 3/(9+i) that is NOT in the order-r subgroup (the cofactor 2q - r is ~2^254, so a
+    random twist point is outside G2 except with negligible probability; checked with [r]P != infinity)"""
+    import pyref
+    rng = SplitMix64(seed)
+    while True:
+        x = (rng.fr() % pyref.Q, rng.fr() % pyref.Q)
+        y = _fq2_sqrt(pyref.fq2_add(pyref.fq2_mul(pyref.fq2_mul(x, x), x), pyref.B2))
+        if y is None:
+            continue
+        P = (x, y)
+        assert pyref.g2_on_curve(P)
+        if g2_mul_raw(P, pyref.R) is not None:
+            return P
+
+
+def test_pairing_rejects_twist_point_outside_g2():
+    """ADVICE r1 (verify.hip): the ate Miller loop is bilinear only on the r-torsion subgroup of the twist"""
+    import pyref
+    P = twist_point_outside_g2(11)
+    with pytest.raises(zk.ZkError):
+        zk.pairing(g1_words(pyref.G1_GEN), g2_words(P))
+    # the same coordinates after clearing the cofactor are accepted
+    h = 2 * pyref.Q - pyref.R
+    Pg = g2_mul_raw(P, h)
+    assert Pg is not None and g2_mul_raw(Pg, pyref.R) is None
+    assert zk.pairing(g1_words(pyref.G1_GEN), g2_words(Pg)) == pyref.fq12_flat(pyref.pairing(pyref.G1_GEN, Pg))
+
+
+@pytest.mark.gpu
+def test_verify_rejects_non_canonical_and_out_of_subgroup_proofs(ctx):
+    """The byte decoder of zk_verify is a trust boundary the reference does not have (it never deserialises proofs):
+    tag 0x00 must be followed by zeros only, tag 0x04 must not carry (0, 0), B must lie in G2."""
+    import pyref
+    from zksnark_rs_amd.circuit import Circuit
+    c = Circuit(open(os.path.join(ZK_DIR, "simple.zk")).read())
+    weights = c.weights([3, 2, 4])
+    qap = c.qap(ctx)
+    rng = SplitMix64(78)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    proof = ctx.prove(crs, qap, weights, rng.fr(), rng.fr())
+    assert ctx.verify(crs, [2, 34], proof)
+    for off, size in ((0, 65), (65, 129), (194, 65)):
+        bad = bytearray(proof); bad[off] = 0                       # infinity tag with the old coordinates behind it
+        assert not ctx.verify(crs, [2, 34], bytes(bad))
+        bad = bytearray(proof); bad[off + 1:off + size] = bytes(size - 1)   # tag 0x04 with (0, 0)
+        assert not ctx.verify(crs, [2, 34], bytes(bad))
+        bad = bytearray(proof); bad[off] = 2                       # unknown tag
+        assert not ctx.verify(crs, [2, 34], bytes(bad))
+    P = twist_point_outside_g2(5)
+    bad = proof[:65] + pyref.enc_g2(P) + proof[194:]
+    assert len(bad) == len(proof) and not ctx.verify(crs, [2, 34], bad)
+
+
 @pytest.mark.gpu
 def test_simple_circuit_test(ctx):
     """lib.rs:156-190: simple.zk, a=3 b=2 c=4 -> verify(b=2, x=34) true, verify(b=2, x=25) false."""

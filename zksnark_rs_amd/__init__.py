@@ -228,9 +228,10 @@ class Context:
         keep += [ptr, gate, val]
         return _lib.SparseRows(ptr.ctypes.data_as(_lib.u64p), gate.ctypes.data_as(_lib.u32p), val.ctypes.data_as(_lib.u64p))
 
-    def sparse_desc(self, log_n, m, input, u, v, w):
+    @staticmethod
+    def sparse_desc(log_n, m, input, u, v, w):
         keep = []
-        d = _lib.QapSparseDesc(log_n, m, input, self._rows(u, keep), self._rows(v, keep), self._rows(w, keep))
+        d = _lib.QapSparseDesc(log_n, m, input, Context._rows(u, keep), Context._rows(v, keep), Context._rows(w, keep))
         d._keep = keep
         return d
 

@@ -18,6 +18,7 @@ MAX_BATCH = 64          # ZK_MAX_BATCH
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
 u8p = C.POINTER(C.c_uint8)
 
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "zk_ntt_fr": (C.c_int, [C.c_void_p, u64p, C.c_uint, C.c_int, C.c_int]),
     "zk_msm_g1": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
     "zk_msm_g2": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
+    "zk_lazy29_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, C.c_size_t, u64p, i32p]),
     "zk_fr_batch": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
     "zk_fq_batch": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, u64p, C.c_size_t]),
     "zk_g1_mul_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),

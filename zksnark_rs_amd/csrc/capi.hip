@@ -24,6 +24,8 @@ const char* zk_strerror(int status) {
     }
 }
 
+void zk_ctx_destroy(zk_ctx* ctx);
+
 int zk_ctx_create(int device_ordinal, zk_ctx** out) {
     if (!out) return ZK_ERR_ARG;
     *out = nullptr;
@@ -52,7 +54,7 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
         }
     });
-    if (rc != ZK_OK) { delete ctx; return rc; }
+    if (rc != ZK_OK) { zk_ctx_destroy(ctx); return rc; }   // destroys whatever streams were created before the failure
     *out = ctx;
     return ZK_OK;
 }
@@ -111,6 +113,10 @@ int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
 int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out[ZK_G2_WORDS]) {
     if (!ctx) return ZK_ERR_ARG;
     return guarded(ctx, [&] { msm_host<Fq2>(ctx, points, scalars, n, window_bits, out); ctx->resolve_profile(); });
+}
+int zk_lazy29_batch(zk_ctx* ctx, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n, uint64_t* out, int32_t* raw_out) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { lazy29_batch(ctx, field, op, a, b, c, d, n, out, raw_out); });
 }
 int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     if (!ctx) return ZK_ERR_ARG;

@@ -14,6 +14,7 @@ static void up_points(zk_ctx* ctx, DevBuf<A>& d, const uint64_t* src, size_t cou
     ZK_REQUIRE(src, ZK_ERR_ARG, "zk_crs_upload: null point array");
     ZK_HIP(hipMemcpyAsync(d.p, src, count * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
     pts_to_mont<A>(ctx, d.p, d.p, count, d_flag);
+    pts_check_on_curve<A>(ctx, d.p, count, d_flag);
 }
 
 zk_crs* crs_upload(zk_ctx* ctx, const zk_crs_desc& d) {
@@ -39,7 +40,8 @@ zk_crs* crs_upload(zk_ctx* ctx, const zk_crs_desc& d) {
     int h = 0;
     ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(hipStreamSynchronize(ctx->stream));
-    ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_crs_upload: coordinate >= q");
+    ZK_REQUIRE(!(h & 2), ZK_ERR_RANGE, "zk_crs_upload: coordinate >= q");
+    ZK_REQUIRE(!(h & 4), ZK_ERR_RANGE, "zk_crs_upload: point not on the curve");
     return c.release();
 }
 

@@ -31,6 +31,9 @@ struct FrParams {
     static constexpr uint32_t R2[8] = {0x45b69bd4u, 0x38c2e14bu, 0x85883377u, 0x0ffedb18u, 0xabc6e54du, 0x7840f9f0u, 0x848b0f05u, 0x0a054a3eu};
     static constexpr uint32_t P29[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr uint32_t INV29 = 0x0fffffffu;  // -p^-1 mod 2^29
+    // k*r for k = -2..2 and 16r, 8r, 4r, 2r, r in "normal form" (see FqParams): lazy29.cuh
+    static constexpr int32_t KP29[5][9] = {{536870910, 31499968, 55031646, 274652697, 351558393, 441024126, 514997629, 55030679, -6342813}, {268435455, 15749984, 295951279, 405761804, 175779196, 488947519, 525934270, 295950795, -3171407}, {0, 0, 0, 0, 0, 0, 0, 0, 0}, {268435457, 521120927, 240919632, 131109107, 361091715, 47923392, 10936641, 240920116, 3171406}, {2, 505370943, 481839265, 262218214, 185312518, 95846785, 21873282, 481840232, 6342812}};
+    static constexpr int32_t POSP29[5][9] = {{16, 284871160, 96617743, 487132983, 408758323, 229903370, 174986257, 96625472, 50742503}, {8, 410871036, 316744327, 512001947, 204379161, 383387141, 87493128, 316748192, 25371251}, {4, 473870974, 426807619, 524436429, 370625036, 191693570, 43746564, 426809552, 12685625}, {2, 505370943, 481839265, 262218214, 185312518, 95846785, 21873282, 481840232, 6342812}, {268435457, 521120927, 240919632, 131109107, 361091715, 47923392, 10936641, 240920116, 3171406}};
 };
 struct FqParams {
     // q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -39,9 +42,10 @@ struct FqParams {
     static constexpr uint32_t R2[8] = {0x659bac10u, 0xe1a2a074u, 0x5406005au, 0x63985586u, 0x2d3e2632u, 0xff54c580u, 0x34ea65a6u, 0x2a11a68cu};
     static constexpr uint32_t P29[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr uint32_t INV29 = 0x04866389u;
-    // k*q for k = -2..2 and 8,4,2,1 in "normal form" (limbs 0..7 in [0, 2^29), signed top limb): lazy29.cuh
+    // k*q for k = -2..2 in "normal form" (limbs 0..7 in [0, 2^29), signed top limb): lazy29.cuh
     static constexpr int32_t KP29[5][9] = {{252052850, 502742674, 119191905, 441825886, 351554831, 441024126, 514997629, 55030679, -6342813}, {126026425, 519806793, 59595952, 489348399, 175777415, 488947519, 525934270, 295950795, -3171407}, {0, 0, 0, 0, 0, 0, 0, 0, 0}, {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}, {284818062, 34128237, 417679006, 95045025, 185316080, 95846785, 21873282, 481840232, 6342812}};
-    static constexpr int32_t POSP29[4][9] = {{65530424, 136512950, 60103288, 380180103, 204393408, 383387141, 87493128, 316748192, 25371251}, {32765212, 68256475, 298487100, 190090051, 370632160, 191693570, 43746564, 426809552, 12685625}, {284818062, 34128237, 417679006, 95045025, 185316080, 95846785, 21873282, 481840232, 6342812}, {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}};
+    // 16p, 8p, 4p, 2p, p in the same form (store_exact's conditional subtractions)
+    static constexpr int32_t POSP29[5][9] = {{131060848, 273025900, 120206576, 223489294, 408786817, 229903370, 174986257, 96625472, 50742503}, {65530424, 136512950, 60103288, 380180103, 204393408, 383387141, 87493128, 316748192, 25371251}, {32765212, 68256475, 298487100, 190090051, 370632160, 191693570, 43746564, 426809552, 12685625}, {284818062, 34128237, 417679006, 95045025, 185316080, 95846785, 21873282, 481840232, 6342812}, {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}};
 };
 
 template <class PR>

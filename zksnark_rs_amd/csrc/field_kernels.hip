@@ -96,6 +96,30 @@ void pts_from_mont(zk_ctx* ctx, const A* in, A* out, size_t n) {
     hipLaunchKernelGGL(k_pts_from_mont<A>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, out, n);
     ZK_HIP(hipGetLastError());
 }
+// flag |= 4 when a finite point (Montgomery form) does not satisfy y^2 = x^3 + b.  b is passed in Montgomery form:
+// 3 for G1, 3 / (9 + i) for the twist (zk_crs_upload / zk_crs_load: a CRS is not trusted to be on the curve --
+// an off-curve base would leak witness scalars through the inner products, invalid-curve style).
+template <class A, class F>
+__global__ void k_pts_on_curve(const A* __restrict__ pts, size_t n, F b, int* flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    A p = pts[i];
+    if (p.is_inf()) return;
+    if (!(p.y.sqr() == p.x.sqr() * p.x + b)) atomicOr(flag, 4);
+}
+static Fq2 twist_b() { return Fq2{Fq::from_u32(3), Fq::zero()} * Fq2{Fq::from_u32(9), Fq::from_u32(1)}.inv(); }
+template <>
+void pts_check_on_curve<G1A>(zk_ctx* ctx, const G1A* d_pts, size_t n, int* d_flag) {
+    if (!n) return;
+    hipLaunchKernelGGL((k_pts_on_curve<G1A, Fq>), dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, Fq::from_u32(3), d_flag);
+    ZK_HIP(hipGetLastError());
+}
+template <>
+void pts_check_on_curve<G2A>(zk_ctx* ctx, const G2A* d_pts, size_t n, int* d_flag) {
+    if (!n) return;
+    hipLaunchKernelGGL((k_pts_on_curve<G2A, Fq2>), dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, twist_b(), d_flag);
+    ZK_HIP(hipGetLastError());
+}
 template void pts_to_mont<G1A>(zk_ctx*, const G1A*, G1A*, size_t, int*);
 template void pts_to_mont<G2A>(zk_ctx*, const G2A*, G2A*, size_t, int*);
 template void pts_from_mont<G1A>(zk_ctx*, const G1A*, G1A*, size_t);

@@ -10,6 +10,8 @@ void fr_to_mont(zk_ctx*, const Fr* in, Fr* out, size_t n, int* d_flag);
 void fr_from_mont(zk_ctx*, const Fr* in, Fr* out, size_t n);
 template <class A> void pts_to_mont(zk_ctx*, const A* in, A* out, size_t n, int* d_flag);
 template <class A> void pts_from_mont(zk_ctx*, const A* in, A* out, size_t n);
+// *d_flag |= 4 when a finite point (Montgomery form) is not on its curve (G1: y^2 = x^3 + 3; G2: the twist)
+template <class A> void pts_check_on_curve(zk_ctx*, const A* d_pts, size_t n, int* d_flag);
 template <class F> void point_mul_batch(zk_ctx*, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
 template <class F> void point_add_batch(zk_ctx*, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
@@ -45,6 +47,7 @@ void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);
 // out[i] = base^i * scale (natural order powers)
 void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
 void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
+void lazy29_batch(zk_ctx*, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n, uint64_t* out, int32_t* raw_out);
 
 // ---- msm.hip ----
 constexpr int MSM_MAX_C = 22;   // window bits; the two-level sort keeps only 2^10 + 2^(c-11) counters in LDS
@@ -59,7 +62,7 @@ struct MsmTable {
 struct MsmWorkspace {
     DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy;
     DevBuf<uint64_t> records;
-    DevBuf<uint8_t> partial, bucket_sums, seg_sums;
+    DevBuf<uint8_t> partial, bucket_sums, fold, seg_sums;
 };
 int msm_auto_window(size_t n);
 void msm_init_attributes();

@@ -7,7 +7,7 @@
 // all temporaries stay in the multiplier's own radix instead:
 //
 //   FpR : 9 signed 32-bit limbs, value = sum v[i] 2^(29 i), a residue mod p (NOT reduced).
-//         "normal form" (N): v[0..7] in [0, 2^29), v[8] small and signed; |value| < 8p.
+//         "normal form" (N): v[0..7] in [0, 2^29), v[8] small and signed; |value| < 16p.
 //   add / sub are 9 independent v_add/v_sub (no carries, no reduction); a difference of two normal
 //   forms has |limb| < 2^29 and can be multiplied directly; sums / longer combinations are brought
 //   back to normal form with `norm` (carry propagation, 24 light instructions).
@@ -198,15 +198,18 @@ struct FpR {
         }
         return hit;
     }
-    // fully reduced 8 x 32 form; accepts any value with |value| < 8p and limbs within int32 range
+    // fully reduced 8 x 32 form; accepts any value with |value| < 16p and limbs within int32 range.  (A Montgomery output is
+    // within (-p/4, 1.3p), sums of a few of them stay below 8p -- but dbl_lazy's X3 = E^2 - 2D and Y3 = E(D - X3) - 8C reach
+    // +-13p, and mul_small_lazy ends in a doubling for every even factor: with the former 8p range the weighted column / row
+    // sums of the MSM tail were stored wrongly for such values.)
     ZK_HD Fp<PR> store_exact() const {
         FpR t;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) t.v[i] = v[i] + PR::POSP29[0][i];   // + 8p: value in (0, 16p)
+        for (int i = 0; i < 9; ++i) t.v[i] = v[i] + PR::POSP29[0][i];   // + 16p: value in (0, 32p)
         t = t.norm();
-        // conditional subtraction of 8p, 4p, 2p, p with borrow propagation in radix 2^29
+        // conditional subtraction of 16p, 8p, 4p, 2p, p with borrow propagation in radix 2^29
 #pragma unroll
-        for (int sh = 0; sh < 4; ++sh) {
+        for (int sh = 0; sh < 5; ++sh) {
             int32_t d[9], br = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {

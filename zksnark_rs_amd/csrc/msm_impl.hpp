@@ -21,7 +21,9 @@
 //              64 B / 128 B points) into a register-resident accumulator in the lazy radix-2^29
 //              form (lazy29.cuh) and parks the accumulator image at bucket boundaries
 //   merge      bucket sums from the parked images (a workgroup per bucket for heavy buckets)
-//   reduce     segmented running sums for sum_b b*S_b, block tree reductions -> one point
+//   reduce     sum_b b*S_b by rows and columns of the bucket index (b - 1 = hi K + lo): plain sums give the K column
+//              sums C_lo and the 2^(c-1)/K row sums R_hi (2 additions per bucket, all parallel, no doubling chains),
+//              sum_b b S_b = sum_lo lo C_lo + sum_hi (hi K + 1) R_hi is left for ~2 sqrt(buckets) points
 // Multi-GPU partial sums: rank g of a job owns windows w = g (mod world) (the digit
 // loop skips other windows), or a range of the points with every window (point_offset).
 #pragma once
@@ -48,7 +50,6 @@ int msm_auto_window(size_t n) {
 }
 #endif  // ZK_MSM_COMMON
 
-constexpr int MSM_SEG = 8;       // buckets per lane in the running-sum reduction
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT2_THREADS = 256;   // level-2 workgroups (several per bin)
 
@@ -515,25 +516,26 @@ __device__ __forceinline__ typename AccOf<F>::type merge_head(uint32_t b, uint32
 }
 
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
-                                                  const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums,
-                                                  uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(256) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
+                                                   const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
+                                                   uint32_t* __restrict__ heavy) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     const uint32_t s = start[b], e = start[b + 1], total = start[buckets];
-    if (s == e) { bucket_sums[b] = Jac<F>::infinity(); return; }
+    typename AccOf<F>::type acc;
+    if (s == e) { acc_clear(acc); img[b].a = acc; return; }
     const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
     if (t1 - t0 > MSM_HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)b; return; }
-    typename AccOf<F>::type acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid);
+    acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid);
     for (uint32_t t = t0 + 1; t <= t1; ++t) acc = acc_add(acc, first[t].a);
-    bucket_sums[b] = acc_store(acc);
+    img[b].a = acc;
 }
 
 constexpr int MSM_HEAVY_THREADS = 128;
 // heavy buckets: one workgroup each, lanes stride over the images, tree over LDS
 template <class F>
 __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
-                                                         const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, Jac<F>* __restrict__ bucket_sums,
+                                                         const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
                                                          const uint32_t* __restrict__ heavy) {
     __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
     const uint32_t count = heavy[0], total = start[buckets];
@@ -550,27 +552,43 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uin
             if ((int)threadIdx.x < d) sh[threadIdx.x].a = acc_add(sh[threadIdx.x].a, sh[threadIdx.x + d].a);
             __syncthreads();
         }
-        if (threadIdx.x == 0) bucket_sums[b] = acc_store(sh[0].a);
+        if (threadIdx.x == 0) img[b].a = sh[0].a;
         __syncthreads();
     }
 }
 
-// segment t covers buckets [t*SEG+1, ...]: out[t] = sum_{b in seg} weight(b) * S_b, weight = the bucket's number within
-// its group of bpg buckets (1-based; bpg = buckets for a single product; segments never straddle groups)
+// ---- sum_b b S_b over the bucket images ---------------------------------------------------------
+// Bucket b of a group has index b - 1 = hi K + lo (K = 2^kbits columns, rows = 2^(c-1) / K).  With the column sums
+// C_lo = sum_hi S[hi][lo] and the row sums R_hi = sum_lo S[hi][lo]:
+//     sum_b b S_b = sum_lo lo C_lo + sum_hi (hi K + 1) R_hi.
+// Column and row sums are plain sums: 2 additions per bucket, every one of them independent of the others (the running-sum
+// form has the same count but needs a k * P of ~c bits per segment of buckets on top, which made 2^19 buckets cost more than
+// the window they save).  What is left to weight is K + rows ~ 2 sqrt(buckets) points.
+//
+// out[a B + b] = sum_{i < f} in[(a f + i) B + b], a < A, b < B: one lane per output image, f - 1 dependent additions.
+// Columns: the row index is folded (B = K); rows: the column index is folded (B = 1); group indices ride in `a`.
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_bucket_reduce(const Jac<F>* __restrict__ bkt, int buckets, int segs, int bpg, Jac<F>* __restrict__ out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= segs) return;
-    int lo = t * MSM_SEG + 1, hi = min(buckets, lo + MSM_SEG - 1);
-    const Jac<F>* wb = bkt - 1;  // wb[b], b in 1..buckets
-    JacR<F> running = jacr_load(Jac<F>::infinity()), acc = running;
-    for (int b = hi; b >= lo; --b) {
-        running = add_lazy(running, jacr_load(wb[b]));
-        acc = add_lazy(acc, running);
-    }
-    const int lo_local = (lo - 1) % bpg + 1;
-    if (lo_local > 1) acc = add_lazy(acc, mul_small_lazy(running, (uint32_t)(lo_local - 1)));
-    out[t] = jacr_store(acc);
+__global__ __launch_bounds__(256) void k_msm_fold(const AccSlot<F>* __restrict__ in, AccSlot<F>* __restrict__ out, uint32_t A, uint32_t f, uint32_t B) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A * B) return;
+    const uint32_t a = j / B, b = j - a * B;
+    const AccSlot<F>* src = in + (size_t)a * f * B + b;
+    typename AccOf<F>::type acc = src[0].a;
+    for (uint32_t i = 1; i < f; ++i) acc = acc_add(acc, src[(size_t)i * B].a);
+    out[j].a = acc;
+}
+
+// term[group][j]: j < K: lo * C[lo] (lo = j); j = K + hi: (hi K + 1) * R[hi].  One point per lane, every lane runs the same
+// double-and-add (weight 0 gives infinity); k_msm_sum_points adds the K + rows terms of a group.
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
+                                                   Jac<F>* __restrict__ term) {
+    const int K = 1 << kbits, g = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= K + rows) return;
+    const AccSlot<F>* src = j < K ? C + (size_t)g * K + j : R + (size_t)g * rows + (j - K);
+    const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u;
+    term[(size_t)g * (K + rows) + j] = jacr_store(mul_small_lazy(jacr_load(acc_store(src->a)), w));
 }
 
 // sums points: workgroup g of G adds in[g], in[g + G], ... (256 lanes, tree over LDS in the 8 x 32 form) -> out[g]
@@ -603,7 +621,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     const int groups = grp.groups;
     const size_t glen = groups > 1 ? grp.glen : std::max<size_t>(n_used, 1), gvalid = groups > 1 ? grp.valid : n_used;
     if (groups > 1) n_used = (size_t)groups * glen;
-    ZK_REQUIRE(groups >= 1 && (groups == 1 || (bpg % MSM_SEG == 0 && gvalid <= glen)), ZK_ERR_ARG, "msm: bad grouping");
+    ZK_REQUIRE(groups >= 1 && (groups == 1 || gvalid <= glen), ZK_ERR_ARG, "msm: bad grouping");
     ZK_REQUIRE(point_offset <= n && gvalid <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
     ZK_REQUIRE(n_used < ((size_t)1 << 32) && (size_t)groups * bpg <= ((size_t)1 << 24), ZK_ERR_SIZE, "msm: too many scalars or buckets");
     const int buckets = bpg * groups;
@@ -626,9 +644,15 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
     // every lane adds the same number of entries (a multiple of 4; 24..48 measured equal within noise)
     size_t entries = (size_t)owned * n_used;
+    // positions in the sorted list (start[], the scan totals, k0 / k1 of the accumulation) are 32-bit, and the level-1
+    // counters of all bins live in LDS: refuse up front instead of wrapping silently / failing after the first launches
+    ZK_REQUIRE(entries < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
+    ZK_REQUIRE((size_t)bins * 4 <= 65536, ZK_ERR_SIZE, "msm: too many groups for this window size (level-1 counters exceed 64 KiB of LDS)");
     const uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
     const size_t lanes = (entries + per_lane - 1) / per_lane;
-    const int segs = (buckets + MSM_SEG - 1) / MSM_SEG;
+    // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
+    const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
+    const int wgs_w = (K + rows + 255) / 256;
 
     ws.hist.ensure((size_t)chunks * bins);
     ws.total.ensure(bins);
@@ -637,13 +661,17 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     ws.start.ensure(buckets + 1);
     ws.sorted.ensure(entries);
     ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
-    ws.bucket_sums.ensure((size_t)buckets * sizeof(Jac<F>));
-    ws.seg_sums.ensure((size_t)segs * sizeof(Jac<F>));
+    ws.bucket_sums.ensure((size_t)buckets * sizeof(AccSlot<F>));                           // S_b as accumulator images
+    ws.fold.ensure(((size_t)buckets + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // 2 x buckets / 2 ping-pong | C | R
+    ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * sizeof(Jac<F>));   // terms | partial sums
     ws.heavy.ensure((size_t)buckets + 1);
     AccSlot<F>* d_first = reinterpret_cast<AccSlot<F>*>(ws.partial.p);
     AccSlot<F>* d_last = d_first + lanes;
     AccSlot<F>* d_mid = d_last + lanes;
-    Jac<F>* d_bsum = reinterpret_cast<Jac<F>*>(ws.bucket_sums.p);
+    AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
+    AccSlot<F>* d_tmp[2] = {reinterpret_cast<AccSlot<F>*>(ws.fold.p), reinterpret_cast<AccSlot<F>*>(ws.fold.p) + (buckets + 1) / 2};
+    AccSlot<F>* d_C = reinterpret_cast<AccSlot<F>*>(ws.fold.p) + 2 * ((buckets + 1) / 2);
+    AccSlot<F>* d_R = d_C + (size_t)groups * K;
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
     const double pt_bytes = (double)sizeof(Aff<F>);
 
@@ -687,26 +715,87 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
     if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     {
-        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * lanes + (double)sizeof(Jac<F>) * (2.0 * buckets + 2.0 * segs), st);
+        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (lanes + 5.0 * buckets), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 64)), dim3(64), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 256)), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
         // heavy buckets are outliers when the average bucket spans few lanes (a small grid that mostly finds nothing
         // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
         // (a narrow top window makes 2^(top bits) buckets heavy at once -- 64..128 at c = 19 -- so the small grid is not THAT small:
         // surplus workgroups read the count and leave)
         const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_bsum, ws.heavy.p);
-        hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(ceil_div(segs, 64)), dim3(64), 0, st, d_bsum, buckets, segs, bpg, d_seg);
-        // per group: one workgroup while each lane has at most ~16 additions, otherwise two levels
-        const int segs_pg = segs / groups;
-        const int wgs = std::min(256, (segs_pg + 4095) / 4096);
-        if (wgs > 1) {
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(wgs, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs_pg, d_bsum, (size_t)wgs * sizeof(Jac<F>));   // bucket sums are dead by now
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_bsum, wgs, d_out, grp.out_stride);
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
+        // column sums C[g][lo] (fold the row index, <= 16 images per lane and pass), then row sums R[g][hi] (fold the column index)
+        constexpr uint32_t FOLD = 16;
+        auto fold_all = [&](uint32_t count, uint32_t B, uint32_t outer, AccSlot<F>* final_out) {
+            // `count` images per output along the folded index; outer = number of (group, kept-index-major) blocks
+            const AccSlot<F>* in = d_img;
+            int tog = 0;
+            for (;;) {
+                const uint32_t f = std::min(count, FOLD);
+                AccSlot<F>* out = count == f ? final_out : d_tmp[tog];
+                const uint32_t A = outer * (count / f);
+                hipLaunchKernelGGL(k_msm_fold<F>, dim3(ceil_div((size_t)A * B, 256)), dim3(256), 0, st, in, out, A, f, B);
+                if (count == f) break;
+                count /= f;
+                in = out;
+                tog ^= 1;
+            }
+        };
+        fold_all((uint32_t)rows, (uint32_t)K, (uint32_t)groups, d_C);
+        fold_all((uint32_t)K, 1u, (uint32_t)groups * (uint32_t)rows, d_R);
+        hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(256), 0, st, d_C, d_R, kbits, rows, d_seg);
+        // K + rows terms per group: one workgroup while each lane has at most 4 of them, otherwise two levels
+        Jac<F>* d_part = d_seg + (size_t)groups * (K + rows);
+        const int terms = K + rows, wgs2 = (terms + 1023) / 1024;
+        if (wgs2 > 1) {
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(wgs2, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, terms, d_part, (size_t)wgs2 * sizeof(Jac<F>));
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_part, wgs2, d_out, grp.out_stride);
         } else {
-            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, segs_pg, d_out, grp.out_stride);
+            hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, terms, d_out, grp.out_stride);
         }
     }
+#ifdef ZK_MSM_SELFCHECK
+    if (groups == 1) {
+        // debugging aid (never in the product build): recompute the tail on the host from the device's bucket images
+        ZK_HIP(hipStreamSynchronize(st));
+        std::vector<AccSlot<F>> h_img(buckets), h_C(K), h_R(rows);
+        Jac<F> h_out;
+        ZK_HIP(hipMemcpy(h_img.data(), d_img, sizeof(AccSlot<F>) * buckets, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(h_C.data(), d_C, sizeof(AccSlot<F>) * K, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(h_R.data(), d_R, sizeof(AccSlot<F>) * rows, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(&h_out, d_out, sizeof(Jac<F>), hipMemcpyDeviceToHost));
+        auto same = [](const Jac<F>& a, const Jac<F>& b) {
+            if (a.is_inf() || b.is_inf()) return a.is_inf() && b.is_inf();
+            Aff<F> x = jac_to_affine(a), y = jac_to_affine(b);
+            return x.x == y.x && x.y == y.y;
+        };
+        int badC = 0, badR = 0, nonempty = 0;
+        for (int b = 0; b < buckets; ++b) nonempty += !h_img[b].a.inf;
+        for (int lo = 0; lo < K; ++lo) {
+            auto acc = h_img[lo].a;
+            for (int hi = 1; hi < rows; ++hi) acc = acc_add(acc, h_img[(size_t)hi * K + lo].a);
+            if (!same(acc_store(acc), acc_store(h_C[lo].a))) { if (badC < 4) fprintf(stderr, "  C[%d] differs (dev inf %d host inf %d)\n", lo, (int)h_C[lo].a.inf, (int)acc.inf); ++badC; }
+        }
+        for (int hi = 0; hi < rows; ++hi) {
+            auto acc = h_img[(size_t)hi * K].a;
+            for (int lo = 1; lo < K; ++lo) acc = acc_add(acc, h_img[(size_t)hi * K + lo].a);
+            if (!same(acc_store(acc), acc_store(h_R[hi].a))) { if (badR < 4) fprintf(stderr, "  R[%d] differs (dev inf %d host inf %d)\n", hi, (int)h_R[hi].a.inf, (int)acc.inf); ++badR; }
+        }
+        int badW = 0;
+        std::vector<Jac<F>> h_term(K + rows);
+        ZK_HIP(hipMemcpy(h_term.data(), d_seg, sizeof(Jac<F>) * (K + rows), hipMemcpyDeviceToHost));
+        JacR<F> total = jacr_load(Jac<F>::infinity());
+        for (int j = 0; j < K + rows; ++j) {
+            const JacR<F> t = j < K ? mul_small_lazy(jacr_load(acc_store(h_C[j].a)), (uint32_t)j)
+                                    : mul_small_lazy(jacr_load(acc_store(h_R[j - K].a)), ((uint32_t)(j - K) << kbits) + 1u);
+            if (!same(jacr_store(t), h_term[j])) { if (badW < 4) fprintf(stderr, "  term %d differs\n", j); ++badW; }
+            total = add_lazy(total, jacr_load(h_term[j]));
+        }
+        const bool okOut = same(jacr_store(total), h_out);
+        fprintf(stderr, "[selfcheck %s] c=%d buckets=%d nonempty=%d K=%d rows=%d: C bad %d, R bad %d, weighted bad %d, final %s\n", g2 ? "G2" : "G1", c, buckets, nonempty, K, rows,
+                badC, badR, badW, okOut ? "ok" : "BAD");
+    }
+#endif
     ZK_HIP(hipGetLastError());
 }
 template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&);

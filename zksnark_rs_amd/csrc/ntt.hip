@@ -389,6 +389,69 @@ void fr_pointwise_mul(zk_ctx* ctx, const Fr* a, const Fr* b, Fr* out, size_t n) 
     ZK_HIP(hipGetLastError());
 }
 
+// ---- zk_lazy29_batch: the lazy radix-2^29 arithmetic on caller-supplied limb patterns (diagnostic) ----
+// The multiplier of the bucket accumulation and of the NTT tiles (lazy29.cuh: FpR::mont / sqr / mont_diff / norm /
+// store_exact; above: fr_reduce, fr_store_exact) normally only sees values the pipeline produces; the bounds it relies on
+// are argued in comments.  This entry point feeds it the EXTREMES those comments allow (all limbs +-(2^29 - 1), 2^30 on one
+// side, values next to k p) so that a column overflow shows up in a test instead of as a wrong proof on a rare input.
+template <class PR>
+__device__ __forceinline__ FpR<PR> lazy_get(const int32_t* p, size_t i) {
+    FpR<PR> r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.v[k] = p[i * 9 + k];
+    return r;
+}
+template <class PR>
+__global__ void k_lazy29(int op, const int32_t* __restrict__ a, const int32_t* __restrict__ b, const int32_t* __restrict__ c, const int32_t* __restrict__ d,
+                         size_t n, Fp<PR>* __restrict__ out, int32_t* __restrict__ raw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef FpR<PR> L;
+    L x = lazy_get<PR>(a, i), r;
+    if (op == ZK_LAZY_MONT) r = L::template mont<false>(x, lazy_get<PR>(b, i));
+    else if (op == ZK_LAZY_SQR) r = x.sqr();
+    else if (op == ZK_LAZY_MONT_DIFF) r = L::mont_diff(x, lazy_get<PR>(b, i), lazy_get<PR>(c, i), lazy_get<PR>(d, i));
+    else if (op == ZK_LAZY_NORM) r = x.norm();
+    else r = x;   // ZK_LAZY_STORE
+    out[i] = r.store_exact();
+    if (raw)
+        for (int k = 0; k < 9; ++k) raw[i * 9 + k] = r.v[k];
+}
+__global__ void k_lazy29_fr(int op, const int32_t* __restrict__ a, size_t n, Fr* __restrict__ out, int32_t* __restrict__ raw) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FrL x = lazy_get<FrParams>(a, i), r = op == ZK_LAZY_FR_REDUCE ? fr_reduce(x) : x;
+    out[i] = fr_store_exact(r);
+    if (raw)
+        for (int k = 0; k < 9; ++k) raw[i * 9 + k] = r.v[k];
+}
+void lazy29_batch(zk_ctx* ctx, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n, uint64_t* out, int32_t* raw_out) {
+    ZK_REQUIRE(field == 0 || field == 1, ZK_ERR_ARG, "zk_lazy29_batch: field must be 0 (Fr) or 1 (Fq)");
+    ZK_REQUIRE(op >= ZK_LAZY_MONT && op <= ZK_LAZY_FR_STORE, ZK_ERR_ARG, "zk_lazy29_batch: unknown op");
+    ZK_REQUIRE(op < ZK_LAZY_FR_REDUCE || field == 0, ZK_ERR_ARG, "zk_lazy29_batch: fr_reduce / fr_store_exact exist for Fr only");
+    const int operands = op == ZK_LAZY_MONT ? 2 : op == ZK_LAZY_MONT_DIFF ? 4 : 1;
+    ZK_REQUIRE(out && (n == 0 || (a && (operands < 2 || b) && (operands < 4 || (c && d)))), ZK_ERR_ARG, "zk_lazy29_batch: null pointer");
+    if (!n) return;
+    const size_t limbs = n * 9;
+    DevBuf<int32_t> da(limbs), db(operands >= 2 ? limbs : 0), dc(operands >= 4 ? limbs : 0), dd(operands >= 4 ? limbs : 0), draw(raw_out ? limbs : 0);
+    DevBuf<Fr> dout(n);
+    hipStream_t st = ctx->stream;
+    ZK_HIP(hipMemcpyAsync(da.p, a, limbs * 4, hipMemcpyHostToDevice, st));
+    if (operands >= 2) ZK_HIP(hipMemcpyAsync(db.p, b, limbs * 4, hipMemcpyHostToDevice, st));
+    if (operands >= 4) {
+        ZK_HIP(hipMemcpyAsync(dc.p, c, limbs * 4, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipMemcpyAsync(dd.p, d, limbs * 4, hipMemcpyHostToDevice, st));
+    }
+    const dim3 grid(ceil_div(n, 256)), block(256);
+    if (op >= ZK_LAZY_FR_REDUCE) hipLaunchKernelGGL(k_lazy29_fr, grid, block, 0, st, op, da.p, n, dout.p, draw.p);
+    else if (field == 0) hipLaunchKernelGGL(k_lazy29<FrParams>, grid, block, 0, st, op, da.p, db.p, dc.p, dd.p, n, dout.p, draw.p);
+    else hipLaunchKernelGGL(k_lazy29<FqParams>, grid, block, 0, st, op, da.p, db.p, dc.p, dd.p, n, reinterpret_cast<Fq*>(dout.p), draw.p);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    if (raw_out) ZK_HIP(hipMemcpyAsync(raw_out, draw.p, limbs * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+}
+
 // zk_ntt_fr: natural order in and out on a host buffer (== field::dft / idft semantics)
 void ntt_host(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
     ZK_REQUIRE(data, ZK_ERR_ARG, "zk_ntt_fr: null data");

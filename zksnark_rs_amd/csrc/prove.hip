@@ -42,39 +42,36 @@ struct AssemblePre {
 
 __device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
 
-// k * P from the 4-bit fixed-base table FT[w][d] = d * 16^w * P: lane w contributes FT[w][digit_w];
-// the 64 contributions are summed by a tree over LDS (6 additions deep instead of 254 doublings).
-template <class F>
-__device__ void fixed_base_mul_wave(const Aff<F>* __restrict__ ft, const Fr& k, Jac<F>* sh, int lane, Jac<F>* out) {
-    sh[lane] = Jac<F>::from_affine(ft[lane * 16 + nibble(k, lane)]);
-    __syncthreads();
-    for (int d = 32; d >= 1; d >>= 1) {
-        if (lane < d) sh[lane] = jac_add_ni(sh[lane], sh[lane + d]);
-        __syncthreads();
-    }
-    if (lane == 0) *out = sh[0];
-}
-
-// Everything that depends only on (r, s) and single CRS points; runs on the side stream while the
-// five inner products execute.  One wave per fixed-base multiplication.
+// k * P from the 4-bit fixed-base table FT[w][d] = d * 16^w * P: lane w contributes FT[w][digit_w]; the 64
+// contributions of a wave are summed by a tree over the wave's own LDS row (6 additions deep instead of 254 doublings).
+// Everything that depends only on (r, s) and single CRS points; runs on the side stream while the five inner products
+// execute.  One wave per fixed-base multiplication: waves 0..3 in G1 (r delta, s alpha, r beta, rs delta), wave 4 in G2
+// (s delta2).  All waves run the SAME loop with workgroup barriers at uniform places -- the G1 / G2 difference is inside
+// barrier-free regions -- so no barrier sits in divergent control flow.
 __device__ __forceinline__ void assemble_pre_body(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1, const G1A* __restrict__ ft_delta1,
                                                   const G2A* __restrict__ ft_delta2, const Fr& r, const Fr& s, AssemblePre* __restrict__ out) {
     __shared__ G1J sh1[4][64];
     __shared__ G2J sh2[64];
-    __shared__ G1J res[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    Fr rs = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
-    // every wave reaches the same number of __syncthreads (7) inside fixed_base_mul_wave
-    if (wave == 0) fixed_base_mul_wave<Fq>(ft_delta1, r, sh1[0], lane, &res[0]);          // r delta
-    else if (wave == 1) fixed_base_mul_wave<Fq>(ft_alpha1, s, sh1[1], lane, &res[1]);     // s alpha
-    else if (wave == 2) fixed_base_mul_wave<Fq>(ft_beta1, r, sh1[2], lane, &res[2]);      // r beta
-    else if (wave == 3) fixed_base_mul_wave<Fq>(ft_delta1, rs, sh1[3], lane, &res[3]);    // rs delta
-    else fixed_base_mul_wave<Fq2>(ft_delta2, s, sh2, lane, &out->s_delta2);               // s delta2
+    const Fr rs = (Fr::from_canonical(r) * Fr::from_canonical(s)).to_canonical();
+    const Fr k = wave == 0 ? r : wave == 1 ? s : wave == 2 ? r : wave == 3 ? rs : s;
+    const G1A* ft1 = wave == 0 ? ft_delta1 : wave == 1 ? ft_alpha1 : wave == 2 ? ft_beta1 : ft_delta1;
+    const uint32_t digit = nibble(k, lane);
+    if (wave < 4) sh1[wave][lane] = G1J::from_affine(ft1[lane * 16 + digit]);
+    else sh2[lane] = G2J::from_affine(ft_delta2[lane * 16 + digit]);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        out->r_delta = res[0];
-        out->fixed_c = jac_add_ni(jac_add_ni(res[1], res[2]), res[3]);
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (lane < d) {
+            if (wave < 4) sh1[wave][lane] = jac_add_ni(sh1[wave][lane], sh1[wave][lane + d]);
+            else sh2[lane] = jac_add_ni(sh2[lane], sh2[lane + d]);
+        }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        out->r_delta = sh1[0][0];
+        out->fixed_c = jac_add_ni(jac_add_ni(sh1[1][0], sh1[2][0]), sh1[3][0]);
+    }
+    if (threadIdx.x == 256) out->s_delta2 = sh2[0];
 }
 __global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
                                                       const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
@@ -201,6 +198,7 @@ struct ProveSlot {
     bool busy = false, partial = false;
     void init() {
         ms.alloc(1); as.alloc(1); d_proof.alloc(ZK_PROOF_BYTES); flag.alloc(1);
+        ZK_HIP(hipMemset(ms.p, 0, sizeof(MsmResults)));   // `spare` is never written but travels with the partial sums
         ZK_HIP(hipHostMalloc((void**)&h_proof, ZK_PROOF_BYTES));
         ZK_HIP(hipHostMalloc((void**)&h_flag, sizeof(int)));
         ZK_HIP(hipEventCreateWithFlags(&fork_evt, hipEventDisableTiming));

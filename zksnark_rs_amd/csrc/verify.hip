@@ -127,7 +127,11 @@ static bool rd_g2(const uint64_t* w, G2A& out) {
     out = G2A{Fq2::from_canonical(x), Fq2::from_canonical(y)};
     if (out.is_inf()) return true;
     Fq2 b2 = Fq2{fq_small(3), Fq::zero()} * Fq2{fq_small(9), fq_small(1)}.inv();   // 3 / xi
-    return out.y.sqr() == out.x.sqr() * out.x + b2;
+    if (!(out.y.sqr() == out.x.sqr() * out.x + b2)) return false;
+    // r-torsion: the twist E'(Fq2) has order r * (2q - r) and the cofactor has small factors; the ate Miller loop is
+    // bilinear only on the order-r subgroup G2, so a twist point outside it is rejected ([r]Q must be infinity).
+    // G1 needs no such test: E(Fq) has prime order r.
+    return jac_mul_words(G2J::from_affine(out), FrParams::P).is_inf();
 }
 static void be_to_words(const uint8_t* be, uint64_t* w) {
     for (int i = 0; i < 4; ++i) {
@@ -137,20 +141,28 @@ static void be_to_words(const uint8_t* be, uint64_t* w) {
     }
 }
 // decode the canonical 65 / 129 byte blocks of a proof
+// The encoding is canonical, so that a proof has exactly one byte string: infinity is tag 0x00 followed by zeros ONLY,
+// a finite point is tag 0x04 with coordinates < q that satisfy the curve equation ((0, 0), the in-memory
+// image of infinity, is not on either curve and is rejected under tag 0x04).
+static bool all_zero(const uint8_t* p, size_t n) {
+    uint8_t acc = 0;
+    for (size_t i = 0; i < n; ++i) acc |= p[i];
+    return acc == 0;
+}
 static bool dec_g1(const uint8_t* p, G1A& out) {
-    if (p[0] == 0) { out = G1A::infinity(); return true; }
+    if (p[0] == 0) { out = G1A::infinity(); return all_zero(p + 1, 64); }
     if (p[0] != 4) return false;
     uint64_t w[8];
     be_to_words(p + 1, w); be_to_words(p + 33, w + 4);
-    return rd_g1(w, out);
+    return rd_g1(w, out) && !out.is_inf();
 }
 static bool dec_g2(const uint8_t* p, G2A& out) {
-    if (p[0] == 0) { out = G2A::infinity(); return true; }
+    if (p[0] == 0) { out = G2A::infinity(); return all_zero(p + 1, 128); }
     if (p[0] != 4) return false;
     uint64_t w[16];
     be_to_words(p + 1, w + 4); be_to_words(p + 33, w);          // x.c1 | x.c0
     be_to_words(p + 65, w + 12); be_to_words(p + 97, w + 8);    // y.c1 | y.c0
-    return rd_g2(w, out);
+    return rd_g2(w, out) && !out.is_inf();
 }
 
 static void fq12_to_words(const Fq12& f, uint64_t* out) {
@@ -189,7 +201,7 @@ int zk_verify(zk_ctx* ctx, const zk_crs* crs, const uint64_t* inputs, size_t n_i
         crs_download(ctx, *crs, o);
         G1A alpha, A, C;
         G2A beta, gamma, delta, B;
-        ZK_REQUIRE(rd_g1(a1.data(), alpha) && rd_g2(b2.data(), beta) && rd_g2(g2.data(), gamma) && rd_g2(d2.data(), delta), ZK_ERR_ARG, "verify: CRS point not on the curve");
+        ZK_REQUIRE(rd_g1(a1.data(), alpha) && rd_g2(b2.data(), beta) && rd_g2(g2.data(), gamma) && rd_g2(d2.data(), delta), ZK_ERR_ARG, "verify: CRS point not on the curve or outside G2");
         if (!dec_g1(proof, A) || !dec_g2(proof + 65, B) || !dec_g1(proof + 194, C)) return;   // malformed / off-curve proof: rejected
         // sum_term = sum_{i<=l} (1, inputs...)_i * sum_gamma_i  (zip truncates, mod.rs:308-314)
         G1J sum = G1J::infinity();
