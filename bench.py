@@ -51,75 +51,101 @@ def build_instance(zk, ctx, log_n, seed, witness="uniform"):
     return dict(n=n, m=m, l=l, rows=(u, v, w), qap=qap, crs=crs, weights=weights, td=td, r=r, s=s, log_n=log_n)
 
 
-def cpu_baseline(zk, ctx, seed):
-    """Times the oracle's FAITHFUL restatement of the reference prove() (dense QAP, schoolbook multiply,
-    long division, n double-and-add scalar multiplications) single-threaded on the chain circuit at
-    n = 2^5..2^8.  It cannot run at 2^20 (O(m n) + O(n^2) field work, dense QAP = 3 m n 32 B = 105 TB), so the
-    2^20 figure is SURVEY 8d's operation count of the reference's prove(),
-        T(n) = k_F (rho n + n^2 + (n-1)(n+1)) + k_I (n-1) + k_G1 (3n + m - l + 3) + k_G2 (n+1),  rho = 3n+1,
-    priced with unit costs measured on this host (Fr multiply-add, Fr inversion, G1 / G2 scalar multiplication)
-    and calibrated by the ratio measured / model at 2^8.  Also times the same-algorithm CPU path (NTT +
-    Pippenger) on 1 thread at 2^12 and on many threads at 2^16."""
+def cpu_baseline(zk, ctx, seed, main_inst, full=False):
+    """CPU legs of SURVEY 8d, timed on this host in this run (the reference itself is Rust + crate bn and cannot be built here):
+    B2, the headline: the oracle's SAME-ALGORITHM path (NTT + Pippenger, bit-identical output) measured DIRECTLY on the metric's
+        workload -- one 2^20 proof on all host threads -- and at 2^16 on 1 thread and on all threads (2^20 on one thread takes
+        minutes: only with --cpu-baseline full);
+    B1: the FAITHFUL restatement of the reference's prove() (dense QAP, schoolbook multiply, long division with an inversion per
+        term, one double-and-add per inner-product term; single thread like the reference) measured at 2^6, 2^8, 2^10, 2^12.  It
+        cannot run at 2^20 (O(m n) + O(n^2) field work on a dense QAP of 3 m n 32 B = 105 TB), so beyond 2^12 only SURVEY 8d's
+        operation count priced with unit costs measured here is given, labelled as an extrapolation."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     orc = oracle_lib.load()
-    pts = []
     t_start = time.time()
-    for log_n in (5, 6, 7, 8):
+    threads = max(1, os.cpu_count() or 1)
+
+    def descs(inst):
+        desc = ctx.sparse_desc(inst["log_n"], inst["m"], inst["l"], *inst["rows"])
+        return desc, ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
+
+    def check(inst, proof):
+        assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU and GPU proofs differ"
+
+    faithful = []
+    for log_n in (6, 8, 10, 12):
         inst = build_instance(zk, ctx, log_n, seed + log_n)
-        desc = ctx.sparse_desc(log_n, inst["m"], inst["l"], *inst["rows"])
-        cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
+        desc, cdesc = descs(inst)
         sec, proof = orc.time_prove_sparse(desc, cdesc, inst["weights"], inst["r"], inst["s"], True, 1)
-        assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU/GPU proofs differ"
-        pts.append((inst["n"], sec))
+        check(inst, proof)
+        faithful.append((inst["n"], sec))
     k_f, k_i, k_g1, k_g2 = orc.unit_costs()
 
     def model(n):
         m, l = 2 * n + 2, 2
         return k_f * ((3 * n + 1) * n + n * n + (n - 1) * (n + 1)) + k_i * (n - 1) + k_g1 * (3 * n + m - l + 3) + k_g2 * (n + 1)
-    ratios = [t / model(n) for n, t in pts]
+    ratios = [t / model(n) for n, t in faithful]
     calib = ratios[-1]
-    n20 = float(1 << 20)
-    t20 = calib * model(n20)
-    inst = build_instance(zk, ctx, 12, seed + 12)
-    desc = ctx.sparse_desc(12, inst["m"], inst["l"], *inst["rows"])
-    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
-    fast_sec, proof = orc.time_prove_sparse(desc, cdesc, inst["weights"], inst["r"], inst["s"], False, 1)
-    assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU/GPU proofs differ"
-    # the same algorithm on many host threads at BASELINE's 2^16 size (five inner products x windows, NTT stages split)
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    inst = build_instance(zk, ctx, 16, seed + 16)
-    desc = ctx.sparse_desc(16, inst["m"], inst["l"], *inst["rows"])
-    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(inst["crs"]))
-    mt_sec, proof = orc.time_prove_sparse_mt(desc, cdesc, inst["weights"], inst["r"], inst["s"], threads, 1)
-    assert proof == ctx.prove(inst["crs"], inst["qap"], inst["weights"], inst["r"], inst["s"]), "CPU/GPU proofs differ"
+    same = {}
+    inst16 = build_instance(zk, ctx, 16, seed + 16)
+    desc, cdesc = descs(inst16)
+    for th in (1, threads):
+        sec, proof = orc.time_prove_sparse_mt(desc, cdesc, inst16["weights"], inst16["r"], inst16["s"], th, 1)
+        check(inst16, proof)
+        same["2^16, %d thread%s" % (th, "" if th == 1 else "s")] = round(sec, 3)
+    del inst16
+    desc, cdesc = descs(main_inst)
+    legs20 = (threads, 1) if full else (threads,)
+    sec20 = None
+    for th in legs20:
+        sec, proof = orc.time_prove_sparse_mt(desc, cdesc, main_inst["weights"], main_inst["r"], main_inst["s"], th, 1)
+        check(main_inst, proof)
+        same["2^%d, %d thread%s" % (main_inst["log_n"], th, "" if th == 1 else "s")] = round(sec, 3)
+        if th == threads:
+            sec20 = sec
+    n_main = float(main_inst["n"])
     return {
-        "value": 1.0 / t20, "unit": "proofs/s", "cores": 1, "kind": "port",
-        "sample": "oracle faithful prove() on the chain circuit, measured n=2^5..2^8 (%s s/proof); 2^20 = the reference's operation "
-                  "count (SURVEY 8d) priced with unit costs measured here (Fr mul-add %.1f ns, Fr inverse %.1f us, G1 mul %.0f us, G2 mul %.0f us), "
-                  "measured/model = %s, calibrated at 2^8 -> %.3e s/proof (%.0f%% of it the 5 n^2 field multiply-adds); the reference "
-                  "itself (Rust+bn) cannot be built here"
-                  % ([round(t, 3) for _, t in pts], k_f * 1e9, k_i * 1e6, k_g1 * 1e6, k_g2 * 1e6, [round(x, 2) for x in ratios], t20,
-                     100.0 * calib * k_f * 5 * n20 * n20 / t20),
-        "cpu_same_algorithm": {"n": 1 << 12, "seconds_per_proof": fast_sec, "cores": 1,
-                               "note": "oracle NTT+Pippenger prove measured at 2^12; ~n log n scaling => x%.0f at 2^20" % (256 * 20 / 12.0)},
-        "cpu_same_algorithm_threads": {"n": 1 << 16, "seconds_per_proof": mt_sec, "cores": threads,
-                                       "note": "same path on %d host threads at 2^16; ~n log n scaling => x%.0f at 2^20" % (threads, 16 * 20 / 16.0)},
+        "value": 1.0 / sec20, "unit": "proofs/s", "cores": threads, "kind": "port",
+        "sample": "ONE whole proof of the metric's workload (2^%d-gate chain circuit) by the oracle's same-algorithm CPU path (NTT + Pippenger, "
+                  "%d host threads, bytes equal to the GPU's), measured directly: %.2f s" % (main_inst["log_n"], threads, sec20),
+        "same_algorithm_seconds_per_proof": same,
+        "reference_algorithm": {
+            "what": "oracle's FAITHFUL restatement of the reference's prove() (mod.rs:213-296), 1 thread like the reference, QAP prebuilt",
+            "measured_seconds_per_proof": {"2^%d" % (n.bit_length() - 1): round(t, 3) for n, t in faithful},
+            "unit_costs": {"fr_mul_add_ns": round(k_f * 1e9, 1), "fr_inverse_us": round(k_i * 1e6, 2), "g1_scalar_mul_us": round(k_g1 * 1e6, 1),
+                           "g2_scalar_mul_us": round(k_g2 * 1e6, 1)},
+            "measured_over_model": [round(x, 2) for x in ratios],
+            "EXTRAPOLATED_seconds_per_proof": {"2^16": round(calib * model(65536.0), 1), "2^20": float("%.3g" % (calib * model(n_main)))},
+            "note": "extrapolation = SURVEY 8d's operation count T(n) = k_F (rho n + n^2 + (n-1)(n+1)) + k_I (n-1) + k_G1 (3n+m-l+3) + k_G2 (n+1), rho = 3n+1, "
+                    "calibrated at 2^12; the faithful path itself cannot run there (dense QAP = 3 m n 32 B)",
+        },
         "wall_s": round(time.time() - t_start, 1),
     }
 
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
+PMC_FILE = "r2_pmc_traffic.json"
+
+# VALU issue ceiling of gfx950 for the two instruction classes of the multiplier, from tools/ubench_valu.hip (>= 5 ms kernels, in-kernel
+# shader / wall clocks, cross-checked with SQ_INSTS_VALU and GRBM_GUI_ACTIVE: profiles/r2_ubench_valu.txt, r2_ubench_valu_pmc.txt):
+#   64-bit / integer-multiply class (v_mad_u64_u32, v_mad_i64_i32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64, carry adds): 4 cycles
+#   per wave-instruction and SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614 G/s (measured 585 at 8 waves/SIMD, 546 at 3, clock 2.36-2.40 GHz);
+#   plain 32-bit class (v_and, v_add_u32, v_mov, shifts): 2 cycles -> 1229 G/s (measured 1062).
+# (Round 1's "5.09 cycles" was a 40-140 us kernel timed with events: launch overhead and the clock ramp inside the measurement.)
+VALU_PEAK_G = {"slow": 1024 * 2.4 / 4.0, "fast": 1024 * 2.4 / 2.0}
+VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
+# wave-instructions per lane-addition (SQ_INSTS_VALU / additions, profiles/r2_pmc_acc.txt) and the share in the 4-cycle class
+# (per mixed addition: 1467 multiply-adds + ~400 64-bit adds / shifts / mul_lo of the column bookkeeping; tools/instr_mix.py lists the loop)
+ACC_INSTR = {"msm_accumulate_g1": (2242.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
 
 
 def pmc_traffic(name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE
-    and --pmc WRITE_SIZE in separate runs of this same command, profiles/r1_pmc_traffic.json; FETCH_SIZE corrected
-    as MI355X_MICROARCH.md prescribes for gfx950: x2 for streams, x1 for the 64-byte gathers of the G1 accumulation as
-    calibrated on a known byte count, profiles/r1_fetch_calibration.txt).  Counters cannot be collected inside this process, so this is
-    null when the file is missing."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this round's build (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this same command, tools/pmc_summary.py -> profiles/r2_pmc_traffic.json; FETCH_SIZE corrected
+    as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: null when the file is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             return json.load(f)["kernels"][PMC_KERNEL[name]]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
@@ -138,10 +164,19 @@ def main():
                          "replicas = independent provers")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
+    ap.add_argument("--fold", type=int, default=0, help="msm_fold tunable (0 = library default)")
+    ap.add_argument("--tail-streams", type=int, default=-1, help="msm_tail_streams option (-1 = library default)")
+    ap.add_argument("--alt-g2", type=int, default=-1, help="msm_alt_g2 option (-1 = library default)")
+    ap.add_argument("--acc-stream", type=int, default=-1, help="msm_acc_stream option (-1 = library default)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, 1 GPU only: time rank 0's share of a W-way window-sharded proof (no collective) instead of whole proofs")
+    ap.add_argument("--transport", choices=["zk", "zk-gloo", "torch"], default="zk",
+                    help="N > 1: zk = the communicator and the exchange pipeline inside libzkgpu.so (RCCL linked into the library: zk_comm_*, "
+                         "zk_mgpu_*; torch.distributed is never initialised, the RCCL id travels through a TCP store); torch = the round-1 driver "
+                         "in Python over torch.distributed collectives; zk-gloo (also what --backend gloo selects) = the same C pipeline over a "
+                         "caller-supplied gloo transport, for functional runs of several ranks on ONE GPU")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="torch.distributed backend; gloo + several ranks on ONE GPU is a functional check of the N > 1 path only")
+                    help="--transport torch: torch.distributed backend; gloo + several ranks on ONE GPU is a functional check of the N > 1 path only")
     ap.add_argument("--shard", choices=["windows", "points"], default="points",
                     help="what a rank owns of each inner product in --mode shard: Pippenger windows w = rank (mod N), or the "
                          "point range [count rank / N, count (rank+1) / N) with every window (5 %% faster at N = 8: 15 windows "
@@ -160,6 +195,8 @@ def main():
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["default", "full"], default="default",
+                    help="full: also the same-algorithm CPU path at 2^20 on ONE thread (minutes)")
     args = ap.parse_args()
 
     import torch
@@ -173,10 +210,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.transport == "zk" and args.backend == "gloo":
+        args.transport = "zk-gloo"
+    use_zk = world > 1 and args.transport in ("zk", "zk-gloo")
     device = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 and args.transport != "zk":
         import torch.distributed as dist
         if args.backend == "gloo":
             dist.init_process_group("gloo")
@@ -184,6 +224,31 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     ctx = zk.Context(device)
+    comm = None
+    if use_zk and args.transport == "zk":
+        from zksnark_rs_amd.distributed import bootstrap_comm
+        comm = bootstrap_comm(ctx, rank, world)     # RCCL communicator inside libzkgpu.so
+    elif use_zk:
+        from zksnark_rs_amd.distributed import gloo_comm
+        comm = gloo_comm(ctx, dist, rank, world)
+        store_port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+        from datetime import timedelta
+        comm._store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), store_port, world, rank == 0, timeout=timedelta(seconds=300))
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        elif dist:
+            dist.barrier()
+
+    def reduce_max(x):
+        if comm is not None:
+            return comm.max_f64(float(x))
+        if dist:
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
     if args.serialize:
@@ -191,15 +256,29 @@ def main():
     ctx.set_option("msm_shard_points", 1 if args.shard == "points" else 0)
     if args.lane_entries:
         ctx.set_option("msm_lane_entries", args.lane_entries)
+    if args.fold:
+        ctx.set_option("msm_fold", args.fold)
+    if args.tail_streams >= 0:
+        ctx.set_option("msm_tail_streams", args.tail_streams)
+    if args.alt_g2 >= 0:
+        ctx.set_option("msm_alt_g2", args.alt_g2)
+    if args.acc_stream >= 0:
+        ctx.set_option("msm_acc_stream", args.acc_stream)
     inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness)
     d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
     m = inst["m"]
     exchange = world > 1 and args.mode == "exchange"
-    if exchange:
+    shard = shard_mode = world > 1 and args.mode == "shard"
+    mprover = None
+    if exchange and use_zk:
+        from zksnark_rs_amd.distributed import MgpuProver
+        mprover = MgpuProver(ctx, comm, inst["crs"], inst["qap"])
+    elif exchange:
         from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
         xprover = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
-    shard = shard_mode = world > 1 and args.mode == "shard"
-    if shard:
+    if shard and use_zk:
+        from zksnark_rs_amd.distributed import prove_sharded_abi
+    elif shard:
         from zksnark_rs_amd.distributed import GpuProver, prove_sharded, prove_sharded_stream
         prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
         bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
@@ -256,7 +335,11 @@ def main():
         if exchange and not local:
             if os.environ.get("ZK_BENCH_TEST_FAIL_EXCHANGE"):   # tests/test_gpu_bench.py: exercises the fallback below
                 raise RuntimeError("injected failure of the exchange protocol")
+            if mprover is not None:     # zk_mgpu_push / zk_mgpu_pop, two rounds pushed ahead of every pop
+                return list(mprover.prove_stream([(d_w.data_ptr(), m, inst["r"], inst["s"])] * k, ahead=2))
             return list(prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k))   # k rounds = k * world proofs
+        if shard and use_zk:
+            return [prove_sharded_abi(ctx, comm, inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
         if shard and depth == 1:
             return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
         if shard:
@@ -301,13 +384,19 @@ def main():
         for p in run(args.warmup):
             proof = p
     except Exception as e:   # noqa: BLE001 -- reported in the JSON line
-        if not dist:
+        if world == 1:
             raise
         err = "%s: %s" % (type(e).__name__, str(e)[:300])
-    if dist:
-        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
+    if world > 1:
+        if comm is not None:
+            # agreement through the bootstrap store (a failed collective may have left the communicator unusable)
+            comm._store.set("warm_%d" % rank, b"1" if err else b"0")
+            failed = any(bytes(comm._store.get("warm_%d" % g)) == b"1" for g in range(world))
+        else:
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            failed = bool(int(flag.item()))
+        if failed:
             state["degraded"] = err or "another rank failed in the warm-up of --mode %s" % args.mode
             torch.cuda.synchronize()
             for t in range(zk.MAX_IN_FLIGHT):   # tickets the failed protocol left in flight
@@ -319,19 +408,30 @@ def main():
                 proof = p
     ctx.set_option("profile", 1)
     ctx.profile_reset()
+    degraded_now = state["degraded"] is not None    # a failed communicator is not used again: barrier through the bootstrap store
+
+    def store_barrier(tag):
+        comm._store.set("%s_%d" % (tag, rank), b"1")
+        for g in range(world):
+            comm._store.get("%s_%d" % (tag, g))
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    if degraded_now and comm is not None:
+        store_barrier("b0")
+    else:
+        barrier()
     t0 = time.perf_counter()
     proofs_out = run(args.steps)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    if degraded_now and comm is not None:
+        store_barrier("b1")
+    else:
+        barrier()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if degraded_now and comm is not None:
+        comm._store.set("t_%d" % rank, repr(elapsed).encode())
+        elapsed = max(float(bytes(comm._store.get("t_%d" % g)).decode()) for g in range(world))
+    else:
+        elapsed = reduce_max(elapsed)
     prof = ctx.profile()
     ctx.set_option("profile", 0)
     # beside the window-sharded line (north_star, configs[4]): the same K steps as independent provers, one
@@ -342,15 +442,12 @@ def main():
     if shard or exchange:
         run(args.warmup, local=True)
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         t1 = time.perf_counter()
         rep_out = run(args.steps, local=True)
         torch.cuda.synchronize()
-        dist.barrier()
-        e2 = time.perf_counter() - t1
-        t = torch.tensor([e2], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        e2 = float(t.item())
+        barrier()
+        e2 = reduce_max(time.perf_counter() - t1)
         assert all(p == proofs_out[0] for p in rep_out), "replica proof differs from the sharded proof"
         replicas = {"mode": "replicas x%d (independent provers, no collective)" % world, "value": round(world * args.steps / e2, 4),
                     "unit": "proofs/s", "scaling": "weak", "ms_per_step": round(1e3 * e2 / args.steps, 3)}
@@ -367,34 +464,47 @@ def main():
         acc = {k: v for k, v in prof.items() if k.startswith("msm_accumulate")}
         dom = max(acc.items(), key=lambda kv: kv[1]["total_ms"]) if acc else None
         roofline = None
+        n = inst["n"]
         if dom:
             name, e = dom
+            g2 = name.endswith("g2")
             avg_ms = e["total_ms"] / e["launches"]
-            bytes_per_launch = e["algo_bytes"] / e["launches"]
+            bytes_per_launch = e["algo_bytes"] / e["launches"]          # 96 B (G1) / 160 B (G2) per (scalar, point) pair
+            pairs = bytes_per_launch / (160.0 if g2 else 96.0)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        # the committed PMC pass was taken on the default workload (2^20, one GPU): not applicable elsewhere
-                        "traffic": pmc_traffic(name) if (args.log_n == 20 and world == 1 and not args.window_bits) else None,
-                        "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch,
-                        "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
-                        "note": "integer-ALU-bound kernel (254-bit modular multiply); HBM fraction is low by construction, see DESIGN.md"}
-            # the bound that actually binds: VALU issue.  Algorithmic bytes per addition = 4 B index + 64 B point + the lane's
-            # share of its 160 B parked image (G1).  2242 wave-instructions per addition is the SQ_INSTS_VALU counter of this
-            # kernel divided by its additions (profiles/r1_pmc_valu.txt); 85 % of them are 64-bit / multiply class
-            # (v_mad_u64_u32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64), which tools/ubench_valu.hip measures at 483 G
-            # wave-instructions/s on the whole chip, the rest 32-bit class at 832 G/s: blended issue peak 515 G/s.
-            if name == "msm_accumulate_g1":
-                adds = bytes_per_launch / (4.0 + 64.0 + 160.0 / 32.0)
-                rate = adds / (avg_ms * 1e-3)
-                winst, peak = 2242.0, 1.0 / (0.85 / 483.0 + 0.15 / 832.0)
-                roofline["alu"] = {"additions_per_launch": round(adds), "G_additions_per_s": round(rate / 1e9, 2),
-                                   "valu_wave_instr_per_addition": winst, "G_wave_instr_per_s": round(rate / 64.0 * winst / 1e9, 1),
-                                   "valu_issue_peak_G_wave_instr_per_s": round(peak, 1),
-                                   "valu_issue_frac": round(rate / 64.0 * winst / 1e9 / peak, 3),
-                                   "note": "measured while sort / NTT / merge kernels of neighbouring products share the SIMDs; "
-                                           "stand-alone (--serialize --depth 1) the same kernel reaches 0.93"}
-        n = inst["n"]
+            c_used = args.window_bits or 17
+            windows = 254 // c_used + 1
+            gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
+            traffic = pmc_traffic(name) if (args.log_n == 20 and world == 1 and not args.window_bits) else None
+            winst, slow = ACC_INSTR[name]
+            adds = pairs * windows
+            g_inst = adds / (avg_ms * 1e-3) / 64.0 * winst / 1e9
+            peak_mix = 1.0 / (slow / VALU_PEAK_G["slow"] + (1.0 - slow) / VALU_PEAK_G["fast"])
+            meas_mix = 1.0 / (slow / VALU_MEASURED_G["slow"] + (1.0 - slow) / VALU_MEASURED_G["fast"])
+            roofline = {
+                # the roofline the metric names: SURVEY 8(d) algorithmic bytes of one launch / its event-timed duration against HBM
+                "bound": "valu", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / bytes_per_launch, 2) if traffic else None,
+                "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch, "pairs_per_launch": round(pairs),
+                "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
+                "implementation_bytes_per_launch": round(gathered),
+                "note": "frac is the HBM fraction SURVEY 8(d) defines (96 B per scalar-point pair in G1, 160 B in G2).  The kernel is not "
+                        "HBM-bound: it is bound by VALU issue (`valu` below).  It gathers one table entry per Pippenger window and pair "
+                        "(implementation_bytes = windows x (4 + 64|128) B x pairs + parked images), which is what `traffic` measures.",
+                # the bound that binds: wave-instructions issued per second against the issue ceiling of the instruction mix
+                "valu": {"achieved": round(g_inst, 1), "unit": "G wave-instr/s", "peak": round(peak_mix, 1), "frac": round(g_inst / peak_mix, 3),
+                         "peak_measured_ubench": round(meas_mix, 1), "frac_of_measured_peak": round(g_inst / meas_mix, 3),
+                         "additions_per_launch": round(adds), "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
+                         "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
+                         "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
+                                 "tools/ubench_valu.hip sustains (585 / 1062 G/s).  Under this kernel the chip clocks at ~1.93 GHz "
+                                 "(GRBM_GUI_ACTIVE / duration, profiles/r2_pmc_acc.txt), i.e. at the sustained clock the issue fraction is "
+                                 "frac x 2.4 / 1.93; other kernels of the pipeline share the SIMDs during this measurement"},
+                "whole_proof": {"algorithmic_bytes": 1404.0 * n, "achieved_GBps": round(1404.0 * n * value / 1e9, 2),
+                                "frac": round(1404.0 * n * value / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
+                                "note": "SURVEY 8(d): 1404 n bytes per proof; per GPU"},
+            }
         out = {
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -404,8 +514,8 @@ def main():
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM"
                                    % (args.log_n, m),
                        "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("point-range" if args.shard == "points" else "window", world)) if shard
-                                      else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums; "
-                                            "a step = one round of %d proofs" % (world, world)) if exchange
+                                      else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums (%s); "
+                                            "a step = one round of %d proofs" % (world, "zk_comm / zk_mgpu inside libzkgpu.so" if use_zk else "torch.distributed", world)) if exchange
                                       else ("replicas x%d" % world),
                        "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
@@ -415,9 +525,13 @@ def main():
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(zk, ctx, args.seed)
+            out["cpu_baseline"] = cpu_baseline(zk, ctx, args.seed, inst, args.cpu_baseline == "full")
             out["cpu_baseline"]["cores_on_host"] = os.cpu_count()
         print(json.dumps(out))
+    if mprover is not None and state["degraded"] is None:
+        mprover.close()
+    if comm is not None:
+        comm.close()
     if dist:
         dist.destroy_process_group()
 

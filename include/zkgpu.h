@@ -44,7 +44,8 @@ typedef enum {
     ZK_ERR_DIV_BY_ZERO = -5,  /* "Dividend must be non-zero" (field/mod.rs:440) / Fr inverse of 0 (fr.rs:54,69) */
     ZK_ERR_RANGE = -6,        /* an Fr/Fq input is >= its modulus */
     ZK_ERR_UNSUPPORTED = -7,
-    ZK_ERR_IO = -8            /* file missing, truncated, altered or not in the expected format */
+    ZK_ERR_IO = -8,           /* file missing, truncated, altered or not in the expected format */
+    ZK_ERR_COMM = -9          /* a collective failed (RCCL error or the caller's transport returned non-zero) */
 } zk_status;
 
 #define ZK_PROOF_BYTES 259
@@ -278,6 +279,76 @@ int zk_prove_scalars_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, c
  * One ticket for the batch; finish with zk_prove_wait(ctx, ticket, NULL). */
 int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int sets, int rank, int world,
                         const void* d_l, const void* d_v, const void* d_u, const void* d_h, void* d_partials_out, int* ticket);
+
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs ("one context owns 1..8 devices"; 8e).  The reference's groth16::prove
+ * (groth16/mod.rs:213-217) is one call on one thread; its inner products (mod.rs:255-272,279-290) are sums of
+ * independent terms and shard over GPUs.  One process per GPU, each with its own zk_ctx; a zk_comm joins them: RCCL over
+ * xGMI (libzkgpu.so links librccl), or a transport supplied by the caller as function pointers.
+ * ---------------------------------------------------------------------------------------- */
+int zk_device_count(void);
+#define ZK_COMM_ID_BYTES 128
+typedef struct zk_comm zk_comm;
+/* Rank 0 draws the id (ncclGetUniqueId) and ships the bytes to the other ranks by any channel (file, TCP store, MPI). */
+int zk_comm_unique_id(uint8_t id_out[ZK_COMM_ID_BYTES]);
+/* Collective: every rank calls it with the same id and its own rank (ncclCommInitRank on ctx's device).  world == 1
+ * needs no id and no RCCL. */
+int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world, zk_comm** out);
+/* Caller-supplied transport.  Buffers are the ones the prover allocated (device memory with the GPU backend); the calls
+ * are blocking: complete on return.  all_to_all: chunk g of `send` (bytes_per_rank bytes) goes to rank g, chunk j of `recv`
+ * comes from rank j.  all_gather: `send` (bytes_per_rank) from every rank, in rank order, into `recv`.  barrier / max_f64
+ * may be NULL (zk_comm_barrier / zk_comm_max_f64 then return ZK_ERR_UNSUPPORTED).  Non-zero return = failure. */
+typedef struct {
+    void* user;
+    int (*all_to_all)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+    int (*barrier)(void* user);
+    int (*max_f64)(void* user, double* value);
+} zk_comm_ops;
+int zk_comm_init_custom(zk_ctx* ctx /* may be NULL */, const zk_comm_ops* ops, int rank, int world, zk_comm** out);
+void zk_comm_destroy(zk_comm* comm);
+int zk_comm_rank(const zk_comm* comm);
+int zk_comm_world(const zk_comm* comm);
+int zk_comm_barrier(zk_comm* comm);
+int zk_comm_max_f64(zk_comm* comm, double* value);      /* *value = max over the ranks (timing of the slowest rank) */
+int zk_comm_all_to_all(zk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);   /* complete on return */
+int zk_comm_all_gather(zk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+
+/* Latency form -- ONE groth16::prove over all ranks: every rank holds the same witness, recomputes the SpMV / NTT stage,
+ * accumulates its share of the four inner products (zk_prove_partial: Pippenger windows w = rank (mod world), or point
+ * ranges with the option msm_shard_points), one 768-byte all-gather, and every rank assembles the same 259 bytes. */
+int zk_mgpu_prove_sharded(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                          const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+
+/* Throughput form -- the scalar exchange of zk_prove_scalars_submit / zk_prove_msm_submit as a software pipeline inside the
+ * library.  A ROUND is `world` proofs, one per rank: zk_mgpu_push hands in THIS rank's proof of the next round (its own
+ * witness and (r, s)), zk_mgpu_pop returns THIS rank's proof of the oldest round.  Both are collective: every rank makes
+ * the same sequence of push / pop calls.  At most three rounds may be pushed and not yet popped; pushing two rounds ahead
+ * of every pop (push, push, push, pop, push, pop, ...) keeps the SpMV / NTT stage two rounds ahead of the inner products, so
+ * that neither the exchanges nor the host waits leave a GPU idle; push / pop strictly alternating is the one-round-at-a-time
+ * (latency) schedule.  Per-GPU work per round is one whole proof's worth whatever `world` is.  Sparse (roots-of-unity)
+ * QAP form only. */
+typedef struct zk_mgpu zk_mgpu;
+int zk_mgpu_create(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out);
+int zk_mgpu_push(zk_mgpu* p, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]);
+int zk_mgpu_pop(zk_mgpu* p, uint8_t proof_out[ZK_PROOF_BYTES]);
+void zk_mgpu_destroy(zk_mgpu* p);
+const char* zk_mgpu_last_error(const zk_mgpu* p);
+/* The pipeline over caller-supplied stages (tests: CPU stand-ins + a gloo transport exercise the schedule and the order of
+ * the collectives without a GPU).  elems: sizes of the four exchange arrays in 32-byte elements (multiples of world);
+ * scalars_submit writes `world` equal chunks into send[0..3]; msm_submit consumes recv[0..3] (chunk j = proof j) and writes
+ * `sets` blobs of ZK_PARTIAL_BYTES; wait completes a ticket; combine assembles from the `world` blobs returned to the owner. */
+typedef struct {
+    void* user;
+    int (*elems)(void* user, int world, size_t elems_out[4]);
+    void* (*alloc)(void* user, size_t bytes);
+    void (*free)(void* user, void* p);
+    int (*scalars_submit)(void* user, const void* weights, size_t m, const uint64_t r[4], const uint64_t s[4], int world, void* const send[4], int* ticket);
+    int (*msm_submit)(void* user, int sets, int rank, int world, void* const recv[4], void* partials_out, int* ticket);
+    int (*wait)(void* user, int ticket);
+    int (*combine)(void* user, const void* partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);
+} zk_mgpu_backend;
+int zk_mgpu_create_custom(zk_comm* comm, const zk_mgpu_backend* backend, zk_mgpu** out);
 
 /* ------------------------------------------------------------------------------------------
  * verify  (groth16::verify, groth16/mod.rs:299-320) -- host code, as in the reference

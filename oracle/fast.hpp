@@ -237,25 +237,71 @@ inline BnCrs fast_setup(const SparseQap& q, const Trapdoor<Fr>& td) {
 template <class F>
 std::vector<Affine<F>> to_affine_vec(const std::vector<Jac<F>>& v, size_t count) {
     std::vector<Affine<F>> out;
-    for (size_t i = 0; i < std::min(count, v.size()); ++i) out.push_back(v[i].to_affine());
+    for (size_t i = 0; i < std::min(count, v.size()); ++i)
+        out.push_back(!v[i].is_zero() && v[i].Z == F::one() ? Affine<F>{v[i].X, v[i].Y, false} : v[i].to_affine());   // Z = 1: no inversion
     return out;
 }
 
 struct FastProveStats { double t_eval = 0, t_ntt = 0, t_msm = 0; };
 
+// One window of a Pippenger MSM: sum_b b * (sum of the points whose c-bit digit at bit `lo` is b), unsigned digits.
+template <class F>
+Jac<F> msm_window(const std::vector<Affine<F>>& pts, const std::vector<U256>& sc, unsigned c, unsigned lo) {
+    const size_t n = std::min(pts.size(), sc.size());
+    std::vector<Jac<F>> buckets((size_t)1 << c, Jac<F>::zero());
+    const uint64_t mask = ((uint64_t)1 << c) - 1;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned word = lo >> 6, off = lo & 63;
+        uint64_t d = word < 4 ? sc[i].l[word] >> off : 0;
+        if (off + c > 64 && word + 1 < 4) d |= sc[i].l[word + 1] << (64 - off);
+        d &= mask;
+        if (d) buckets[d] = madd(buckets[d], pts[i]);
+    }
+    Jac<F> run = Jac<F>::zero(), acc = Jac<F>::zero();
+    for (size_t b = buckets.size() - 1; b >= 1; --b) { run = run + buckets[b]; acc = acc + run; }
+    return acc;
+}
+template <class F>
+Jac<F> msm_combine(const std::vector<Jac<F>>& wsum, unsigned c) {
+    Jac<F> total = Jac<F>::zero();
+    for (int w = (int)wsum.size() - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < c; ++k) total = total.dbl();
+        total = total + wsum[w];
+    }
+    return total;
+}
+
+// The CRS as prove() reads it, in affine form (what the CPU path needs for mixed additions).  Built once per CRS, outside any
+// timed region: the reference, too, holds its CRS ready-made (it clones vectors of points, groth16/mod.rs:282,288).
+struct FastCrs {
+    std::vector<Affine<Fq>> xi1, xit, sdl;
+    std::vector<Affine<Fq2>> xi2;
+    const BnCrs* crs = nullptr;
+    FastCrs(const BnCrs& c, size_t n) : crs(&c) {
+        xi1 = to_affine_vec(c.s1.xi, n); xi2 = to_affine_vec(c.s2.xi, n);
+        xit = to_affine_vec(c.s1.xi_t, n); sdl = to_affine_vec(c.s1.sum_delta, (size_t)-1);
+    }
+};
+
 // prove for a SparseQap: NTT for interpolation / product, exact division by t = x^n - 1,
 // Pippenger for the five inner products.  Same group elements as prove_with_rs.
-inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std::vector<Fr>& weights,
+// threads > 1: the NTT stages are split over the workers and the (inner product, window) pairs of the five Pippenger sums are
+// ONE task list pulled from an atomic counter, G2 windows first (they cost ~3x a G1 window) -- 5 x ceil(256 / c) tasks.
+inline Proof<G1, G2> fast_prove(const SparseQap& q, const FastCrs& fc, const std::vector<Fr>& weights,
                                 const Fr& r, const Fr& s, unsigned c = 0, unsigned threads = 1) {
+    const BnCrs& crs = *fc.crs;
     size_t n = q.n();
-    if (c == 0) c = q.log_n <= 8 ? 4 : (q.log_n <= 14 ? q.log_n - 4 : 12);
+    if (c == 0) c = q.log_n <= 8 ? 4 : (q.log_n <= 14 ? q.log_n - 4 : std::min(16u, q.log_n - 3));
     std::vector<Fr> U = q.eval_vec(q.u, weights), V = q.eval_vec(q.v, weights), W = q.eval_vec(q.w, weights);
     fr_ntt(U, q.log_n, true, threads); fr_ntt(V, q.log_n, true, threads); fr_ntt(W, q.log_n, true, threads);   // coefficient form
     // product on a domain of size 2n
     std::vector<Fr> A = U, B = V;
     A.resize(2 * n, Fr::zero()); B.resize(2 * n, Fr::zero());
     fr_ntt(A, q.log_n + 1, false, threads); fr_ntt(B, q.log_n + 1, false, threads);
-    for (size_t i = 0; i < 2 * n; ++i) A[i] = A[i] * B[i];
+    parallel_for(threads > 1 ? 64 : 1, threads, [&](size_t blk) {
+        const size_t per = (2 * n + 63) / 64, lo = threads > 1 ? blk * per : 0, hi = threads > 1 ? std::min(2 * n, lo + per) : 2 * n;
+        for (size_t i = lo; i < hi; ++i) A[i] = A[i] * B[i];
+    });
     fr_ntt(A, q.log_n + 1, true, threads);
     for (size_t i = 0; i < n; ++i) A[i] = A[i] - W[i];           // P = U*V - W, deg <= 2n-2
     // long division by x^n - 1: q_k = r_{k+n}, r_k += r_{k+n}, top down
@@ -263,26 +309,30 @@ inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std:
     for (size_t k = 2 * n - 1; k >= n; --k) { if (k - n < h.size()) h[k - n] = A[k]; A[k - n] = A[k - n] + A[k]; }
     auto scal = [](const std::vector<Fr>& v, size_t cnt) {
         std::vector<U256> out; for (size_t i = 0; i < std::min(cnt, v.size()); ++i) out.push_back(v[i].to_u256()); return out; };
-    auto xi1 = to_affine_vec(crs.s1.xi, n);
-    auto xi2 = to_affine_vec(crs.s2.xi, n);
     std::vector<Fr> wl(weights.begin() + std::min(weights.size(), q.input + 1), weights.end());
-    auto xit = to_affine_vec(crs.s1.xi_t, n), sdl = to_affine_vec(crs.s1.sum_delta, (size_t)-1);
     auto su = scal(U, n), sv = scal(V, n), sh = scal(h, n), sl = scal(wl, (size_t)-1);
-    G1 a_g1, b_g1, c_h, c_l;
-    G2 b_g2;
-    // the five inner products are independent: with threads > 1 each gets a share of the workers
-    const unsigned per = threads > 1 ? std::max(1u, threads / 5) : 1;
-    parallel_for(5, threads > 1 ? 5 : 1, [&](size_t k) {
-        if (k == 0) a_g1 = msm_pippenger(xi1, su, c, per);
-        if (k == 1) b_g1 = msm_pippenger(xi1, sv, c, per);
-        if (k == 2) b_g2 = msm_pippenger(xi2, sv, c, per);
-        if (k == 3) c_h = msm_pippenger(xit, sh, c, per);
-        if (k == 4) c_l = msm_pippenger(sdl, sl, c, per);
+    const unsigned windows = (256 + c - 1) / c;
+    std::vector<Jac<Fq>> wa(windows, Jac<Fq>::zero()), wb1 = wa, wh = wa, wl_ = wa;
+    std::vector<Jac<Fq2>> wb2(windows, Jac<Fq2>::zero());
+    parallel_for((size_t)5 * windows, threads, [&](size_t t) {
+        const unsigned k = (unsigned)(t / windows), w = (unsigned)(t % windows), lo = w * c;
+        if (k == 0) wb2[w] = msm_window(fc.xi2, sv, c, lo);
+        if (k == 1) wl_[w] = msm_window(fc.sdl, sl, c, lo);
+        if (k == 2) wa[w] = msm_window(fc.xi1, su, c, lo);
+        if (k == 3) wb1[w] = msm_window(fc.xi1, sv, c, lo);
+        if (k == 4) wh[w] = msm_window(fc.xit, sh, c, lo);
     });
+    G1 a_g1 = msm_combine(wa, c), b_g1 = msm_combine(wb1, c), c_h = msm_combine(wh, c), c_l = msm_combine(wl_, c);
+    G2 b_g2 = msm_combine(wb2, c);
     G1 a = a_g1 + crs.s1.alpha + crs.s1.delta.mul(r);
     G2 b = b_g2 + crs.s2.beta + crs.s2.delta.mul(s);
     G1 cc = c_h + c_l + a.mul(s) + (crs.s1.beta + b_g1 + crs.s1.delta.mul(s)).mul(r) - crs.s1.delta.mul(r * s);
     return Proof<G1, G2>{a, b, cc};
+}
+inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std::vector<Fr>& weights,
+                                const Fr& r, const Fr& s, unsigned c = 0, unsigned threads = 1) {
+    FastCrs fc(crs, q.n());
+    return fast_prove(q, fc, weights, r, s, c, threads);
 }
 
 // Closed-form honest proof for a SparseQap (O(n) field work; usable at n = 2^20).

@@ -82,6 +82,36 @@ DummyRep<Fr> sparse_to_root_rep(const SparseQap& q) {
     rr.u = conv(q.u); rr.v = conv(q.v); rr.w = conv(q.w);
     return rr;
 }
+// The dense QAP<CoefficientPoly<Fr>> that QAP::from(root_rep) (fr.rs:140-173) produces for the roots w^j, built in O(nnz n)
+// instead of the reference's O(nnz n^2) Lagrange sums: on that domain L_j(x) = (1/n) sum_k w^(-jk) x^k.  Same polynomials, same
+// representation (n coefficients for a non-empty row, the empty sum for an empty one; t = x^n - 1 = root_poly(roots)): QAP
+// construction is not part of prove(), this only makes the FAITHFUL prove measurable up to 2^12 gates.
+QAP<Fr> qap_dense_unity(const SparseQap& q) {
+    const size_t n = q.n();
+    const std::vector<Fr> wp = powers(fr_root_of_unity((int)q.log_n).inv(), n);   // w^-t
+    const Fr ninv = Fr::from_u64(n).inv();
+    QAP<Fr> out;
+    auto rows = [&](const SparseMat& M) {
+        std::vector<Coeffs<Fr>> r(q.m);
+        for (size_t i = 0; i < q.m; ++i) {
+            if (M.ptr[i] == M.ptr[i + 1]) { r[i] = poly_sum(std::vector<Coeffs<Fr>>{}); continue; }
+            Coeffs<Fr> c(n, Fr::zero());
+            for (size_t e = M.ptr[i]; e < M.ptr[i + 1]; ++e) {
+                const Fr v = M.val[e] * ninv;
+                const size_t j = M.gate[e];
+                for (size_t k = 0; k < n; ++k) c[k] = c[k] + v * wp[(j * k) & (n - 1)];
+            }
+            r[i] = c;
+        }
+        return r;
+    };
+    out.u = rows(q.u); out.v = rows(q.v); out.w = rows(q.w);
+    out.t = Coeffs<Fr>(n + 1, Fr::zero());
+    out.t[0] = -Fr::one(); out.t[n] = Fr::one();
+    out.input = q.input;
+    out.degree = n;
+    return out;
+}
 QAP<Fr> rd_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input) {
     QAP<Fr> q;
     auto rows = [&](const uint64_t* src) {
@@ -311,11 +341,19 @@ double orc_time_prove_sparse(const zk_qap_sparse_desc* d, const zk_crs_desc* crs
     BnCrs c = rd_crs(crs);
     auto wts = rd_frs(weights, m_w);
     QAP<Fr> qap;
-    if (faithful) qap = qap_from_root_rep(sparse_to_root_rep(q));   // QAP construction is not part of prove()
+    if (faithful) {   // QAP construction is not part of prove(); the reference's own construction (Lagrange sums) up to 2^6 gates
+        qap = qap_dense_unity(q);
+        if (q.log_n <= 6) {
+            QAP<Fr> ref = qap_from_root_rep(sparse_to_root_rep(q));
+            if (!(ref.u == qap.u && ref.v == qap.v && ref.w == qap.w && ref.t == qap.t && ref.degree == qap.degree))
+                throw std::logic_error("qap_dense_unity differs from QAP::from(root_rep)");
+        }
+    }
+    FastCrs fc(c, faithful ? 0 : q.n());                             // neither is the CRS (affine form held ready)
     auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < reps; ++k) {
         if (faithful) wr_proof(prove_with_rs<BnEngine>(qap, c.s1, c.s2, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
-        else wr_proof(fast_prove(q, c, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+        else wr_proof(fast_prove(q, fc, wts, rd_f<Fr>(r), rd_f<Fr>(s)), proof);
     }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
@@ -370,8 +408,9 @@ double orc_time_prove_sparse_mt(const zk_qap_sparse_desc* d, const zk_crs_desc* 
     SparseQap q = rd_sparse(d);
     BnCrs c = rd_crs(crs);
     auto wts = rd_frs(weights, m_w);
+    FastCrs fc(c, q.n());
     auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < reps; ++k) wr_proof(fast_prove(q, c, wts, rd_f<Fr>(r), rd_f<Fr>(s), 0, (unsigned)std::max(1, threads)), proof);
+    for (int k = 0; k < reps; ++k) wr_proof(fast_prove(q, fc, wts, rd_f<Fr>(r), rd_f<Fr>(s), 0, (unsigned)std::max(1, threads)), proof);
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 

@@ -41,3 +41,50 @@ def test_reference_tests_through_cpp_api(tmp_path):
     for name in ("simple_circuit_test", "single_mult_honest_bn", "bn_encrypt_quad_test", "bn_encrypt_cubic_test",
                  "bn_encrypt_deg_15_test", "error_behaviour"):
         assert "ok " + name in res.stdout, res.stdout + res.stderr
+
+
+# ---- the Rust shim's call sequences (bindings/rust/src/gpu.rs), executed from C ----
+SHIM_SRC = os.path.join(ROOT, "tests", "cpp", "rust_shim_sequence.c")
+
+
+def build_shim(out_dir):
+    exe = os.path.join(str(out_dir), "rust_shim_sequence")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SHIM_SRC, "-o", exe,
+           "-L", LIBDIR, "-lzkgpu", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_rust_shim_sequence_compiles_and_links(tmp_path):
+    """plain C against include/zkgpu.h: every entry point and struct layout the shim binds exists with that signature"""
+    try:
+        exe = build_shim(tmp_path)
+    except subprocess.CalledProcessError as e:
+        pytest.fail("gcc failed:\n" + e.stderr[-3000:])
+    assert os.path.exists(exe)
+    # the extern block of the shim names nothing the header does not declare
+    import re
+    shim = open(os.path.join(ROOT, "bindings", "rust", "src", "gpu.rs")).read()
+    header = open(os.path.join(ROOT, "include", "zkgpu.h")).read()
+    for fn in re.findall(r"\bfn (zk_[a-z0-9_]+)\(", shim):
+        assert re.search(r"\b%s\s*\(" % fn, header), fn
+    # the byte conversions run before the first device call: checked here on the CPU as well
+    res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zk", "simple.zk")] + g2_generator_packed(), capture_output=True, text=True, timeout=120)
+    assert "ok byte_conversions" in res.stdout, res.stdout + res.stderr
+
+
+def g2_generator_packed():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyref
+    (x0, x1), (y0, y1) = pyref.G2_GEN
+    return ["%0128x" % (c1 * pyref.Q + c0) for c0, c1 in ((x0, x1), (y0, y1))]     # bn's Fq2 packing (SURVEY 8a row P)
+
+
+@pytest.mark.gpu
+def test_rust_shim_sequence_on_the_gpu(tmp_path):
+    exe = build_shim(tmp_path)
+    res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zk", "simple.zk")] + g2_generator_packed(), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for name in ("byte_conversions", "setup", "prove", "verify", "prove_stream", "from_root_rep"):
+        assert "ok " + name in res.stdout, res.stdout + res.stderr

@@ -173,11 +173,108 @@ def _worker(rank, world, port, q):
     my_want = [pyref.enc_proof(*pyref.prove_with_rs(qap, s1, s2, my_wts, rr, ss)) for rr, ss in my_jobs]
     exchanged = list(prove_exchange_stream(CpuExchangeProver(my_wts), dist, rank, world, my_jobs))
 
+    # the SAME stand-ins under the pipeline that now lives inside libzkgpu.so (csrc/comm.hip: zk_mgpu_create_custom / push / pop)
+    # with gloo as the caller-supplied transport (zk_comm_init_custom): schedule, buffer rotation and the order of the collectives
+    import ctypes as C
+    from zksnark_rs_amd import _lib
+    from zksnark_rs_amd.distributed import Comm, MgpuProver
+    keep = {}
+
+    def view(addr):
+        return torch.from_numpy(keep[addr])
+
+    def words(ptr):
+        return sum(int(ptr[i]) << (64 * i) for i in range(4))
+
+    stand_in = CpuExchangeProver(my_wts)
+    calls = []
+
+    def be_elems(user, w, out):
+        for k, c in enumerate(stand_in.chunk):
+            out[k] = c * w
+        return 0
+
+    def be_alloc(user, nbytes):
+        a = np.zeros(max(nbytes, 1), np.uint8)
+        keep[a.ctypes.data] = a
+        return a.ctypes.data
+
+    def be_free(user, ptr):
+        keep.pop(ptr, None)
+
+    def be_scalars(user, wptr, m, rp, sp, w, send, ticket):
+        calls.append("A")
+        stand_in.scalars_submit(words(rp), words(sp), w, [view(send[k]) for k in range(4)])
+        ticket[0] = 0
+        return 0
+
+    def be_msm(user, sets, rk, w, recv, part, ticket):
+        calls.append("B")
+        stand_in.msm_submit(sets, rk, w, [view(recv[k]) for k in range(4)], view(part))
+        ticket[0] = 1
+        return 0
+
+    def be_wait(user, ticket):
+        return 0
+
+    def be_combine(user, part, w, rp, sp, out):
+        calls.append("F")
+        proof = stand_in.combine_own(view(part), w, words(rp), words(sp))
+        C.memmove(out, proof, len(proof))
+        return 0
+
+    def op_a2a(user, send, recv, per_rank):
+        dist.all_to_all_single(view(recv), view(send))
+        return 0
+
+    def op_gather(user, send, recv, per_rank):
+        dist.all_gather_into_tensor(view(recv), view(send))
+        return 0
+
+    def op_barrier(user):
+        dist.barrier()
+        return 0
+
+    def op_max(user, val):
+        t = torch.tensor([val[0]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        val[0] = float(t.item())
+        return 0
+
+    ops = _lib.CommOps(None, _lib.A2A_FN(op_a2a), _lib.A2A_FN(op_gather), _lib.BARRIER_FN(op_barrier), _lib.MAXF64_FN(op_max))
+    backend = _lib.MgpuBackend(None, _lib.ELEMS_FN(be_elems), _lib.ALLOC_FN(be_alloc), _lib.FREE_FN(be_free), _lib.SCALARS_FN(be_scalars),
+                               _lib.MSM_FN(be_msm), _lib.WAIT_FN(be_wait), _lib.COMBINE_FN(be_combine))
+    comm = Comm(None, rank, world, ops=ops)
+    assert comm.max_f64(float(rank)) == float(world - 1)
+    comm.barrier()
+    dummy = np.zeros(4, np.uint64)
+    abi_ok = True
+    for ahead, order in ((2, "AABABFABFBFF"), (0, "ABFABFABFABF"), (1, "AABBFABFABFF")):
+        del calls[:]
+        prover = MgpuProver(None, comm, backend=backend)
+        got_abi = list(prover.prove_stream([(dummy.ctypes.data, len(my_wts), rr, ss) for rr, ss in my_jobs], ahead=ahead))
+        if got_abi != my_want or "".join(calls) != order:
+            print("rank", rank, "ahead", ahead, "proofs equal", got_abi == my_want, "calls", "".join(calls), "expected", order, flush=True)
+        abi_ok = abi_ok and got_abi == my_want and "".join(calls) == order
+        # a fourth round in flight is refused before anything is enqueued
+        if ahead == 2:
+            for rr, ss in my_jobs[:3]:
+                prover.push(dummy.ctypes.data, len(my_wts), rr, ss)
+            try:
+                prover.push(dummy.ctypes.data, len(my_wts), *my_jobs[3])
+                abi_ok = False
+            except Exception:
+                pass
+            abi_ok = abi_ok and [prover.pop() for _ in range(3)] == my_want[:3]
+        prover.close()
+    assert not keep or all(isinstance(v, np.ndarray) for v in keep.values())
+    comm.close()
+
     got = prove_sharded(CpuProver(), dist, rank, world, r, s)
     # pipelined driver: three proofs in a row through the two-deep pipeline, same bytes each
     from zksnark_rs_amd.distributed import prove_sharded_stream
     streamed = list(prove_sharded_stream(CpuProver(), dist, rank, world, [(r, s)] * 3))
-    q.put((rank, got == want and streamed == [want] * 3 and exchanged == my_want))
+    q.put((rank, got == want and streamed == [want] * 3 and exchanged == my_want and abi_ok))
     dist.destroy_process_group()
 
 

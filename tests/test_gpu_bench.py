@@ -31,16 +31,21 @@ def test_bench_line_single_gpu():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
 
 
-@pytest.mark.parametrize("mode,shard", [("exchange", "points"), ("shard", "points"), ("shard", "windows")])
-def test_bench_line_two_ranks_on_one_gpu(mode, shard):
+@pytest.mark.parametrize("mode,shard,transport", [("exchange", "points", "zk-gloo"), ("shard", "points", "zk-gloo"), ("shard", "windows", "zk-gloo"),
+                                                  ("exchange", "points", "torch"), ("shard", "points", "torch")])
+def test_bench_line_two_ranks_on_one_gpu(mode, shard, transport):
+    """zk-gloo: the pipeline and collectives inside libzkgpu.so (zk_mgpu_*, zk_comm_* with a caller-supplied gloo transport);
+    torch: the round-1 Python driver over torch.distributed"""
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--log-n", "12", "--backend", "gloo", "--mode", mode, "--shard", shard]
+           "--log-n", "12", "--backend", "gloo", "--mode", mode, "--shard", shard, "--transport", transport]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     d = last_json_line(res.stdout)
     assert KEYS <= set(d)
+    if mode == "exchange":
+        assert ("inside libzkgpu.so" in d["config"]["parallelism"]) == (transport == "zk-gloo")
     assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if mode == "shard" else "weak") and d["value"] > 0
     assert d["replicas"]["value"] > 0 and d["replicas"]["scaling"] == "weak"
 

@@ -78,7 +78,9 @@ def test_mont_sqr_and_mont_diff_at_the_limb_bounds(ctx, field):
     got = run(ctx, field, SQR, B29)
     assert got == [value(a) ** 2 * rinv % p for a in B29]
     quads = [(B29[i], B29[(i * 7 + 1) % len(B29)], B29[(i * 5 + 2) % len(B29)], B29[(i * 3 + 3) % len(B29)]) for i in range(len(B29))]
-    quads += [([M29] * 9, [M29] * 9, [M29] * 9, [-M29] * 9), ([-M29] * 9, [M29] * 9, [M29] * 9, [M29] * 9)]   # both products with the same sign
+    hi, lo = B29[0], B29[1]            # every low limb at +(2^29 - 1) / -(2^29 - 1), top limb at the value bound
+    neg = [-x for x in hi]
+    quads += [(hi, hi, hi, neg), (neg, hi, hi, hi), (lo, lo, hi, neg)]   # both products with the same sign: 18 column terms add up
     got, raw = run(ctx, field, MONT_DIFF, *[[q[k] for q in quads] for k in range(4)], raw=True)
     for q, g, r in zip(quads, got, raw):
         assert g == (value(q[0]) * value(q[1]) - value(q[2]) * value(q[3])) * rinv % p

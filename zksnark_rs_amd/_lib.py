@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("ZKGPU_LIB") or os.path.join(_HERE, "libzkgpu.so")   #
 
 ZK_OK = 0
 ZK_ERR_ARG, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_SIZE, ZK_ERR_DIV_BY_ZERO, ZK_ERR_RANGE, ZK_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+ZK_ERR_IO, ZK_ERR_COMM = -8, -9
+COMM_ID_BYTES = 128
 PROOF_BYTES = 259
 PARTIAL_BYTES = 768
 MAX_IN_FLIGHT = 4      # ZK_MAX_IN_FLIGHT
@@ -42,6 +44,30 @@ class CrsOut(C.Structure):
     _fields_ = [("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p), ("xi_g1", u64p),
                 ("sum_gamma_g1", u64p), ("sum_delta_g1", u64p), ("xi_t_g1", u64p),
                 ("beta_g2", u64p), ("gamma_g2", u64p), ("delta_g2", u64p), ("xi_g2", u64p)]
+
+
+# zk_comm_ops / zk_mgpu_backend: tables of C callbacks (tests plug gloo and CPU stand-ins in here)
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+MAXF64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+
+class CommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all", A2A_FN), ("all_gather", A2A_FN), ("barrier", BARRIER_FN), ("max_f64", MAXF64_FN)]
+
+
+ELEMS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_size_t))
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+SCALARS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int))
+MSM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int))
+WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+COMBINE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p)
+
+
+class MgpuBackend(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("elems", ELEMS_FN), ("alloc", ALLOC_FN), ("free", FREE_FN), ("scalars_submit", SCALARS_FN),
+                ("msm_submit", MSM_FN), ("wait", WAIT_FN), ("combine", COMBINE_FN)]
 
 
 # every symbol include/zkgpu.h declares: (restype, argtypes)
@@ -100,6 +126,24 @@ SIGNATURES = {
     "zk_prove_msm_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
+    "zk_device_count": (C.c_int, []),
+    "zk_comm_unique_id": (C.c_int, [u8p]),
+    "zk_comm_init": (C.c_int, [C.c_void_p, u8p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_comm_init_custom": (C.c_int, [C.c_void_p, C.POINTER(CommOps), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_comm_destroy": (None, [C.c_void_p]),
+    "zk_comm_rank": (C.c_int, [C.c_void_p]),
+    "zk_comm_world": (C.c_int, [C.c_void_p]),
+    "zk_comm_barrier": (C.c_int, [C.c_void_p]),
+    "zk_comm_max_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "zk_comm_all_to_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zk_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zk_mgpu_prove_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, u8p]),
+    "zk_mgpu_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "zk_mgpu_create_custom": (C.c_int, [C.c_void_p, C.POINTER(MgpuBackend), C.POINTER(C.c_void_p)]),
+    "zk_mgpu_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p]),
+    "zk_mgpu_pop": (C.c_int, [C.c_void_p, u8p]),
+    "zk_mgpu_destroy": (None, [C.c_void_p]),
+    "zk_mgpu_last_error": (C.c_char_p, [C.c_void_p]),
     "zk_verify": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, u8p, C.POINTER(C.c_int)]),
     "zk_pairing": (C.c_int, [u64p, u64p, u64p]),
     "zk_profile_reset": (C.c_int, [C.c_void_p]),

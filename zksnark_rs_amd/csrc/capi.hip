@@ -20,6 +20,7 @@ const char* zk_strerror(int status) {
         case ZK_ERR_RANGE: return "field element out of range";
         case ZK_ERR_UNSUPPORTED: return "unsupported";
         case ZK_ERR_IO: return "file missing, truncated, altered or in the wrong format";
+        case ZK_ERR_COMM: return "collective failed";
         default: return "unknown status";
     }
 }
@@ -50,9 +51,19 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         ZK_HIP(hipStreamCreateWithPriority(&ctx->finish, hipStreamNonBlocking, prio_greatest));
         ZK_HIP(hipStreamCreateWithPriority(&ctx->main_alt, hipStreamNonBlocking, prio_greatest));
         msm_init_attributes();
+        // Streams share hardware queues per priority level (4 each by default): a FIFTH stream of a level shares a queue with another
+        // one and serialises with it (measured: reduction tails on two extra low-priority streams -27 %, the G2 product alternating
+        // onto a fifth MSM stream -5 %; at a level of their own: no loss).  Three levels are used:
+        //   high  main / alternate main (SpMV + NTT stage), side (r, s multiples), finish (join, assembly, copy-out)
+        //   mid   one stream per inner product: its sort and its reduction tail (+ two optional tail streams)
+        //   low   ONE stream for every bucket accumulation -- the only kernels that fill the chip for milliseconds; at the lowest level
+        //         their thousands of pending workgroups never stand in front of a short dependent kernel in the dispatcher
+        const int prio_mid = (prio_least + prio_greatest) / 2;
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
-            ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_least));
+            ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_mid));
         }
+        ZK_HIP(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_least));
+        for (int i = 0; i < 2; ++i) ZK_HIP(hipStreamCreateWithPriority(&ctx->tail_stream[i], hipStreamNonBlocking, prio_mid));
     });
     if (rc != ZK_OK) { zk_ctx_destroy(ctx); return rc; }   // destroys whatever streams were created before the failure
     *out = ctx;
@@ -69,6 +80,9 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     ctx->msm_ws0.reset();
     for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i)
         if (ctx->msm_stream[i]) (void)hipStreamDestroy(ctx->msm_stream[i]);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->tail_stream[i]) (void)hipStreamDestroy(ctx->tail_stream[i]);
+    if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
     if (ctx->finish) (void)hipStreamDestroy(ctx->finish);
     if (ctx->main_alt) (void)hipStreamDestroy(ctx->main_alt);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -85,6 +99,10 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "profile")) return &ctx->opt_profile;
     if (!std::strcmp(key, "msm_lane_entries")) return &ctx->opt_lane_entries;
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;
+    if (!std::strcmp(key, "msm_fold")) return &ctx->opt_fold;
+    if (!std::strcmp(key, "msm_tail_streams")) return &ctx->opt_tail_streams;
+    if (!std::strcmp(key, "msm_alt_g2")) return &ctx->opt_alt_g2;
+    if (!std::strcmp(key, "msm_acc_stream")) return &ctx->opt_acc_stream;
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
     return nullptr;

@@ -1,0 +1,367 @@
+// comm.hip -- several GPUs behind the C ABI (SURVEY.md 8b "one context owns 1..8 devices", 8e).
+//
+// The reference's groth16::prove (/root/reference/src/groth16/mod.rs:213-217) is one call on one thread; its inner
+// products (mod.rs:255-272, 279-290) are sums of independent terms, so they shard.  One process per GPU (the launch model of
+// torch.distributed.run and of MPI); what crosses the GPUs goes through a zk_comm:
+//   * RCCL over xGMI (zk_comm_init: ncclCommInitRank on the context's device; byte all-to-all = grouped ncclSend/ncclRecv,
+//     byte all-gather = ncclAllGather -- group elements cannot be all-reduced), or
+//   * a caller-supplied transport (zk_comm_init_custom: function pointers; the CPU tests plug gloo in here).
+// On top of it zk_mgpu runs the scalar-exchange prover as a software pipeline (formerly Python, distributed.py): in a round
+// of `world` proofs rank j runs the SpMV / NTT stage of proof j only, four equal-split all-to-alls hand every rank the
+// scalars that multiply ITS point range of the four inner products, the rank accumulates them for all proofs of the
+// round in grouped MSMs, one more all-to-all returns the 768-byte partial sums to the proofs' owners.  The stages
+// themselves are called through a zk_mgpu_backend table: the default one is this library's GPU entry points
+// (zk_prove_scalars_submit / zk_prove_msm_submit / zk_prove_wait / zk_prove_combine); tests may substitute CPU stand-ins
+// so that the pipeline logic and the collectives' order run under world-size-2 gloo without a GPU.
+#include <rccl/rccl.h>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <vector>
+#include "pipeline.hpp"
+
+namespace zk { struct GpuBackend; }
+
+struct zk_comm {
+    zk_ctx* ctx = nullptr;          // null for a custom transport created without a device
+    int rank = 0, world = 1;
+    bool custom = false;
+    zk_comm_ops ops{};
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;   // collectives run here, never on the compute streams
+    int* d_flag = nullptr;          // barrier / max-reduce scratch (device)
+};
+
+struct zk_mgpu {
+    zk_comm* comm = nullptr;
+    zk_mgpu_backend be{};
+    bool own_backend = false;
+    zk::GpuBackend* gpu = nullptr;
+    size_t elems[4] = {0, 0, 0, 0};
+    // two sets of exchange buffers (round k uses set k % 2): scalars out / in for L, V, U, H and the partial-sum blobs
+    void* send[2][4] = {};
+    void* recv[2][4] = {};
+    void* part_send[2] = {};
+    void* part_recv[2] = {};
+    struct Round { uint64_t r[4], s[4]; int t_scalars = -1, t_msm = -1; bool ip_done = false; };
+    std::deque<Round> rounds;       // pushed and not yet popped, oldest first
+    size_t first = 0;               // round number of rounds.front()
+    std::string last_error;
+};
+
+namespace zk {
+
+#define ZK_NCCL(expr)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) throw ::zk::StatusError{ZK_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(_r)}; \
+    } while (0)
+
+// ---- transport ----------------------------------------------------------------------------------
+static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    if (c->world == 1) {
+        if (c->custom) { ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed"); return; }
+        ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
+        return;
+    }
+    if (c->custom) {
+        ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
+        return;
+    }
+    // chunk g of d_send goes to rank g; chunk j of d_recv comes from rank j.  xGMI is point to point (7 links per GPU): the
+    // grouped send / recv pairs run on all links at once, which is what an equal-split exchange wants.
+    ZK_NCCL(ncclGroupStart());
+    for (int peer = 0; peer < c->world; ++peer) {
+        ZK_NCCL(ncclSend((const uint8_t*)d_send + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, c->nccl, c->stream));
+        ZK_NCCL(ncclRecv((uint8_t*)d_recv + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, c->nccl, c->stream));
+    }
+    ZK_NCCL(ncclGroupEnd());
+}
+static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    if (c->custom) {
+        ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
+        return;
+    }
+    if (c->world == 1) { ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream)); return; }
+    ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->nccl, c->stream));
+}
+static void comm_sync(zk_comm* c) {
+    if (!c->custom) ZK_HIP(hipStreamSynchronize(c->stream));
+}
+
+// ---- the default backend: this library's GPU stages -----------------------------------------------
+struct GpuBackend {
+    zk_ctx* ctx;
+    const zk_crs* crs;
+    const zk_qap* qap;
+};
+static int gpu_elems(void* u, int world, size_t out[4]) { return zk_prove_exchange_elems(((GpuBackend*)u)->qap, world, out); }
+static void* gpu_alloc(void* u, size_t bytes) {
+    void* p = nullptr;
+    (void)hipSetDevice(((GpuBackend*)u)->ctx->device);
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, bytes ? bytes : 1);
+    return p;
+}
+static void gpu_free(void*, void* p) { (void)hipFree(p); }
+static int gpu_scalars(void* u, const void* w, size_t m, const uint64_t r[4], const uint64_t s[4], int world, void* const send[4], int* t) {
+    GpuBackend* g = (GpuBackend*)u;
+    return zk_prove_scalars_submit(g->ctx, g->crs, g->qap, w, m, r, s, world, send[0], send[1], send[2], send[3], t);
+}
+static int gpu_msm(void* u, int sets, int rank, int world, void* const recv[4], void* part, int* t) {
+    GpuBackend* g = (GpuBackend*)u;
+    return zk_prove_msm_submit(g->ctx, g->crs, g->qap, sets, rank, world, recv[0], recv[1], recv[2], recv[3], part, t);
+}
+static int gpu_wait(void* u, int t) { return zk_prove_wait(((GpuBackend*)u)->ctx, t, nullptr); }
+static int gpu_combine(void* u, const void* part_recv, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof) {
+    GpuBackend* g = (GpuBackend*)u;
+    return zk_prove_combine(g->ctx, g->crs, part_recv, world, r, s, proof);
+}
+
+// ---- the pipeline ---------------------------------------------------------------------------------
+// Round k: A(k) = scalars of this rank's proof k; B(k) = wait A(k), four all-to-alls, grouped inner products over this rank's
+// points for the `world` proofs of the round; F(k) = wait B(k), all-to-all of the partial sums, assembly of proof k.
+// Issue order (every rank the same, so the collectives pair up): push(j) = A(j), then B(j-1); pop() = F(oldest), after
+// B(oldest) if the caller did not push ahead.  With two rounds pushed ahead of every pop this is the schedule measured in
+// round 1: the scalars run two rounds ahead of the inner products (under the chip-filling accumulations the SpMV / NTT stage
+// only progresses in the gaps) and the inner products of round k+1 are queued before those of round k end.
+static void be_check(zk_mgpu* g, int rc, const char* what) {
+    if (rc != 0) throw StatusError{rc, std::string("zk_mgpu: ") + what + " failed"};
+}
+static void inner_products(zk_mgpu* g, size_t k) {
+    zk_mgpu::Round& R = g->rounds[k - g->first];
+    if (R.ip_done) return;
+    const int set = (int)(k & 1), world = g->comm->world;
+    be_check(g, g->be.wait(g->be.user, R.t_scalars), "wait (scalars)");
+    for (int a = 0; a < 4; ++a) comm_all_to_all(g->comm, g->send[set][a], g->recv[set][a], g->elems[a] / world * 32);
+    comm_sync(g->comm);
+    be_check(g, g->be.msm_submit(g->be.user, world, g->comm->rank, world, g->recv[set], g->part_send[set], &R.t_msm), "msm_submit");
+    R.ip_done = true;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+static int comm_guard(zk_comm* c, std::string* err, const std::function<void()>& fn) {
+    try {
+        if (c && c->ctx) ZK_HIP(hipSetDevice(c->ctx->device));
+        fn();
+        return ZK_OK;
+    } catch (const HipError& e) {
+        if (err) *err = std::string(hipGetErrorString(e.code)) + " in " + e.where;
+        if (c && c->ctx) c->ctx->last_error = std::string(hipGetErrorString(e.code)) + " in " + e.where;
+        return ZK_ERR_HIP;
+    } catch (const StatusError& e) {
+        if (err) *err = e.msg;
+        if (c && c->ctx) c->ctx->last_error = e.msg;
+        return e.status;
+    } catch (...) {
+        if (err) *err = "unknown error";
+        return ZK_ERR_ARG;
+    }
+}
+
+extern "C" {
+
+int zk_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int zk_comm_unique_id(uint8_t id_out[ZK_COMM_ID_BYTES]) {
+    static_assert(ZK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!id_out) return ZK_ERR_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return ZK_ERR_COMM;
+    std::memcpy(id_out, id.internal, ZK_COMM_ID_BYTES);
+    return ZK_OK;
+}
+
+int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world, zk_comm** out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return ZK_ERR_ARG;
+    *out = nullptr;
+    zk_comm* c = new (std::nothrow) zk_comm();
+    if (!c) return ZK_ERR_HIP;
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    int rc = comm_guard(c, nullptr, [&] {
+        ZK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        ZK_HIP(hipMalloc((void**)&c->d_flag, 64));
+        if (world > 1) {
+            ncclUniqueId nid;
+            std::memcpy(nid.internal, id, ZK_COMM_ID_BYTES);
+            ZK_NCCL(ncclCommInitRank(&c->nccl, world, nid, rank));
+        }
+    });
+    if (rc != ZK_OK) { zk_comm_destroy(c); return rc; }
+    *out = c;
+    return ZK_OK;
+}
+
+int zk_comm_init_custom(zk_ctx* ctx, const zk_comm_ops* ops, int rank, int world, zk_comm** out) {
+    if (!out || !ops || !ops->all_to_all || !ops->all_gather || world < 1 || rank < 0 || rank >= world) return ZK_ERR_ARG;
+    zk_comm* c = new (std::nothrow) zk_comm();
+    if (!c) return ZK_ERR_HIP;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->custom = true; c->ops = *ops;
+    *out = c;
+    return ZK_OK;
+}
+
+void zk_comm_destroy(zk_comm* c) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+int zk_comm_rank(const zk_comm* c) { return c ? c->rank : -1; }
+int zk_comm_world(const zk_comm* c) { return c ? c->world : 0; }
+
+/* Every rank blocks until all have arrived (an all-gather of one flag per rank). */
+int zk_comm_barrier(zk_comm* c) {
+    if (!c) return ZK_ERR_ARG;
+    if (c->custom) return c->ops.barrier ? c->ops.barrier(c->ops.user) : ZK_ERR_UNSUPPORTED;
+    return comm_guard(c, nullptr, [&] {
+        if (c->world > 1) {
+            int one = 1;
+            ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, c->nccl, c->stream));
+            (void)one;
+        }
+        ZK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+/* *value = max over the ranks of *value (the bench's "time of the slowest rank") */
+int zk_comm_max_f64(zk_comm* c, double* value) {
+    if (!c || !value) return ZK_ERR_ARG;
+    if (c->custom) return c->ops.max_f64 ? c->ops.max_f64(c->ops.user, value) : ZK_ERR_UNSUPPORTED;
+    return comm_guard(c, nullptr, [&] {
+        if (c->world == 1) return;
+        double* d = reinterpret_cast<double*>(c->d_flag) + 2;
+        ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, c->nccl, c->stream));
+        ZK_HIP(hipMemcpyAsync(value, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+/* Byte collectives on device buffers, for callers that drive the stages themselves; complete on return. */
+int zk_comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    if (!c || !d_send || !d_recv) return ZK_ERR_ARG;
+    return comm_guard(c, nullptr, [&] { comm_all_to_all(c, d_send, d_recv, bytes_per_rank); comm_sync(c); });
+}
+int zk_comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    if (!c || !d_send || !d_recv) return ZK_ERR_ARG;
+    return comm_guard(c, nullptr, [&] { comm_all_gather(c, d_send, d_recv, bytes_per_rank); comm_sync(c); });
+}
+
+/* ---- latency form: ONE proof over all ranks (every rank holds the same witness) ---- */
+int zk_mgpu_prove_sharded(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
+                          const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!ctx || !c || !crs || !qap || !d_weights || !r || !s || !proof_out) return ZK_ERR_ARG;
+    void *part = nullptr, *all = nullptr;
+    int rc = comm_guard(c, nullptr, [&] {
+        ZK_HIP(hipMalloc(&part, ZK_PARTIAL_BYTES));
+        ZK_HIP(hipMalloc(&all, (size_t)c->world * ZK_PARTIAL_BYTES));
+        int st = zk_prove_partial(ctx, crs, qap, d_weights, m, r, s, c->rank, c->world, part);
+        ZK_REQUIRE(st == ZK_OK, st, ctx->last_error);
+        comm_all_gather(c, part, all, ZK_PARTIAL_BYTES);
+        comm_sync(c);
+        st = zk_prove_combine(ctx, crs, all, c->world, r, s, proof_out);
+        ZK_REQUIRE(st == ZK_OK, st, ctx->last_error);
+    });
+    if (part) (void)hipFree(part);
+    if (all) (void)hipFree(all);
+    return rc;
+}
+
+/* ---- throughput form: the scalar-exchange pipeline ---- */
+static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, zk_mgpu** out) {
+    zk_mgpu* g = new (std::nothrow) zk_mgpu();
+    if (!g) { delete gpu; return ZK_ERR_HIP; }
+    g->comm = c; g->be = *be; g->gpu = gpu;
+    int rc = comm_guard(c, &g->last_error, [&] {
+        be_check(g, g->be.elems(g->be.user, c->world, g->elems), "elems");
+        for (int set = 0; set < 2; ++set) {
+            for (int a = 0; a < 4; ++a) {
+                ZK_REQUIRE(g->elems[a] % (size_t)c->world == 0, ZK_ERR_ARG, "zk_mgpu: exchange arrays must split evenly");
+                g->send[set][a] = g->be.alloc(g->be.user, g->elems[a] * 32);
+                g->recv[set][a] = g->be.alloc(g->be.user, g->elems[a] * 32);
+                ZK_REQUIRE(g->send[set][a] && g->recv[set][a], ZK_ERR_HIP, "zk_mgpu: buffer allocation failed");
+            }
+            g->part_send[set] = g->be.alloc(g->be.user, (size_t)c->world * ZK_PARTIAL_BYTES);
+            g->part_recv[set] = g->be.alloc(g->be.user, (size_t)c->world * ZK_PARTIAL_BYTES);
+            ZK_REQUIRE(g->part_send[set] && g->part_recv[set], ZK_ERR_HIP, "zk_mgpu: buffer allocation failed");
+        }
+    });
+    if (rc != ZK_OK) { zk_mgpu_destroy(g); return rc; }
+    *out = g;
+    return ZK_OK;
+}
+
+int zk_mgpu_create(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out) {
+    if (!ctx || !c || !crs || !qap || !out) return ZK_ERR_ARG;
+    if (qap->dense) return ZK_ERR_UNSUPPORTED;
+    GpuBackend* gpu = new (std::nothrow) GpuBackend{ctx, crs, qap};
+    if (!gpu) return ZK_ERR_HIP;
+    zk_mgpu_backend be{gpu, gpu_elems, gpu_alloc, gpu_free, gpu_scalars, gpu_msm, gpu_wait, gpu_combine};
+    return mgpu_create(c, &be, gpu, out);
+}
+int zk_mgpu_create_custom(zk_comm* c, const zk_mgpu_backend* be, zk_mgpu** out) {
+    if (!c || !be || !out || !be->elems || !be->alloc || !be->free || !be->scalars_submit || !be->msm_submit || !be->wait || !be->combine) return ZK_ERR_ARG;
+    return mgpu_create(c, be, nullptr, out);
+}
+
+void zk_mgpu_destroy(zk_mgpu* g) {
+    if (!g) return;
+    for (auto& R : g->rounds) {   // tickets still in flight
+        if (R.t_msm >= 0) (void)g->be.wait(g->be.user, R.t_msm);
+        else if (R.t_scalars >= 0 && !R.ip_done) (void)g->be.wait(g->be.user, R.t_scalars);
+    }
+    for (int set = 0; set < 2; ++set) {
+        for (int a = 0; a < 4; ++a) {
+            if (g->send[set][a]) g->be.free(g->be.user, g->send[set][a]);
+            if (g->recv[set][a]) g->be.free(g->be.user, g->recv[set][a]);
+        }
+        if (g->part_send[set]) g->be.free(g->be.user, g->part_send[set]);
+        if (g->part_recv[set]) g->be.free(g->be.user, g->part_recv[set]);
+    }
+    delete g->gpu;
+    delete g;
+}
+const char* zk_mgpu_last_error(const zk_mgpu* g) { return g ? g->last_error.c_str() : "null prover"; }
+
+int zk_mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]) {
+    if (!g || !d_weights || !r || !s) return ZK_ERR_ARG;
+    return comm_guard(g->comm, &g->last_error, [&] {
+        ZK_REQUIRE(g->rounds.size() < 3, ZK_ERR_ARG, "zk_mgpu_push: three rounds in flight (call zk_mgpu_pop first)");
+        const size_t k = g->first + g->rounds.size();
+        // the send buffers of set k % 2 were last used by round k - 2: its exchange must be complete (it normally is, from push(k - 1))
+        if (g->rounds.size() >= 2) inner_products(g, k - 2);
+        zk_mgpu::Round R;
+        std::memcpy(R.r, r, 32); std::memcpy(R.s, s, 32);
+        be_check(g, g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars), "scalars_submit");
+        g->rounds.push_back(R);
+        if (g->rounds.size() >= 2) inner_products(g, k - 1);   // A(k), then B(k - 1): the scalars run ahead of the inner products
+    });
+}
+
+int zk_mgpu_pop(zk_mgpu* g, uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!g || !proof_out) return ZK_ERR_ARG;
+    return comm_guard(g->comm, &g->last_error, [&] {
+        ZK_REQUIRE(!g->rounds.empty(), ZK_ERR_ARG, "zk_mgpu_pop: nothing pushed");
+        const size_t k = g->first;
+        // the collectives must be issued in round order on every rank: B(k), then B(k+1) if it was pushed, then F(k)
+        inner_products(g, k);
+        if (g->rounds.size() >= 2) inner_products(g, k + 1);
+        zk_mgpu::Round R = g->rounds.front();
+        const int set = (int)(k & 1), world = g->comm->world;
+        be_check(g, g->be.wait(g->be.user, R.t_msm), "wait (inner products)");
+        comm_all_to_all(g->comm, g->part_send[set], g->part_recv[set], ZK_PARTIAL_BYTES);
+        comm_sync(g->comm);
+        g->rounds.pop_front();
+        g->first = k + 1;
+        be_check(g, g->be.combine(g->be.user, g->part_recv[set], world, R.r, R.s, proof_out), "combine");
+    });
+}
+
+}  // extern "C"

@@ -21,6 +21,18 @@
 #define ZK_SCHED_FENCE() ((void)0)
 #endif
 
+// Wave priority of the short, dependent kernels of a proof (SpMV / NTT stage, the sort, the reduction tails, assembly).  The
+// bucket accumulations fill every SIMD with waves that live ~0.5 ms, and the SIMD arbitrates VALU issue by priority first,
+// age second: at equal priority a freshly launched wave of a small kernel gets the slots the older accumulation waves leave
+// over, so each of the ~100 dependent launches of a proof crawled while an accumulation ran (the timeline showed the scalars
+// of an inner product arriving 1-2 ms after the chip went idle).  Raised priority makes them finish in their stand-alone time;
+// the accumulation loses only the issue slots those few waves actually use.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_PRIO)
+#define ZK_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
+#else
+#define ZK_LATENCY_KERNEL() ((void)0)
+#endif
+
 namespace zk {
 
 struct FrParams {

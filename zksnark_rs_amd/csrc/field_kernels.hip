@@ -50,6 +50,7 @@ template void field_batch<Fq>(zk_ctx*, int, const uint64_t*, const uint64_t*, ui
 
 // ---- canonical <-> Montgomery over arrays ------------------------------------------------
 __global__ void k_fr_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n, int* flag) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr x = in[i];
@@ -57,6 +58,7 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, si
     out[i] = Fr::from_canonical(x);
 }
 __global__ void k_fr_from_mont(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i].to_canonical();
 }

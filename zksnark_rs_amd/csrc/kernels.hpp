@@ -63,6 +63,9 @@ struct MsmWorkspace {
     DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy;
     DevBuf<uint64_t> records;
     DevBuf<uint8_t> partial, bucket_sums, fold, seg_sums;
+    hipStream_t tail_stream = nullptr;   // where the reduction tail runs (null: on the product's own stream)
+    hipStream_t acc_stream = nullptr;    // where the bucket accumulation runs (null: on the product's own stream)
+    hipEvent_t sorted_evt = nullptr;     // sort -> accumulation hand-over when acc_stream is set (owned; lives as long as the context)
 };
 int msm_auto_window(size_t n);
 void msm_init_attributes();
@@ -83,8 +86,9 @@ struct MsmGroups {
     int groups = 1;
     size_t glen = 0, valid = 0, out_stride = 0;
 };
+// Returns the stream the result lands on (the tail stream when the workspace names one).
 template <class F>
-void msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
+hipStream_t msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
              int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0,
              const MsmGroups& grp = MsmGroups());
 template <class F>

@@ -178,6 +178,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uin
 // multiplies point i % glen (scalars at or behind gvalid are ignored); group g owns the bins [g bins_pg, (g+1) bins_pg).
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
                                                            int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups, uint32_t* __restrict__ hist) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = 0;
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
 
 // total[b] = sum over chunks of hist[chunk][b]
 __global__ void k_msm_bin_totals(const uint32_t* __restrict__ hist, int chunks, int bins, uint32_t* __restrict__ total) {
+    ZK_LATENCY_KERNEL();
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= bins) return;
     uint32_t run = 0;
@@ -207,6 +209,7 @@ __global__ void k_msm_bin_totals(const uint32_t* __restrict__ hist, int chunks, 
 
 // hist[chunk][b] -> position of the chunk's first record of bin b
 __global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int bins, const uint32_t* __restrict__ start) {
+    ZK_LATENCY_KERNEL();
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= bins) return;
     uint32_t run = start[b];
@@ -220,6 +223,7 @@ __global__ void k_msm_chunk_prefix(uint32_t* __restrict__ hist, int chunks, int 
 
 // exclusive scan of total[0..count) -> start[0..count]; one workgroup
 __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ total, uint32_t* __restrict__ start, int count) {
+    ZK_LATENCY_KERNEL();
     __shared__ uint32_t part[1024];
     int per = (count + 1023) / 1024;
     int lo = min((int)threadIdx.x * per, count), hi = min(lo + per, count);
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
                                                                      int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups,
                                                                      const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
     const uint32_t sub_mask = (1u << sub_bits) - 1;
@@ -289,6 +294,7 @@ __device__ __forceinline__ bool bin_slice(const uint32_t* __restrict__ bin_start
 
 // part_start[b] = exclusive scan of ceil(len_b / target) (at least one workgroup per bin); one workgroup
 __global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restrict__ bin_start, int bins, uint32_t target, uint32_t* __restrict__ part_start) {
+    ZK_LATENCY_KERNEL();
     __shared__ uint32_t scratch[1024];
     for (int b = threadIdx.x; b < bins; b += 1024) {
         const uint32_t len = bin_start[b + 1] - bin_start[b];
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restri
 
 __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
                                                                 const uint32_t* __restrict__ part_start, int bins, int sub_bits, uint32_t* __restrict__ cnt) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int subs = 1 << sub_bits;
     uint32_t lo, hi;
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* 
 // one workgroup per bin: cnt[bin][part][sub] -> first position of that (part, sub); start[bucket]
 __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ part_start,
                                                                    int bins, int sub_bits, uint32_t* __restrict__ start) {
+    ZK_LATENCY_KERNEL();
     __shared__ uint32_t part_sum[SORT2_THREADS];
     const int subs = 1 << sub_bits;
     const int bin = blockIdx.x;
@@ -362,6 +370,7 @@ constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
 __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
                                                                   const uint32_t* __restrict__ part_start, int bins, int sub_bits,
                                                                   const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t scratch[BINS_THREADS];
     const int subs = 1 << sub_bits;
@@ -505,6 +514,11 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
 // S_b = sum of the parked images of bucket b (see k_msm_accumulate).  One lane per bucket; buckets spread
 // over more than MSM_HEAVY lanes (skewed digit distributions) are queued for k_msm_merge_heavy instead.
 constexpr uint32_t MSM_HEAVY = 96;
+// Workgroup size of the reduction tail (merge / fold / weigh).  ONE wave: while an accumulation fills the chip, a 256-lane
+// workgroup of a 150..250-register kernel needs all four SIMDs of a CU to have room at the same moment, which only happens in
+// the accumulation's last round (the timeline showed the previous proof's G2 tail still running 8 ms after its accumulation
+// and the next proof's sort waiting behind it on the same stream); a single wave fits wherever one accumulation wave retires.
+constexpr int TAIL_THREADS = 64;
 
 template <class F>
 __device__ __forceinline__ typename AccOf<F>::type merge_head(uint32_t b, uint32_t s, uint32_t e, uint32_t t0, uint32_t per_lane, uint32_t total,
@@ -516,9 +530,10 @@ __device__ __forceinline__ typename AccOf<F>::type merge_head(uint32_t b, uint32
 }
 
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
+__global__ __launch_bounds__(TAIL_THREADS) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
                                                    const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
                                                    uint32_t* __restrict__ heavy) {
+    ZK_LATENCY_KERNEL();
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     const uint32_t s = start[b], e = start[b + 1], total = start[buckets];
@@ -537,6 +552,7 @@ template <class F>
 __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
                                                          const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
                                                          const uint32_t* __restrict__ heavy) {
+    ZK_LATENCY_KERNEL();
     __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
     const uint32_t count = heavy[0], total = start[buckets];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
@@ -568,7 +584,8 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uin
 // out[a B + b] = sum_{i < f} in[(a f + i) B + b], a < A, b < B: one lane per output image, f - 1 dependent additions.
 // Columns: the row index is folded (B = K); rows: the column index is folded (B = 1); group indices ride in `a`.
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_fold(const AccSlot<F>* __restrict__ in, AccSlot<F>* __restrict__ out, uint32_t A, uint32_t f, uint32_t B) {
+__global__ __launch_bounds__(TAIL_THREADS) void k_msm_fold(const AccSlot<F>* __restrict__ in, AccSlot<F>* __restrict__ out, uint32_t A, uint32_t f, uint32_t B) {
+    ZK_LATENCY_KERNEL();
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A * B) return;
     const uint32_t a = j / B, b = j - a * B;
@@ -581,10 +598,11 @@ __global__ __launch_bounds__(256) void k_msm_fold(const AccSlot<F>* __restrict__
 // term[group][j]: j < K: lo * C[lo] (lo = j); j = K + hi: (hi K + 1) * R[hi].  One point per lane, every lane runs the same
 // double-and-add (weight 0 gives infinity); k_msm_sum_points adds the K + rows terms of a group.
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
+__global__ __launch_bounds__(TAIL_THREADS) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
                                                    Jac<F>* __restrict__ term) {
+    ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * TAIL_THREADS + threadIdx.x;
     if (j >= K + rows) return;
     const AccSlot<F>* src = j < K ? C + (size_t)g * K + j : R + (size_t)g * rows + (j - K);
     const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u;
@@ -595,6 +613,7 @@ __global__ __launch_bounds__(256) void k_msm_weigh(const AccSlot<F>* __restrict_
 // blockIdx.y = group: its `count` inputs start at in + y count, its gridDim.x outputs at (bytes) out + y out_stride
 template <class F>
 __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
     in += (size_t)blockIdx.y * count;
@@ -611,8 +630,8 @@ __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict
 }
 
 template <class F>
-void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-             int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp) {
+hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
+                    int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp) {
     const bool g2 = sizeof(F) > sizeof(Fq);
     const int c = tab.c, windows = tab.windows, bpg = 1 << (c - 1);
     const size_t n = tab.n;
@@ -633,7 +652,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
             ZK_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_out) + (size_t)j * grp.out_stride, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
-        return;
+        return st;
     }
     // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
     // 2^8 bins (more only to keep the sub-bucket level at 2^11 counters at most)
@@ -652,7 +671,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     const size_t lanes = (entries + per_lane - 1) / per_lane;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
     const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
-    const int wgs_w = (K + rows + 255) / 256;
+    const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
 
     ws.hist.ensure((size_t)chunks * bins);
     ws.total.ensure(bins);
@@ -706,18 +725,47 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
                            sub_bits, ws.bin_cnt.p, ws.sorted.p);
     }
     {
-        // algorithmic bytes: every (window, point) digit reads its 4 B index and its affine point once;
-        // every lane parks one accumulator image
-        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
-        ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (4.0 + pt_bytes) * entries + (double)sizeof(AccSlot<F>) * lanes, st);
-        hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, st, tab.table.p + point_offset, ws.sorted.p, ws.start.p, buckets, per_lane,
-                           d_first, d_last, d_mid);
+        // algorithmic bytes as SURVEY.md 8(d) prices an inner product: one 32-byte scalar and one affine point per (scalar, point)
+        // pair -- 96 B in G1, 160 B in G2 -- whatever the window count.  (What this implementation actually gathers is W times
+        // that: a 4-byte index and a 64 / 128-byte table entry per window and pair, plus one parked image per lane; bench.py
+        // reports that figure and the PMC-measured traffic beside the 8(d) number.)
+        // All bucket accumulations of a context run in submission order on ONE low-priority stream (ws.acc_stream), the sort before
+        // and the reduction tail after it on the product's own stream at a higher priority: the accumulation's thousands of pending
+        // workgroups then never stand in front of the short dependent kernels in the dispatcher.
+        hipStream_t ast = ws.acc_stream ? ws.acc_stream : st;
+        if (ws.acc_stream) {
+            if (!ws.sorted_evt) ZK_HIP(hipEventCreateWithFlags(&ws.sorted_evt, hipEventDisableTiming));
+            ZK_HIP(hipEventRecord(ws.sorted_evt, st));
+            ZK_HIP(hipStreamWaitEvent(ast, ws.sorted_evt, 0));
+        }
+        if (acc_wait) ZK_HIP(hipStreamWaitEvent(ast, acc_wait, 0));
+        {
+            ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, ast);
+            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, ast, tab.table.p + point_offset, ws.sorted.p, ws.start.p, buckets, per_lane,
+                               d_first, d_last, d_mid);
+        }
+        if (acc_done) ZK_HIP(hipEventRecord(acc_done, ast));
+        if (ws.acc_stream) {
+            if (!acc_done) {   // no caller event: reuse the workspace's
+                ZK_HIP(hipEventRecord(ws.sorted_evt, ast));
+                ZK_HIP(hipStreamWaitEvent(st, ws.sorted_evt, 0));
+            } else {
+                ZK_HIP(hipStreamWaitEvent(st, acc_done, 0));
+            }
+        }
     }
-    if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
+    // The reduction tail runs on its own stream when the caller provides one (ws.tail_stream): on `st` it would sit in front of
+    // the NEXT proof's sort of this product, and under the following accumulations the 150..250-register tail kernels only get
+    // scheduled in the gaps -- the timeline showed the G2 tail of proof k-1 ending 1.6 ms into proof k, its sort starting only
+    // then and the chip idling 0.9 ms per proof for it.
+    if (ws.tail_stream && acc_done) {
+        ZK_HIP(hipStreamWaitEvent(ws.tail_stream, acc_done, 0));
+        st = ws.tail_stream;
+    }
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (lanes + 5.0 * buckets), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, 256)), dim3(256), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
         // heavy buckets are outliers when the average bucket spans few lanes (a small grid that mostly finds nothing
         // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
         // (a narrow top window makes 2^(top bits) buckets heavy at once -- 64..128 at c = 19 -- so the small grid is not THAT small:
@@ -725,7 +773,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
         hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
         // column sums C[g][lo] (fold the row index, <= 16 images per lane and pass), then row sums R[g][hi] (fold the column index)
-        constexpr uint32_t FOLD = 16;
+        const uint32_t FOLD = (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64));   // images per lane and pass (msm_fold option)
         auto fold_all = [&](uint32_t count, uint32_t B, uint32_t outer, AccSlot<F>* final_out) {
             // `count` images per output along the folded index; outer = number of (group, kept-index-major) blocks
             const AccSlot<F>* in = d_img;
@@ -734,7 +782,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
                 const uint32_t f = std::min(count, FOLD);
                 AccSlot<F>* out = count == f ? final_out : d_tmp[tog];
                 const uint32_t A = outer * (count / f);
-                hipLaunchKernelGGL(k_msm_fold<F>, dim3(ceil_div((size_t)A * B, 256)), dim3(256), 0, st, in, out, A, f, B);
+                hipLaunchKernelGGL(k_msm_fold<F>, dim3(ceil_div((size_t)A * B, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, in, out, A, f, B);
                 if (count == f) break;
                 count /= f;
                 in = out;
@@ -743,7 +791,7 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
         };
         fold_all((uint32_t)rows, (uint32_t)K, (uint32_t)groups, d_C);
         fold_all((uint32_t)K, 1u, (uint32_t)groups * (uint32_t)rows, d_R);
-        hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(256), 0, st, d_C, d_R, kbits, rows, d_seg);
+        hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(TAIL_THREADS), 0, st, d_C, d_R, kbits, rows, d_seg);
         // K + rows terms per group: one workgroup while each lane has at most 4 of them, otherwise two levels
         Jac<F>* d_part = d_seg + (size_t)groups * (K + rows);
         const int terms = K + rows, wgs2 = (terms + 1023) / 1024;
@@ -797,8 +845,9 @@ void msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& t
     }
 #endif
     ZK_HIP(hipGetLastError());
+    return st;
 }
-template void msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&);
+template hipStream_t msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&);
 
 
 #ifdef ZK_MSM_COMMON

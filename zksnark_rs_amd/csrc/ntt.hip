@@ -273,6 +273,7 @@ __device__ __forceinline__ void ntt_round(int32_t* lds, const Fr* __restrict__ t
 
 template <bool DIT>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data, NttPass p) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const unsigned log_rows = p.log_rows, log_cols = p.log_cols;
     const int cols = 1 << log_cols;
@@ -379,6 +380,7 @@ void bitrev_permute(zk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n) {
 }
 
 __global__ void k_pointwise_mul(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out, size_t n) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
 }

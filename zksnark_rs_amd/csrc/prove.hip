@@ -76,12 +76,14 @@ __device__ __forceinline__ void assemble_pre_body(const G1A* __restrict__ ft_alp
 __global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
                                                       const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
                                                       Fr r, Fr s, AssemblePre* __restrict__ out) {
+    ZK_LATENCY_KERNEL();
     assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, r, s, out);
 }
 // batch form (zk_prove_batch_*): workgroup j serves proof j; (r, s) pairs in device memory
 __global__ __launch_bounds__(320) void k_assemble_pre_batch(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
                                                             const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
                                                             const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
+    ZK_LATENCY_KERNEL();
     assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, rs[2 * blockIdx.x], rs[2 * blockIdx.x + 1], out + blockIdx.x);
 }
 
@@ -130,17 +132,20 @@ __device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms,
 }
 __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
                                                   const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
+    ZK_LATENCY_KERNEL();
     assemble_body(ms, pre, alpha1, beta2, proof);
 }
 
 // batch form: workgroup j assembles proof j from blob j of the partial sums
 __global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre,
                                                         const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proofs) {
+    ZK_LATENCY_KERNEL();
     assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, alpha1, beta2,
                   proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES);
 }
 
 __global__ void k_sum_partials(const uint8_t* __restrict__ partials, int world, MsmResults* __restrict__ out) {
+    ZK_LATENCY_KERNEL();
     int which = threadIdx.x >> 6;
     if ((threadIdx.x & 63) || which > 4) return;
     if (which < 4) {
@@ -246,6 +251,22 @@ struct StreamSwap {
     StreamSwap(zk_ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
     ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
 };
+
+// MSM stream k -> the stream of its reduction tail: one for the G2 product (k = 0), one shared by the three G1 products;
+// null (tail on the product's own stream) in the measurement mode and when the option msm_tail_streams is 0
+static hipStream_t tail_stream_for(zk_ctx* ctx, int k) {
+    if (ctx->opt_serialize || !ctx->opt_tail_streams) return nullptr;
+    return ctx->tail_stream[k == 0 ? 0 : 1];
+}
+
+// Stream of inner product k of the proof in slot `ticket`.  The G2 product (k = 0) alternates between two streams (index 3 is
+// free since B in G1 was folded into the H product): its reduction tail is the longest chain of a proof -- ~5 ms under the
+// following accumulations -- and on ONE stream the next proof's G2 sort waits behind it (sort + accumulation + tail of the G2
+// product came to ~10.3 ms of a 12 ms period, and the timeline showed the chip idle 0.9 ms per proof waiting for that sort).
+static hipStream_t msm_stream_for(zk_ctx* ctx, int k, int ticket) {
+    if (k == 0 && ctx->opt_alt_g2 && (ticket & 1)) return ctx->msm_stream[3];
+    return ctx->msm_stream[k];
+}
 
 static ProveState& prove_state(zk_ctx* ctx) {
     if (!ctx->prove_state) ctx->prove_state = std::make_shared<ProveState>();
@@ -360,18 +381,21 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
         if (xout) return;
-        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];   // serialize: measurement mode, no overlap at all
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
+        S.ws[k].tail_stream = tail_stream_for(ctx, k);
+        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
+        hipStream_t end_st;
         if (world > 1 && ctx->opt_shard_points) {
             // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
             const size_t lo = count * (size_t)rank / (size_t)world, hi = count * ((size_t)rank + 1) / (size_t)world;
-            msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], lo);
+            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], lo);
         } else {
-            msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k]);
+            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k]);
         }
-        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
     if (!q.dense) {
@@ -503,7 +527,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
     // reduction tails (group j = proof j with its own 2^(c-1) buckets); chain L -> B2 -> A -> H as in a whole proof
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out) {
-        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
@@ -511,9 +535,11 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         const size_t valid = range(chunk, count, &lo);
         MsmGroups grp;
         grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        if (sets == 1) msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo);
-        else msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
-        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        S.ws[k].tail_stream = tail_stream_for(ctx, k);
+        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
+        hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
+                                       : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
+        ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
     if (sets > 0) {
@@ -584,15 +610,17 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     }
     MsmResults* ms = reinterpret_cast<MsmResults*>(S.b_partials.p);
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t glen, size_t valid, auto* out) {
-        hipStream_t ms_st = ctx->opt_serialize ? st : ctx->msm_stream[k];
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         MsmGroups grp;
         grp.groups = count; grp.glen = glen; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        if (count == 1) msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k]);
-        else msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
-        ZK_HIP(hipEventRecord(S.msm_done[k], ms_st));
+        S.ws[k].tail_stream = tail_stream_for(ctx, k);
+        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
+        hipStream_t end_st = count == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k])
+                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
+        ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
     // L needs only the witnesses (zip truncation, mod.rs:233-253: zero scalars behind a short witness)

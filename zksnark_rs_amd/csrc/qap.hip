@@ -146,6 +146,7 @@ void qap_free(zk_qap* q) {
 // out[row] = sum_k a[idx[k]] * val[k]   (one lane per row; rows of the chain circuit have 1-2 entries)
 __global__ void k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const Fr* __restrict__ val,
                        const Fr* __restrict__ a, size_t a_len, Fr* __restrict__ out, size_t rows) {
+    ZK_LATENCY_KERNEL();
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= rows) return;
     Fr acc = Fr::zero();
@@ -178,6 +179,7 @@ void dense_matvec(zk_ctx* ctx, const Fr* M, const Fr* a, size_t rows, size_t n, 
 
 // h[pos] = canonical( x[pos] * 1/2  -  tab[pos] * y[pos] ),  tab = g^-brev(pos) / 2
 __global__ void k_h_combine(const Fr* __restrict__ x, const Fr* __restrict__ y, const Fr* __restrict__ tab, Fr half, Fr* __restrict__ out, size_t n) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (x[i] * half - tab[i] * y[i]).to_canonical();
 }
@@ -189,6 +191,7 @@ void h_combine(zk_ctx* ctx, const Fr* x, const Fr* y, const Fr* tab, Fr half, Fr
 
 // out[i] = canonical(in[i] * k)   (in Montgomery form, k Montgomery)
 __global__ void k_scale_to_canonical(const Fr* __restrict__ in, Fr k, Fr* __restrict__ out, size_t n) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (in[i] * k).to_canonical();
 }
@@ -201,6 +204,7 @@ void fr_scale_to_canonical(zk_ctx* ctx, const Fr* in, Fr k, Fr* out, size_t n) {
 
 // out[i] = canonical(a[i] * ka + b[i] * kb)
 __global__ void k_lincomb_to_canonical(const Fr* __restrict__ a, Fr ka, const Fr* __restrict__ b, Fr kb, Fr* __restrict__ out, size_t n) {
+    ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (a[i] * ka + b[i] * kb).to_canonical();
 }

@@ -15,7 +15,185 @@ w = rank (mod world) of the inner products (zk_prove_partial), all-gathers the p
 as raw bytes (RCCL cannot reduce group elements) and finishes locally (zk_prove_combine).
 SURVEY.md 8e.  The same function drives the CPU `gloo` test with a stand-in backend.
 """
-from . import PARTIAL_BYTES
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import PARTIAL_BYTES, PROOF_BYTES, ZkError, _lib, fr_to_limbs
+
+
+# ---- the C ABI's own multi-GPU layer (csrc/comm.hip): RCCL inside libzkgpu.so, no torch collective on the data path ----
+def _fr(x):
+    a = np.ascontiguousarray(fr_to_limbs(x) if isinstance(x, int) else x, dtype=np.uint64)
+    return a, a.ctypes.data_as(_lib.u64p)
+
+
+class Comm:
+    """zk_comm.  Comm(ctx, rank, world, id_bytes) = RCCL (zk_comm_init; rank 0 draws the id with Comm.unique_id() and ships it by any
+    channel); Comm(ctx_or_None, rank, world, ops=CommOps) = caller-supplied transport (zk_comm_init_custom)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        rc = _lib.load().zk_comm_unique_id(buf)
+        if rc != 0:
+            raise ZkError(rc)
+        return bytes(buf)
+
+    def __init__(self, ctx, rank, world, id_bytes=None, ops=None):
+        self.lib = _lib.load()
+        self.ctx, self.rank, self.world, self._ops = ctx, rank, world, ops
+        p = C.c_void_p()
+        cptr = ctx.ptr if ctx is not None else None
+        if ops is not None:
+            rc = self.lib.zk_comm_init_custom(cptr, C.byref(ops), rank, world, C.byref(p))
+        else:
+            idb = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(id_bytes) if id_bytes is not None else None
+            rc = self.lib.zk_comm_init(cptr, idb, rank, world, C.byref(p))
+        if rc != 0:
+            raise ZkError(rc, self.lib.zk_last_error(cptr).decode() if cptr else "")
+        self.ptr = p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkError(rc, self.lib.zk_last_error(self.ctx.ptr).decode() if self.ctx is not None else "")
+
+    def barrier(self):
+        self._check(self.lib.zk_comm_barrier(self.ptr))
+
+    def max_f64(self, v):
+        d = C.c_double(v)
+        self._check(self.lib.zk_comm_max_f64(self.ptr, C.byref(d)))
+        return d.value
+
+    def all_to_all(self, d_send, d_recv, bytes_per_rank):
+        self._check(self.lib.zk_comm_all_to_all(self.ptr, C.c_void_p(d_send), C.c_void_p(d_recv), bytes_per_rank))
+
+    def all_gather(self, d_send, d_recv, bytes_per_rank):
+        self._check(self.lib.zk_comm_all_gather(self.ptr, C.c_void_p(d_send), C.c_void_p(d_recv), bytes_per_rank))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.zk_comm_destroy(self.ptr)
+            self.ptr = None
+
+
+def bootstrap_comm(ctx, rank, world, addr=None, port=None):
+    """One process per GPU launched by torch.distributed.run / torchrun: rank 0 draws the RCCL id and publishes it through a
+    TCP key-value store on MASTER_ADDR : MASTER_PORT + 1 (a store, not a collective -- torch.distributed is never
+    initialised); every rank then joins the communicator inside libzkgpu.so."""
+    if world == 1:
+        return Comm(ctx, 0, 1)
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    store = TCPStore(addr, port, world, rank == 0, timeout=timedelta(seconds=300))
+    if rank == 0:
+        store.set("zk_comm_id", Comm.unique_id())
+    comm = Comm(ctx, rank, world, bytes(store.get("zk_comm_id")))
+    comm._store = store      # keeps rank 0's server alive as long as the communicator
+    return comm
+
+
+def gloo_comm(ctx, dist, rank, world):
+    """A zk_comm whose transport is torch.distributed's gloo backend, with the device buffers of the GPU backend staged through
+    the host (zk_comm_init_custom).  For functional runs of the C pipeline with several ranks on ONE GPU, where RCCL refuses
+    to form a communicator; never the measured configuration."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    D2H, H2D = 2, 1
+
+    def staged(fn, send, recv, n_send, n_recv):
+        hs, hr = np.empty(n_send, np.uint8), np.empty(n_recv, np.uint8)
+        if hip.hipMemcpy(hs.ctypes.data, send, n_send, D2H) != 0:
+            return 1
+        fn(torch.from_numpy(hr), torch.from_numpy(hs))
+        return 1 if hip.hipMemcpy(recv, hr.ctypes.data, n_recv, H2D) != 0 else 0
+
+    def a2a(user, send, recv, per_rank):
+        return staged(dist.all_to_all_single, send, recv, per_rank * world, per_rank * world)
+
+    def gather(user, send, recv, per_rank):
+        return staged(dist.all_gather_into_tensor, send, recv, per_rank, per_rank * world)
+
+    def barrier(user):
+        dist.barrier()
+        return 0
+
+    def max_f64(user, val):
+        t = torch.tensor([val[0]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        val[0] = float(t.item())
+        return 0
+
+    ops = _lib.CommOps(None, _lib.A2A_FN(a2a), _lib.A2A_FN(gather), _lib.BARRIER_FN(barrier), _lib.MAXF64_FN(max_f64))
+    return Comm(ctx, rank, world, ops=ops)
+
+
+class MgpuProver:
+    """zk_mgpu: the scalar-exchange prover as a pipeline inside the library.  push() hands in this rank's proof of the next
+    round, pop() returns this rank's proof of the oldest round; both are collective (same call sequence on every rank)."""
+
+    def __init__(self, ctx, comm, crs=None, qap=None, backend=None):
+        self.lib = _lib.load()
+        self.comm, self._backend, self._keep = comm, backend, (crs, qap)
+        p = C.c_void_p()
+        if backend is not None:
+            rc = self.lib.zk_mgpu_create_custom(comm.ptr, C.byref(backend), C.byref(p))
+        else:
+            rc = self.lib.zk_mgpu_create(ctx.ptr, comm.ptr, crs.ptr, qap.ptr, C.byref(p))
+        if rc != 0:
+            raise ZkError(rc, self.lib.zk_last_error(ctx.ptr).decode() if ctx is not None else "")
+        self.ptr = p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ZkError(rc, self.lib.zk_mgpu_last_error(self.ptr).decode())
+
+    def push(self, d_weights_ptr, m, r, s):
+        r_, rp = _fr(r)
+        s_, sp = _fr(s)
+        self._check(self.lib.zk_mgpu_push(self.ptr, C.c_void_p(d_weights_ptr), m, rp, sp))
+
+    def pop(self):
+        out = np.zeros(PROOF_BYTES, dtype=np.uint8)
+        self._check(self.lib.zk_mgpu_pop(self.ptr, out.ctypes.data_as(_lib.u8p)))
+        return out.tobytes()
+
+    def prove_stream(self, jobs, ahead=2):
+        """jobs: iterable of (d_weights_ptr, m, r, s), this rank's proof of each round; yields this rank's proofs in order with
+        `ahead` rounds pushed beyond the one being popped (2 = the pipelined schedule, 0 = one round at a time)."""
+        pending = 0
+        for j in jobs:
+            self.push(*j)
+            pending += 1
+            if pending > ahead:
+                yield self.pop()
+                pending -= 1
+        while pending:
+            yield self.pop()
+            pending -= 1
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.zk_mgpu_destroy(self.ptr)
+            self.ptr = None
+
+
+def prove_sharded_abi(ctx, comm, crs, qap, d_weights_ptr, m, r, s):
+    """zk_mgpu_prove_sharded: one proof over all ranks (latency form); the same bytes on every rank."""
+    r_, rp = _fr(r)
+    s_, sp = _fr(s)
+    out = np.zeros(PROOF_BYTES, dtype=np.uint8)
+    ctx._check(ctx.lib.zk_mgpu_prove_sharded(ctx.ptr, comm.ptr, crs.ptr, qap.ptr, C.c_void_p(d_weights_ptr), m, rp, sp, out.ctypes.data_as(_lib.u8p)))
+    return out.tobytes()
+
+
+# ---- the same protocols driven from Python over torch.distributed (round 1; kept as the fallback transport of bench.py) ----
 
 
 class GpuProver:
