@@ -204,6 +204,14 @@ void zk_crs_free(zk_crs* crs);
  * and returns ZK_ERR_IO for a missing, truncated or altered file. */
 int zk_crs_save(zk_ctx* ctx, const zk_crs* crs, const char* path);
 int zk_crs_load(zk_ctx* ctx, const char* path, zk_crs** out);
+/* The same for a QAP ("ZKQAPv1": the sparse rows over the roots w^j, or the dense coefficient matrices -- what
+ * zk_qap_upload_sparse / zk_qap_upload_dense take; QAP<P> has no serialisation in the reference, groth16/mod.rs:60-67) and for a
+ * proof ("ZKPRFv1": versioned magic | the 259 canonical bytes | checksum; Proof has no encoding in the reference, mod.rs:124-128).
+ * ZK_ERR_IO for missing, truncated, altered or foreign files; values are range-checked by the upload path. */
+int zk_qap_save(zk_ctx* ctx, const zk_qap* qap, const char* path);
+int zk_qap_load(zk_ctx* ctx, const char* path, zk_qap** out);
+int zk_proof_save(const uint8_t proof[ZK_PROOF_BYTES], const char* path);
+int zk_proof_load(const char* path, uint8_t proof_out[ZK_PROOF_BYTES]);
 
 /* ------------------------------------------------------------------------------------------
  * prove  (groth16::prove, groth16/mod.rs:213-296) with (r, s) injected (mod.rs:231)

@@ -23,7 +23,7 @@ R_MODULUS = 21888242871839275222246405745257275088548364400416034343698204186575
 Q_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 
 __all__ = ["Context", "ZkError", "fr_to_limbs", "limbs_to_int", "ints_to_limbs", "limbs_to_ints",
-           "PROOF_BYTES", "PARTIAL_BYTES", "MAX_IN_FLIGHT", "MAX_BATCH", "R_MODULUS", "Q_MODULUS", "SplitMix64", "pairing"]
+           "PROOF_BYTES", "PARTIAL_BYTES", "MAX_IN_FLIGHT", "MAX_BATCH", "R_MODULUS", "Q_MODULUS", "SplitMix64", "pairing", "proof_save", "proof_load"]
 
 
 class ZkError(RuntimeError):
@@ -100,6 +100,22 @@ def pairing(g1, g2):
     if rc != 0:
         raise ZkError(rc)
     return limbs_to_ints(out)
+
+
+def proof_save(proof, path):
+    """zk_proof_save: versioned proof file ("ZKPRFv1" | 259 canonical bytes | checksum)."""
+    buf = (C.c_uint8 * PROOF_BYTES).from_buffer_copy(proof)
+    rc = _lib.load().zk_proof_save(buf, str(path).encode())
+    if rc != 0:
+        raise ZkError(rc)
+
+
+def proof_load(path):
+    buf = (C.c_uint8 * PROOF_BYTES)()
+    rc = _lib.load().zk_proof_load(str(path).encode(), buf)
+    if rc != 0:
+        raise ZkError(rc)
+    return bytes(buf)
 
 
 class _Handle:
@@ -294,6 +310,21 @@ class Context:
         c = Crs(self, p, self.lib.zk_crs_free)
         c.n, c.m, c.input = n, m, input
         return c
+
+    def qap_save(self, qap, path):
+        """Write the QAP container (zk_qap_save): sparse rows or dense matrices."""
+        self._check(self.lib.zk_qap_save(self.ptr, qap.ptr, str(path).encode()))
+
+    def qap_load(self, path):
+        p = C.c_void_p()
+        self._check(self.lib.zk_qap_load(self.ptr, str(path).encode(), C.byref(p)))
+        q = Qap(self, p, self.lib.zk_qap_free)
+        n, m, l, dense = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+        self._check(self.lib.zk_qap_dims(p, C.byref(n), C.byref(m), C.byref(l), C.byref(dense)))
+        q.n, q.m, q.input, q.dense = n.value, m.value, l.value, bool(dense.value)
+        if not q.dense:
+            q.log_n = q.n.bit_length() - 1
+        return q
 
     def crs_save(self, crs, path):
         """Write the CRS container (zk_crs_save)."""

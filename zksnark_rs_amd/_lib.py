@@ -126,6 +126,10 @@ SIGNATURES = {
     "zk_prove_msm_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
+    "zk_qap_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p]),
+    "zk_qap_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "zk_proof_save": (C.c_int, [u8p, C.c_char_p]),
+    "zk_proof_load": (C.c_int, [C.c_char_p, u8p]),
     "zk_device_count": (C.c_int, []),
     "zk_comm_unique_id": (C.c_int, [u8p]),
     "zk_comm_init": (C.c_int, [C.c_void_p, u8p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

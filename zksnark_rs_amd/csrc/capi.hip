@@ -190,6 +190,23 @@ int zk_crs_dims(const zk_crs* crs, size_t* n, size_t* m, size_t* input) {
     crs_dims(*crs, n, m, input);
     return ZK_OK;
 }
+int zk_qap_save(zk_ctx* ctx, const zk_qap* qap, const char* path) {
+    if (!ctx || !qap || !path) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { qap_save(ctx, *qap, path); });
+}
+int zk_qap_load(zk_ctx* ctx, const char* path, zk_qap** out) {
+    if (!ctx || !path || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = qap_load(ctx, path); });
+}
+int zk_proof_save(const uint8_t proof[ZK_PROOF_BYTES], const char* path) {
+    if (!proof || !path) return ZK_ERR_ARG;
+    return guarded(nullptr, [&] { proof_save(proof, path); });
+}
+int zk_proof_load(const char* path, uint8_t proof_out[ZK_PROOF_BYTES]) {
+    if (!proof_out || !path) return ZK_ERR_ARG;
+    return guarded(nullptr, [&] { proof_load(path, proof_out); });
+}
 int zk_crs_save(zk_ctx* ctx, const zk_crs* crs, const char* path) {
     if (!ctx || !crs || !path) return ZK_ERR_ARG;
     return guarded(ctx, [&] { crs_save(ctx, *crs, path); });

@@ -63,6 +63,10 @@ namespace zk {
 zk_qap* qap_upload_sparse(zk_ctx*, const zk_qap_sparse_desc&);
 zk_qap* qap_upload_dense(zk_ctx*, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input);
 void qap_free(zk_qap*);
+void qap_save(zk_ctx*, const zk_qap&, const char* path);      // serialize.hip
+zk_qap* qap_load(zk_ctx*, const char* path);
+void proof_save(const uint8_t proof[ZK_PROOF_BYTES], const char* path);
+void proof_load(const char* path, uint8_t proof[ZK_PROOF_BYTES]);
 
 zk_crs* crs_upload(zk_ctx*, const zk_crs_desc&);
 zk_crs* crs_setup(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20]);

@@ -1,4 +1,4 @@
-// serialize.hip -- on-disk container for the CRS.
+// serialize.hip -- on-disk containers for the CRS, the QAP and proofs.
 //
 // The reference keeps (SigmaG1, SigmaG2) (/root/reference/src/groth16/mod.rs:105-121) in memory only
 // and has no serialisation; re-running groth16::setup (mod.rs:134-197) draws a new
@@ -84,6 +84,134 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
     zk_crs_desc d{n, m, input, b + lay.off[0], b + lay.off[1], b + lay.off[2], b + lay.off[3], b + lay.off[4], b + lay.off[5], b + lay.off[6],
                   b + lay.off[7], b + lay.off[8], b + lay.off[9], b + lay.off[10]};
     return crs_upload(ctx, d);
+}
+
+// ---- QAP container ("ZKQAPv1") and proof file ("ZKPRFv1") ------------------------------------------------------------
+// The reference cannot store a QAP either (QAP<P> has private fields and no serialisation, groth16/mod.rs:60-67); the container
+// holds what zk_qap_upload_sparse / zk_qap_upload_dense take, as canonical little-endian integers:
+//   offset 0   "ZKQAPv1\0"
+//          8   kind (0 = sparse rows over the roots w^j, 1 = dense coefficient matrices), n_or_log_n, m, input      4 x u64
+//         40   nnz(u), nnz(v), nnz(w)  (0 for the dense kind)                                                    3 x u64
+//         64   FNV-1a 64 of the payload
+//         72   payload  sparse: for u, v, w: ptr[m+1] (u64) | gate[nnz] (u32, padded to 8 bytes) | val[nnz] (32 B)
+//                       dense : u, v, w (m n x 32 B each), t ((n+1) x 32 B)
+// Loading goes through the upload entry points, so every value is range-checked on the GPU.
+namespace {
+constexpr char QMAGIC[8] = {'Z', 'K', 'Q', 'A', 'P', 'v', '1', '\0'};
+constexpr char PMAGIC[8] = {'Z', 'K', 'P', 'R', 'F', 'v', '1', '\0'};
+
+void csr_to_host(zk_ctx* ctx, const DevCsr& c, size_t rows, std::vector<uint64_t>& ptr, std::vector<uint32_t>& gate, std::vector<uint64_t>& val) {
+    std::vector<uint32_t> p32(rows + 1);
+    ZK_HIP(hipMemcpy(p32.data(), c.ptr.p, (rows + 1) * 4, hipMemcpyDeviceToHost));
+    ptr.assign(p32.begin(), p32.end());
+    const size_t nnz = p32[rows];
+    gate.assign(nnz + (nnz & 1), 0);
+    val.assign(nnz * 4, 0);
+    if (!nnz) return;
+    ZK_HIP(hipMemcpy(gate.data(), c.idx.p, nnz * 4, hipMemcpyDeviceToHost));
+    DevBuf<Fr> tmp(nnz);
+    fr_from_mont(ctx, c.val.p, tmp.p, nnz);
+    ZK_HIP(hipMemcpyAsync(val.data(), tmp.p, nnz * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+}
+}  // namespace
+
+void qap_save(zk_ctx* ctx, const zk_qap& q, const char* path) {
+    std::vector<uint64_t> payload;
+    uint64_t head[9] = {0};
+    std::memcpy(head, QMAGIC, 8);
+    head[1] = q.dense ? 1 : 0; head[2] = q.dense ? q.n : q.log_n; head[3] = q.m; head[4] = q.input;
+    if (!q.dense) {
+        const DevCsr* rows[3] = {&q.u_wire, &q.v_wire, &q.w_wire};
+        for (int k = 0; k < 3; ++k) {
+            std::vector<uint64_t> ptr, val;
+            std::vector<uint32_t> gate;
+            csr_to_host(ctx, *rows[k], q.m, ptr, gate, val);
+            head[5 + k] = ptr[q.m];
+            payload.insert(payload.end(), ptr.begin(), ptr.end());
+            const size_t at = payload.size();
+            payload.resize(at + gate.size() / 2);
+            std::memcpy(payload.data() + at, gate.data(), gate.size() * 4);
+            payload.insert(payload.end(), val.begin(), val.end());
+        }
+    } else {
+        const size_t mn = q.m * q.n;
+        payload.resize((3 * mn + q.n + 1) * 4);
+        DevBuf<Fr> tmp(std::max(mn, q.n + 1));
+        const Fr* src[4] = {q.du.p, q.dv.p, q.dw.p, q.dt.p};
+        for (int k = 0; k < 4; ++k) {
+            const size_t cnt = k < 3 ? mn : q.n + 1;
+            fr_from_mont(ctx, src[k], tmp.p, cnt);
+            ZK_HIP(hipMemcpyAsync(payload.data() + (size_t)k * mn * 4, tmp.p, cnt * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+            ZK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    head[8] = fnv1a(reinterpret_cast<const uint8_t*>(payload.data()), payload.size() * 8);
+    File f(std::fopen(path, "wb"));
+    ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("qap_save: cannot open ") + path);
+    bool ok = std::fwrite(head, 8, 9, f.f) == 9 && std::fwrite(payload.data(), 8, payload.size(), f.f) == payload.size() && std::fflush(f.f) == 0;
+    ZK_REQUIRE(ok, ZK_ERR_IO, std::string("qap_save: short write to ") + path);
+}
+
+zk_qap* qap_load(zk_ctx* ctx, const char* path) {
+    File f(std::fopen(path, "rb"));
+    ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("qap_load: cannot open ") + path);
+    uint64_t head[9];
+    ZK_REQUIRE(std::fread(head, 8, 9, f.f) == 9 && !std::memcmp(head, QMAGIC, 8), ZK_ERR_IO, "qap_load: not a ZKQAPv1 file");
+    const uint64_t kind = head[1], m = head[3], input = head[4];
+    ZK_REQUIRE(kind <= 1 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
+    size_t words;
+    if (kind == 0) {
+        ZK_REQUIRE(head[2] <= 26 && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
+        words = 0;
+        for (int k = 0; k < 3; ++k) words += (m + 1) + (head[5 + k] + 1) / 2 + head[5 + k] * 4;
+    } else {
+        ZK_REQUIRE(head[2] >= 1 && head[2] <= ((uint64_t)1 << 22) && m * head[2] <= ((uint64_t)1 << 33), ZK_ERR_IO, "qap_load: implausible header");
+        words = (3 * m * head[2] + head[2] + 1) * 4;
+    }
+    std::vector<uint64_t> buf(words);
+    ZK_REQUIRE(std::fread(buf.data(), 8, words, f.f) == words, ZK_ERR_IO, "qap_load: file is truncated");
+    uint8_t extra;
+    ZK_REQUIRE(std::fread(&extra, 1, 1, f.f) == 0, ZK_ERR_IO, "qap_load: trailing bytes after the payload");
+    ZK_REQUIRE(fnv1a(reinterpret_cast<const uint8_t*>(buf.data()), words * 8) == head[8], ZK_ERR_IO, "qap_load: checksum mismatch");
+    if (kind == 1) {
+        const size_t mn = m * head[2];
+        return qap_upload_dense(ctx, buf.data(), buf.data() + mn * 4, buf.data() + 2 * mn * 4, buf.data() + 3 * mn * 4, m, head[2], input);
+    }
+    zk_qap_sparse_desc d{};
+    d.log_n = (unsigned)head[2]; d.m = m; d.input = input;
+    zk_sparse_rows* rows[3] = {&d.u, &d.v, &d.w};
+    const uint64_t* at = buf.data();
+    for (int k = 0; k < 3; ++k) {
+        const size_t nnz = head[5 + k];
+        rows[k]->ptr = at; at += m + 1;
+        ZK_REQUIRE(rows[k]->ptr[m] == nnz, ZK_ERR_IO, "qap_load: row offsets disagree with the header");
+        rows[k]->gate = reinterpret_cast<const uint32_t*>(at); at += (nnz + 1) / 2;
+        rows[k]->val = at; at += nnz * 4;
+    }
+    return qap_upload_sparse(ctx, d);
+}
+
+// A proof on disk: magic (the version lives in it), the 259 canonical bytes, FNV-1a 64 of them.  The in-memory encoding of the
+// ABI stays the bare 259 bytes -- the reference's Proof has no encoding at all (mod.rs:124-128).
+void proof_save(const uint8_t proof[ZK_PROOF_BYTES], const char* path) {
+    File f(std::fopen(path, "wb"));
+    ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("proof_save: cannot open ") + path);
+    const uint64_t sum = fnv1a(proof, ZK_PROOF_BYTES);
+    bool ok = std::fwrite(PMAGIC, 1, 8, f.f) == 8 && std::fwrite(proof, 1, ZK_PROOF_BYTES, f.f) == ZK_PROOF_BYTES && std::fwrite(&sum, 8, 1, f.f) == 1 && std::fflush(f.f) == 0;
+    ZK_REQUIRE(ok, ZK_ERR_IO, std::string("proof_save: short write to ") + path);
+}
+void proof_load(const char* path, uint8_t proof[ZK_PROOF_BYTES]) {
+    File f(std::fopen(path, "rb"));
+    ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("proof_load: cannot open ") + path);
+    char magic[8];
+    uint64_t sum;
+    uint8_t extra;
+    ZK_REQUIRE(std::fread(magic, 1, 8, f.f) == 8 && !std::memcmp(magic, PMAGIC, 8), ZK_ERR_IO, "proof_load: not a ZKPRFv1 file");
+    ZK_REQUIRE(std::fread(proof, 1, ZK_PROOF_BYTES, f.f) == ZK_PROOF_BYTES && std::fread(&sum, 8, 1, f.f) == 1, ZK_ERR_IO, "proof_load: file is truncated");
+    ZK_REQUIRE(std::fread(&extra, 1, 1, f.f) == 0, ZK_ERR_IO, "proof_load: trailing bytes");
+    ZK_REQUIRE(sum == fnv1a(proof, ZK_PROOF_BYTES), ZK_ERR_IO, "proof_load: checksum mismatch");
+    ZK_REQUIRE((proof[0] == 0 || proof[0] == 4) && (proof[65] == 0 || proof[65] == 4) && (proof[194] == 0 || proof[194] == 4), ZK_ERR_IO, "proof_load: unknown point tag");
 }
 
 }  // namespace zk
