@@ -135,6 +135,15 @@ typedef struct {
     zk_sparse_rows u, v, w;
 } zk_qap_sparse_desc;
 int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** out);
+/* The same rows over the roots ASTParser emits, the integers 1..n (circuit/mod.rs:517: `roots: (1..=n)`), for any
+ * n <= 2^21 (desc->log_n is ignored).  Equivalent to QAP::from(root_rep) (fr.rs:140-173) followed by the reference's
+ * coefficient-form prove (mod.rs:199-290) -- the proofs are byte-identical to the dense form's -- but nothing is ever
+ * interpolated: the prover keeps U, V as values on {1..n}, the quotient as values on {n+1..2n-1}, and takes its inner
+ * products with the CRS in those Lagrange bases, which zk_setup emits next to the reference's [x^i] arrays.  Costs
+ * O(nnz + n log n) per proof where the dense form is O(m n); SURVEY.md 8-f4.  A CRS for such a QAP must come from
+ * zk_setup on this library (zk_crs_upload / zk_crs_load carry only the reference's arrays: ZK_ERR_UNSUPPORTED at prove);
+ * batches and the multi-GPU scalar exchange need the roots-of-unity form. */
+int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out);
 
 /* Dense coefficient form, exactly the fields of QAP<CoefficientPoly<FrLocal>>: u, v, w are
  * m x n row-major (coefficient k of wire i at [i*n + k], zero padded), t has n+1 coefficients
@@ -168,6 +177,8 @@ const char* zk_circuit_last_error(const zk_circuit* c);
 /* QAP<CoefficientPoly<FrLocal>>::from(root_rep) (fr.rs:140-173; Lagrange interpolation
  * coefficient_poly.rs:159-200) on the GPU for the circuit's roots 1..n -> dense device QAP. */
 int zk_circuit_qap(zk_ctx* ctx, const zk_circuit* c, zk_qap** out);
+/* The same QAP through zk_qap_upload_sparse_integers: no interpolation, no 16384-gate limit, identical proofs. */
+int zk_circuit_qap_sparse(zk_ctx* ctx, const zk_circuit* c, zk_qap** out);
 
 /* ------------------------------------------------------------------------------------------
  * CRS  (SigmaG1 / SigmaG2, groth16/mod.rs:105-121)

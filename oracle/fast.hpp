@@ -169,7 +169,8 @@ struct SparseQap {
     unsigned log_n = 0;
     size_t m = 0, input = 0;
     SparseMat u, v, w;
-    size_t n() const { return (size_t)1 << log_n; }
+    size_t n_ap = 0;   // > 0: the domain is the integers 1..n_ap (ASTParser's roots, circuit/mod.rs:517) instead of the roots of unity
+    size_t n() const { return n_ap ? n_ap : (size_t)1 << log_n; }
 
     // evaluation vector over the domain: E[j] = sum_i weights[i] * M_i(omega^j)
     std::vector<Fr> eval_vec(const SparseMat& M, const std::vector<Fr>& weights) const {
@@ -196,6 +197,25 @@ struct SparseQap {
         for (size_t j = 0; j < N; ++j) L[j] = c * wj[j] * den[j];
         return L;
     }
+    // Lagrange basis values L_k(x), k = 1..n, for the domain {1, .., n}: L_k(x) = t(x) w_k / (x - k), t(x) = prod (x - j),
+    // w_k = 1 / prod_{j != k} (k - j) = (-1)^(n-k) / ((k-1)! (n-k)!)   (coefficient_poly.rs:173-190 evaluated at x)
+    std::vector<Fr> lagrange_at_integers(const Fr& x, Fr* t_at_x = nullptr) const {
+        const size_t N = n();
+        std::vector<Fr> fact(N + 1), den(N), L(N);
+        fact[0] = Fr::one();
+        for (size_t j = 1; j <= N; ++j) fact[j] = fact[j - 1] * Fr::from_u64(j);
+        Fr tx = Fr::one();
+        for (size_t k = 1; k <= N; ++k) { den[k - 1] = x - Fr::from_u64(k); tx = tx * den[k - 1]; }
+        if (t_at_x) *t_at_x = tx;
+        for (size_t k = 1; k <= N; ++k) {
+            if (den[k - 1].is_zero()) { for (auto& l : L) l = Fr::zero(); L[k - 1] = Fr::one(); return L; }
+            den[k - 1] = den[k - 1] * fact[k - 1] * fact[N - k];
+            if ((N - k) & 1) den[k - 1] = -den[k - 1];
+        }
+        batch_inverse(den);
+        for (size_t k = 0; k < N; ++k) L[k] = tx * den[k];
+        return L;
+    }
     std::vector<Fr> wire_evals(const SparseMat& M, const std::vector<Fr>& L) const {
         std::vector<Fr> out(m, Fr::zero());
         for (size_t i = 0; i < m; ++i)
@@ -214,7 +234,7 @@ inline BnCrs fast_setup(const SparseQap& q, const Trapdoor<Fr>& td) {
     static FixedBase<Fq> fb1(enc_base_g1());
     static FixedBase<Fq2> fb2(enc_base_g2());
     size_t n = q.n();
-    std::vector<Fr> L = q.lagrange_at(td.x);
+    std::vector<Fr> L = q.n_ap ? q.lagrange_at_integers(td.x) : q.lagrange_at(td.x);
     std::vector<Fr> ux = q.wire_evals(q.u, L), vx = q.wire_evals(q.v, L), wx = q.wire_evals(q.w, L);
     Fr tx = td.x;
     for (unsigned k = 0; k < q.log_n; ++k) tx = tx.sqr();
@@ -338,7 +358,7 @@ inline Proof<G1, G2> fast_prove(const SparseQap& q, const BnCrs& crs, const std:
 // Closed-form honest proof for a SparseQap (O(n) field work; usable at n = 2^20).
 inline Proof<G1, G2> fast_trapdoor_proof(const SparseQap& q, const Trapdoor<Fr>& td, const std::vector<Fr>& weights,
                                          const Fr& r, const Fr& s) {
-    std::vector<Fr> L = q.lagrange_at(td.x);
+    std::vector<Fr> L = q.n_ap ? q.lagrange_at_integers(td.x) : q.lagrange_at(td.x);
     std::vector<Fr> ux = q.wire_evals(q.u, L), vx = q.wire_evals(q.v, L), wx = q.wire_evals(q.w, L);
     std::vector<Fr> Ue = q.eval_vec(q.u, weights), Ve = q.eval_vec(q.v, weights), We = q.eval_vec(q.w, weights);
     Fr U = Fr::zero(), V = Fr::zero(), W = Fr::zero(), rem = Fr::zero();

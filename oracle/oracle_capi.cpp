@@ -289,6 +289,15 @@ int orc_trapdoor_proof_sparse(const zk_qap_sparse_desc* d, const uint64_t trapdo
                               const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
     return guarded([&] { wr_proof(fast_trapdoor_proof(rd_sparse(d), rd_td(trapdoor), rd_frs(weights, m_w), rd_f<Fr>(r), rd_f<Fr>(s)), proof); });
 }
+// the same for the domain {1, .., n} (ASTParser's roots): the rows' gate index g means the root g + 1; d->log_n is ignored
+int orc_trapdoor_proof_integers(const zk_qap_sparse_desc* d, size_t n, const uint64_t trapdoor[20], const uint64_t* weights, size_t m_w,
+                                const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
+    return guarded([&] {
+        SparseQap q = rd_sparse(d);
+        q.n_ap = n;
+        wr_proof(fast_trapdoor_proof(q, rd_td(trapdoor), rd_frs(weights, m_w), rd_f<Fr>(r), rd_f<Fr>(s)), proof);
+    });
+}
 int orc_trapdoor_proof_dense(const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input,
                              const uint64_t trapdoor[20], const uint64_t* weights, size_t m_w, const uint64_t r[4], const uint64_t s[4], uint8_t proof[259]) {
     return guarded([&] {

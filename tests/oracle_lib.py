@@ -154,6 +154,15 @@ class Oracle:
                                                      _p(fr_to_limbs(r)), _p(fr_to_limbs(s)), out.ctypes.data_as(u8p)))
         return out.tobytes()
 
+    def trapdoor_proof_integers(self, desc, n, trapdoor, weights, r, s):
+        """closed-form proof for sparse rows over the roots 1..n (gate index g = root g + 1)"""
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.uint64).reshape(-1, 4))
+        td = np.ascontiguousarray(trapdoor, dtype=np.uint64)
+        out = np.zeros(259, np.uint8)
+        self._chk(self.lib.orc_trapdoor_proof_integers(C.byref(desc), C.c_size_t(n), _p(td), _p(w), C.c_size_t(w.shape[0]),
+                                                       _p(fr_to_limbs(r)), _p(fr_to_limbs(s)), out.ctypes.data_as(u8p)))
+        return out.tobytes()
+
     def trapdoor_proof_dense(self, u, v, w, t, input, trapdoor, weights, r, s):
         m, n = u.shape[0], u.shape[1]
         wt = np.ascontiguousarray(np.asarray(weights, dtype=np.uint64).reshape(-1, 4))

@@ -1,0 +1,257 @@
+"""Sparse QAPs over the roots ASTParser emits, the integers 1..n (circuit/mod.rs:517), at any size -- SURVEY.md 8-f4.
+
+CPU: the oracle's closed form for that domain (oracle/fast.hpp lagrange_at_integers) is pinned to the fixture proofs of
+simple.zk and deg_15.zk, i.e. to the faithful coefficient-form restatement of mod.rs:199-290.
+GPU: zk_qap_upload_sparse_integers / zk_circuit_qap_sparse give the bytes of the dense (reference-shaped) path wherever that
+path runs, and the closed form's bytes beyond it, up to BASELINE's 2^20 gates.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zksnark_rs_amd as zk
+from zksnark_rs_amd import SplitMix64, ints_to_limbs, limbs_to_int
+from zksnark_rs_amd.circuit import Circuit
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PROOFS = json.load(open(os.path.join(GOLD, "proofs.json")))
+H = lambda s: int(s, 16)   # noqa: E731
+
+
+def case(name):
+    return next(c for c in PROOFS["cases"] if c["name"] == name)
+
+
+def case_inputs(c):
+    return [v if isinstance(v, int) else H(v) for v in c["inputs"]]
+
+
+def chain_program(n):
+    """deg_15.zk generalised to n gates: t1 = x*a1, tk = x*(t(k-1) + ak), y = 1*(t(n-1) + an)."""
+    ins = " ".join("a%d" % k for k in range(1, n + 1))
+    body = ["    (= t1 (* x a1))"]
+    body += ["    (= t%d (* x (+ t%d a%d)))" % (k, k - 1, k) for k in range(2, n)]
+    body.append("    (= y (* 1 (+ t%d a%d))))" % (n - 1, n))
+    return "(in x %s)\n(out y)\n(verify x y)\n\n(program\n%s\n" % (ins, "\n".join(body))
+
+
+def random_rows(rng, n, m, density):
+    ptr, gates, vals = [0], [], []
+    for _ in range(m):
+        k = rng.next() % (density + 1)
+        gs = sorted({int(rng.next() % n) for _ in range(k)})
+        gates += gs
+        vals += [rng.fr() for _ in gs]
+        ptr.append(len(gates))
+    val = ints_to_limbs(vals) if vals else np.zeros((0, 4), np.uint64)
+    return np.array(ptr, np.uint64), np.array(gates, np.uint32), val
+
+
+def chain_rows_integers(n):
+    """Rows of chain_program(n) in the parser's own wire order, without going through the parser (2^20 gates of program text
+    would be 40 MB): wires 1 | x | y | t_1 a_1 t_2 a_2 .. t_(n-1) a_(n-1) | a_n; gate k: x * (t_(k-1) + a_k) = t_k, the last
+    gate 1 * (t_(n-1) + a_n) = y."""
+    m = 2 * n + 2
+    one = ints_to_limbs([1])[0]
+    tw = lambda k: 3 + 2 * (k - 1)                         # noqa: E731  wire of t_k, k = 1..n-1
+    aw = lambda k: 4 + 2 * (k - 1) if k < n else 2 * n + 1   # noqa: E731  wire of a_k, k = 1..n
+    u = [[] for _ in range(m)]; v = [[] for _ in range(m)]; w = [[] for _ in range(m)]
+    for g in range(n):                                     # gate g computes t_(g+1) (y for the last)
+        (u[1] if g < n - 1 else u[0]).append(g)
+        v[aw(g + 1)].append(g)
+        if g > 0:
+            v[tw(g)].append(g)
+        (w[tw(g + 1)] if g < n - 1 else w[2]).append(g)
+
+    def pack(rows):
+        ptr = np.zeros(m + 1, np.uint64)
+        ptr[1:] = np.cumsum([len(r) for r in rows])
+        gate = np.array([g for r in rows for g in r], np.uint32)
+        return ptr, gate, np.tile(one, (len(gate), 1))
+    return m, 2, pack(u), pack(v), pack(w)
+
+
+def chain_weights_integers(n, x, avals):
+    P = zk.R_MODULUS
+    t, out = 0, [1, x, 0]
+    for k in range(n - 1):
+        t = x * ((t + avals[k]) % P) % P
+        out += [t, avals[k]]
+    out[2] = (t + avals[n - 1]) % P
+    return ints_to_limbs(out + [avals[n - 1]])
+
+
+# ---------------------------------------------------------------- CPU
+@pytest.mark.parametrize("name", ["simple.zk", "deg_15.zk"])
+def test_closed_form_for_integer_roots_reproduces_fixture_proofs(orc, name):
+    c = case(name)
+    circ = Circuit(open(os.path.join(GOLD, "zk", name)).read())
+    weights = circ.weights(case_inputs(c))
+    assert [limbs_to_int(w) for w in weights] == [H(w) for w in c["weights"]]
+    desc = zk.Context.sparse_desc(0, circ.m, circ.input, circ.rows(0), circ.rows(1), circ.rows(2))
+    td = ints_to_limbs([H(t) for t in c["trapdoor"]])
+    assert orc.trapdoor_proof_integers(desc, circ.n, td, weights, H(c["r"]), H(c["s"])).hex() == c["proof"]
+    bad = weights.copy(); bad[2, 0] ^= np.uint64(1)
+    q = orc.zk_qap_dense(open(os.path.join(GOLD, "zk", name)).read())
+    want_bad = orc.trapdoor_proof_dense(q["u"], q["v"], q["w"], q["t"], q["input"], td, bad, H(c["r"]), H(c["s"]))
+    assert orc.trapdoor_proof_integers(desc, circ.n, td, bad, H(c["r"]), H(c["s"])) == want_bad
+
+
+def test_chain_rows_helper_matches_the_parser():
+    n = 9
+    circ = Circuit(chain_program(n))
+    m, l, u, v, w = chain_rows_integers(n)
+    assert (circ.n, circ.m, circ.input) == (n, m, l)
+    for k, mine in enumerate((u, v, w)):
+        ptr, gate, val = circ.rows(k)
+        assert np.array_equal(ptr, mine[0]) and np.array_equal(gate, mine[1]) and np.array_equal(val, mine[2]), k
+    rng = SplitMix64(5)
+    ins = [rng.fr() for _ in range(n + 1)]
+    assert np.array_equal(circ.weights(ins), chain_weights_integers(n, ins[0], ins[1:]))
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simple.zk", "deg_15.zk"])
+def test_gpu_sparse_form_reproduces_fixture_proofs(ctx, name):
+    c = case(name)
+    circ = Circuit(open(os.path.join(GOLD, "zk", name)).read())
+    weights = circ.weights(case_inputs(c))
+    qap = circ.qap_sparse(ctx)
+    crs = ctx.setup(qap, ints_to_limbs([H(t) for t in c["trapdoor"]]))
+    proof = ctx.prove(crs, qap, weights, H(c["r"]), H(c["s"]))
+    assert proof.hex() == c["proof"]
+    assert ctx.verify(crs, [v if isinstance(v, int) else H(v) for v in c["verify_inputs"]], proof)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["simple.zk", "lispesque_quad.zk", "lispesque_cubic.zk", "deg_15.zk"])
+def test_gpu_sparse_form_matches_faithful_oracle(ctx, orc, prog):
+    """same CRS arrays and same proof bytes as the reference's coefficient-form path (mod.rs:134-290) on QAP::from(root_rep)"""
+    code = open(os.path.join(GOLD, "zk", prog)).read()
+    q = orc.zk_qap_dense(code)
+    circ = Circuit(code)
+    rng = SplitMix64(77 + len(code))
+    weights = circ.weights([rng.fr() for _ in range(q["n_in"])])
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    qap = circ.qap_sparse(ctx)
+    crs = ctx.setup(qap, td)
+    arrs = ctx.crs_download(crs)
+    want = orc.setup_dense(q["u"], q["v"], q["w"], q["t"], q["input"], td)
+    for k in want:
+        assert np.array_equal(arrs[k], want[k]), k
+    cdesc = ctx.crs_desc(q["n"], q["m"], q["input"], arrs)
+    bad = weights.copy(); bad[2, 0] += np.uint64(1)
+    for wts in (weights, bad, weights[:-1], np.concatenate([weights, weights[:2]])):
+        assert ctx.prove(crs, qap, wts, r, s) == orc.prove_dense(q["u"], q["v"], q["w"], q["t"], q["input"], cdesc, wts, r, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 5, 600, 1025, 4096])
+def test_gpu_sparse_form_equals_dense_form(ctx, n):
+    """the two device forms of one ASTParser circuit: identical CRS, identical bytes for a valid and an invalid witness"""
+    circ = Circuit(chain_program(n))
+    rng = SplitMix64(9100 + n)
+    weights = circ.weights([rng.fr() for _ in range(n + 1)])
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    qd, qs = circ.qap(ctx), circ.qap_sparse(ctx)
+    cd, cs = ctx.setup(qd, td), ctx.setup(qs, td)
+    ad, as_ = ctx.crs_download(cd), ctx.crs_download(cs)
+    for k in ad:
+        assert np.array_equal(ad[k], as_[k]), k
+    r, s = rng.fr(), rng.fr()
+    bad = weights.copy(); bad[5 % circ.m, 0] ^= np.uint64(1)
+    good = ctx.prove(cs, qs, weights, r, s)
+    assert good == ctx.prove(cd, qd, weights, r, s)
+    assert ctx.prove(cs, qs, bad, r, s) == ctx.prove(cd, qd, bad, r, s)
+    pub = [limbs_to_int(weights[1]), limbs_to_int(weights[2])]
+    assert ctx.verify(cs, pub, good)
+    # pipelined submissions of the sparse form (slots alternate main streams)
+    hosts = [np.ascontiguousarray(w) for w in (weights, bad, weights)]
+    t = [ctx.prove_submit_host(cs, qs, w.ctypes.data, w.shape[0], r, s) for w in hosts]
+    got = [ctx.prove_wait(x) for x in t]
+    assert got[0] == good and got[2] == good and got[1] != good
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,l", [(1, 4, 1), (2, 5, 0), (7, 20, 3), (100, 260, 5), (1000, 1500, 2), (4099, 3000, 1)])
+def test_gpu_random_rows_match_closed_form(ctx, orc, n, m, l):
+    """arbitrary rows (empty wires, m unrelated to n, n not a power of two), unsatisfying witnesses of three lengths"""
+    rng = SplitMix64(9300 + n)
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    desc = ctx.sparse_desc(0, m, l, u, v, w)
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    for count in (m, max(l + 1, m - 3), m + 2):
+        wts = ints_to_limbs([1] + [rng.fr() for _ in range(count - 1)])
+        assert ctx.prove(crs, qap, wts, r, s) == orc.trapdoor_proof_integers(desc, n, td, wts, r, s), count
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [(1 << 16) + 3, 1 << 20])
+def test_gpu_chain_circuit_at_full_size(ctx, orc, n):
+    """BASELINE's 2^20 gates with the roots the reference's parser would give that circuit (dense form: 3 m n field elements
+    = 211 TB)"""
+    m, l, u, v, w = chain_rows_integers(n)
+    rng = SplitMix64(9500 + (n & 0xFFFF))
+    x, avals = rng.fr(), [rng.fr() for _ in range(n)]
+    weights = chain_weights_integers(n, x, avals)
+    desc = ctx.sparse_desc(0, m, l, u, v, w)
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    good = ctx.prove(crs, qap, weights, r, s)
+    assert good == orc.trapdoor_proof_integers(desc, n, td, weights, r, s)
+    assert ctx.verify(crs, [x, limbs_to_int(weights[2])], good)
+    bad = weights.copy(); bad[n // 2, 0] ^= np.uint64(1)
+    got_bad = ctx.prove(crs, qap, bad, r, s)
+    assert got_bad == orc.trapdoor_proof_integers(desc, n, td, bad, r, s)
+    assert not ctx.verify(crs, [x, limbs_to_int(weights[2])], got_bad)
+
+
+@pytest.mark.gpu
+def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
+    n = 12
+    circ = Circuit(chain_program(n))
+    rng = SplitMix64(9700)
+    weights = circ.weights([rng.fr() for _ in range(n + 1)])
+    qap = circ.qap_sparse(ctx)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    good = ctx.prove(crs, qap, weights, r, s)
+    # a CRS that carries only the reference's arrays cannot serve this form
+    crs2 = ctx.crs_upload(circ.n, circ.m, circ.input, ctx.crs_download(crs))
+    with pytest.raises(zk.ZkError) as e:
+        ctx.prove(crs2, qap, weights, r, s)
+    assert e.value.status == -7 and "zk_setup" in str(e.value)
+    # ... but serves the dense form of the same circuit, with the same bytes
+    assert ctx.prove(crs2, circ.qap(ctx), weights, r, s) == good
+    # x among 1..2n-1: the Lagrange denominators vanish
+    with pytest.raises(zk.ZkError) as e:
+        ctx.setup(qap, ints_to_limbs([5, 6, 7, 8, 2 * n - 1]))
+    assert e.value.status == -7
+    # batches and the scalar exchange want the roots-of-unity form
+    host = np.ascontiguousarray(weights)
+    with pytest.raises(zk.ZkError) as e:
+        ctx.prove_batch_submit(crs, qap, [host.ctypes.data], [host.shape[0]], [r], [s])   # refused before the pointer is touched
+    assert e.value.status == -7
+    with pytest.raises(zk.ZkError) as e:
+        ctx.prove_exchange_elems(qap, 2)
+    assert e.value.status == -7
+    # size limit
+    one = (np.zeros(3, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64))
+    with pytest.raises(zk.ZkError) as e:
+        ctx.qap_sparse_integers((1 << 21) + 1, 2, 0, one, one, one)
+    assert e.value.status == -4
+    # container: kind 2 round trip
+    ctx.qap_save(qap, tmp_path / "c.zkqap")
+    q2 = ctx.qap_load(tmp_path / "c.zkqap")
+    assert (q2.n, q2.m, q2.input, q2.dense) == (n, circ.m, circ.input, False)
+    assert ctx.prove(ctx.setup(q2, td), q2, weights, r, s) == good

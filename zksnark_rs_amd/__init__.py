@@ -260,6 +260,15 @@ class Context:
         q.n, q.m, q.input, q.dense, q.log_n = 1 << log_n, m, input, False, log_n
         return q
 
+    def qap_sparse_integers(self, n, m, input, u, v, w):
+        """Rows as in qap_sparse, over the roots 1..n that ASTParser emits (circuit/mod.rs:517); any n <= 2^21."""
+        d = self.sparse_desc(0, m, input, u, v, w)
+        p = C.c_void_p()
+        self._check(self.lib.zk_qap_upload_sparse_integers(self.ptr, C.byref(d), n, C.byref(p)))
+        q = Qap(self, p, self.lib.zk_qap_free)
+        q.n, q.m, q.input, q.dense, q.roots = n, m, input, False, "integers"
+        return q
+
     def qap_dense(self, u, v, w, t, input):
         """u, v, w: (m, n, 4) coefficient matrices, t: (n+1, 4)."""
         u, up = _u64(u); v, vp = _u64(v); w, wp = _u64(w); t, tp = _u64(t)

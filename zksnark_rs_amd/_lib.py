@@ -89,6 +89,7 @@ SIGNATURES = {
     "zk_g1_add_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
     "zk_g2_add_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
     "zk_qap_upload_sparse": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.POINTER(C.c_void_p)]),
+    "zk_qap_upload_sparse_integers": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_upload_dense": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_free": (None, [C.c_void_p]),
     "zk_qap_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "zk_circuit_weights": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]),
     "zk_circuit_last_error": (C.c_char_p, [C.c_void_p]),
     "zk_circuit_qap": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "zk_circuit_qap_sparse": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_crs_upload": (C.c_int, [C.c_void_p, C.POINTER(CrsDesc), C.POINTER(C.c_void_p)]),
     "zk_setup": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_void_p)]),
     "zk_crs_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

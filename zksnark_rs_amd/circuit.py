@@ -66,6 +66,14 @@ class Circuit:
         q.n, q.m, q.input, q.dense = self.n, self.m, self.input, True
         return q
 
+    def qap_sparse(self, ctx):
+        """The same QAP kept as rows over the integer roots 1..n (no interpolation, any size)."""
+        p = C.c_void_p()
+        ctx._check(self.lib.zk_circuit_qap_sparse(ctx.ptr, self.ptr, C.byref(p)))
+        q = Qap(ctx, p, self.lib.zk_qap_free)
+        q.n, q.m, q.input, q.dense, q.roots = self.n, self.m, self.input, False, "integers"
+        return q
+
 
 def qap_download_dense(ctx, qap):
     u = np.zeros((qap.m, qap.n, 4), np.uint64)

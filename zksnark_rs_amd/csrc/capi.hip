@@ -167,6 +167,11 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
     *out = nullptr;
     return guarded(ctx, [&] { *out = qap_upload_sparse(ctx, *desc); });
 }
+int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out) {
+    if (!ctx || !desc || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = qap_upload_sparse_integers(ctx, *desc, n); });
+}
 int zk_qap_upload_dense(zk_ctx* ctx, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t,
                         size_t m, size_t n, size_t input, zk_qap** out) {
     if (!ctx || !out) return ZK_ERR_ARG;
@@ -266,7 +271,7 @@ int zk_prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out)
 }
 int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]) {
     if (!qap || world < 1 || !elems_out) return ZK_ERR_ARG;
-    if (qap->dense) return ZK_ERR_UNSUPPORTED;
+    if (qap->dense || qap->roots) return ZK_ERR_UNSUPPORTED;
     prove_exchange_elems(*qap, world, elems_out);
     return ZK_OK;
 }

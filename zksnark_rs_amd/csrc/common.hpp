@@ -97,10 +97,10 @@ struct zk_ctx {
     long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges
     long opt_long_division = 0;   // dense form: always use the reference's long division (A/B check of the Newton form)
     long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
-    long opt_acc_stream = 1;      // all bucket accumulations on one low-priority stream, sorts / tails on mid-priority streams
+    long opt_acc_stream = 0;      // 1: every bucket accumulation on ONE low-priority stream, sorts / tails mid-priority (equal at 2^20, -25 % at 2^16: off)
     long opt_tail_streams = 0;    // reduction tails of the inner products on two streams of their own (measured: -27 %, kept as an experiment switch)
     long opt_alt_g2 = 0;          // the G2 inner product of odd-numbered proof slots runs on the spare MSM stream
-    long opt_fold = 16;           // images summed per lane and pass in the row / column sums of the MSM tail
+    long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_lane_entries = 32;   // additions per lane of the bucket accumulation (multiple of 4)
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;

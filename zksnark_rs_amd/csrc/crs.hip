@@ -106,8 +106,10 @@ void crs_ensure_brev(zk_ctx* ctx, zk_crs& c, unsigned log_n) {
     c.br_log_n = log_n;
 }
 
-void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
-    if (c.tables_kind == (brev ? 1 : 0) && c.tables_c == ctx->opt_window_bits) return;
+void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool lagrange) {
+    const int kind = lagrange ? 2 : (brev ? 1 : 0);
+    if (c.tables_kind == kind && c.tables_c == ctx->opt_window_bits) return;
+    ZK_REQUIRE(!lagrange || c.ap, ZK_ERR_UNSUPPORTED, "prove: an integer-roots QAP needs the CRS zk_setup made for it (Lagrange-basis points)");
     if (brev) crs_ensure_brev(ctx, c, log_n);
     // msm_window_bits: 0 = automatic, c = the same window for every table, 100*big + small = `big` for tables of
     // 2^21 points and more and `small` below, + 10000*g2 = its own window for the G2 table (tuning sweeps)
@@ -119,24 +121,28 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n) {
         return (int)(count >= ((size_t)1 << 21) - 8 ? o / 100 : o % 100);
     };
     const size_t n = c.n, nl = c.m - c.input - 1;
+    // integer-roots form: the inner products run over the Lagrange-basis points instead of the powers (natural order)
+    const G1A* b_xi1 = lagrange ? c.lag1.p : (brev ? c.xi1_br.p : c.xi1.p);
+    const G1A* b_xit = lagrange ? c.lagS_t1.p : (brev ? c.xi_t1_br.p : c.xi_t1.p);
+    const G2A* b_xi2 = lagrange ? c.lag2.p : (brev ? c.xi2_br.p : c.xi2.p);
     // xi_t has n-1 points; the bit-reversed copy is padded with infinity to n entries
-    msm_build_table<Fq>(ctx, brev ? c.xi1_br.p : c.xi1.p, n, pick(n), c.t_xi1);
+    msm_build_table<Fq>(ctx, b_xi1, n, pick(n), c.t_xi1);
     {   // bases of the merged product H + r*B1: xi_t | xi
         const size_t nt = brev ? n : n - 1;
         DevBuf<G1A> cat(nt + n);
-        if (nt) ZK_HIP(hipMemcpyAsync(cat.p, brev ? c.xi_t1_br.p : c.xi_t1.p, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
-        ZK_HIP(hipMemcpyAsync(cat.p + nt, brev ? c.xi1_br.p : c.xi1.p, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        if (nt) ZK_HIP(hipMemcpyAsync(cat.p, b_xit, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(cat.p + nt, b_xi1, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
         msm_build_table<Fq>(ctx, cat.p, nt + n, pick(nt + n), c.t_hb1);
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
     msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
-    msm_build_table<Fq2>(ctx, brev ? c.xi2_br.p : c.xi2.p, n, o_g2 > 0 ? (int)o_g2 : pick(n), c.t_xi2);
+    msm_build_table<Fq2>(ctx, b_xi2, n, o_g2 > 0 ? (int)o_g2 : pick(n), c.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables now hold the permuted points
         c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();
         c.has_br = false;
     }
-    c.tables_kind = brev ? 1 : 0;
+    c.tables_kind = kind;
     c.tables_c = ctx->opt_window_bits;
 }
 
@@ -203,7 +209,7 @@ __device__ __forceinline__ Fq fq_from_words(const uint32_t* w) {
 
 // one lane: trapdoor (canonical) -> Montgomery constants, inverses, t(x), encryption bases
 __global__ void k_setup_consts(const Fr* __restrict__ td, G2GenWords gen, int dense, size_t n, unsigned log_n,
-                               const Fr* __restrict__ t_coeffs, SetupConsts* __restrict__ out) {
+                               const Fr* __restrict__ t_coeffs, Fr tx_given, SetupConsts* __restrict__ out) {
     if (threadIdx.x || blockIdx.x) return;
     SetupConsts c;
     c.alpha = Fr::from_canonical(td[0]);
@@ -213,7 +219,10 @@ __global__ void k_setup_consts(const Fr* __restrict__ td, G2GenWords gen, int de
     c.x = Fr::from_canonical(td[4]);
     c.gamma_inv = c.gamma.inv();
     c.delta_inv = c.delta.inv();
-    if (dense) {
+    if (dense == 2) {          // integer roots: t(x) = prod (x - k) computed by the host (aproots.hip)
+        c.tx = tx_given;
+        c.lag_c = Fr::zero();
+    } else if (dense) {
         Fr acc = Fr::zero();  // Horner, Polynomial::evaluate (field/mod.rs:338-343)
         for (size_t k = n + 1; k-- > 0;) acc = acc * c.x + t_coeffs[k];
         c.tx = acc;
@@ -356,13 +365,26 @@ zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
         ZK_HIP(hipStreamSynchronize(st));
         ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_setup: trapdoor element >= r");
     }
-    hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, st, td.p, G2GEN, q.dense ? 1 : 0, n, q.log_n, q.dt.p, cs.p);
+    const bool ap = !q.dense && q.roots == 1;
+    hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, st, td.p, G2GEN, ap ? 2 : (q.dense ? 1 : 0), n, q.log_n, q.dt.p,
+                       ap ? ap_t_at_x(q, trapdoor) : Fr::zero(), cs.p);
     ZK_HIP(hipGetLastError());
+    DevBuf<Fr> apL(ap ? n : 0), apLS(ap ? std::max<size_t>(n - 1, 1) : 0);
 
     DevBuf<Fr> xi_s(n), xit_s(std::max<size_t>(n, 1)), comb(m);
     hipLaunchKernelGGL(k_setup_powers, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, xi_s.p, xit_s.p, n);
     if (q.dense) {
         hipLaunchKernelGGL(k_setup_comb_dense, dim3(ceil_div(m, 64)), dim3(64), 0, st, cs.p, q.du.p, q.dv.p, q.dw.p, m, n, l, comb.p);
+    } else if (ap) {
+        ap_setup_lagrange(ctx, q, trapdoor, apL.p, apLS.p, flag.p);
+        hipLaunchKernelGGL(k_setup_comb_sparse, dim3(ceil_div(m * 64, 256)), dim3(256), 0, st, cs.p, apL.p,
+                           q.u_wire.ptr.p, q.u_wire.idx.p, q.u_wire.val.p, q.v_wire.ptr.p, q.v_wire.idx.p, q.v_wire.val.p,
+                           q.w_wire.ptr.p, q.w_wire.idx.p, q.w_wire.val.p, m, l, comb.p);
+        ZK_HIP(hipGetLastError());
+        int h = 0;
+        ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_REQUIRE(!(h & 8), ZK_ERR_UNSUPPORTED, "zk_setup: the trapdoor's x is one of the integers 1..2n-1 (draw another)");
     } else {
         DevBuf<Fr> L(n);
         hipLaunchKernelGGL(k_lagrange_at, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, host_root_of_unity(q.log_n), L.p, n);
@@ -394,6 +416,13 @@ zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
     fixed_base_mul<Fq>(ctx, g1, comb.p, c->sum_gamma1.p, l + 1, "setup_fixed_base_g1");
     fixed_base_mul<Fq>(ctx, g1, comb.p + l + 1, c->sum_delta1.p, m - l - 1, "setup_fixed_base_g1");
     fixed_base_mul<Fq2>(ctx, g2, xi_s.p, c->xi2.p, n, "setup_fixed_base_g2");
+    if (ap) {   // the same CRS in the Lagrange bases of R and S (see aproots.hip)
+        c->ap = true;
+        c->lag1.alloc(n); c->lag2.alloc(n); c->lagS_t1.alloc(std::max<size_t>(n - 1, 1));
+        fixed_base_mul<Fq>(ctx, g1, apL.p, c->lag1.p, n, "setup_fixed_base_g1");
+        fixed_base_mul<Fq2>(ctx, g2, apL.p, c->lag2.p, n, "setup_fixed_base_g2");
+        fixed_base_mul<Fq>(ctx, g1, apLS.p, c->lagS_t1.p, n - 1, "setup_fixed_base_g1");
+    }
     // alpha, beta, gamma, delta sit first in SetupConsts (Montgomery)
     const Fr* tdm = &cs.p->alpha;
     fixed_base_mul<Fq>(ctx, g1, tdm + 0, c->alpha1.p, 1, "setup_fixed_base_g1");

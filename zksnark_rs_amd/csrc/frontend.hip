@@ -416,6 +416,34 @@ static zk_qap* circuit_to_qap(zk_ctx* ctx, const zk_circuit& c) {
     return q.release();
 }
 
+// The same QAP without the interpolation: the root representation's rows go to the device as they are and the prover works on
+// the integer roots 1..n in the evaluation basis (aproots.hip).  No 16384-gate limit; proofs are byte-identical to the dense form's.
+static zk_qap* circuit_to_qap_sparse(zk_ctx* ctx, const zk_circuit& c) {
+    const size_t n = c.n_gates, m = c.u.size();
+    ZK_REQUIRE(n >= 1, ZK_ERR_ARG, "circuit has no gates");
+    struct HostRows { std::vector<uint64_t> ptr, val; std::vector<uint32_t> gate; };
+    HostRows h[3];
+    const std::vector<zk_circuit::Row>* src[3] = {&c.u, &c.v, &c.w};
+    for (int k = 0; k < 3; ++k) {
+        h[k].ptr.assign(m + 1, 0);
+        for (size_t i = 0; i < m; ++i) {
+            for (const auto& e : (*src[k])[i]) {
+                h[k].gate.push_back(e.first);
+                const Fr v = e.second.to_canonical();
+                for (int j = 0; j < 4; ++j) h[k].val.push_back((uint64_t)v.l[2 * j] | ((uint64_t)v.l[2 * j + 1] << 32));
+            }
+            h[k].ptr[i + 1] = h[k].gate.size();
+        }
+        if (h[k].gate.empty()) { h[k].gate.push_back(0); h[k].val.assign(4, 0); }   // never a null array
+    }
+    zk_qap_sparse_desc d{};
+    d.m = m; d.input = c.input;
+    d.u = {h[0].ptr.data(), h[0].gate.data(), h[0].val.data()};
+    d.v = {h[1].ptr.data(), h[1].gate.data(), h[1].val.data()};
+    d.w = {h[2].ptr.data(), h[2].gate.data(), h[2].val.data()};
+    return qap_upload_sparse_integers(ctx, d, n);
+}
+
 static void qap_download_dense(zk_ctx* ctx, const zk_qap& q, uint64_t* u, uint64_t* v, uint64_t* w, uint64_t* t) {
     ZK_REQUIRE(q.dense, ZK_ERR_ARG, "zk_qap_download_dense: QAP is in sparse form");
     auto down = [&](const DevBuf<Fr>& src, uint64_t* dst, size_t count) {
@@ -495,6 +523,11 @@ int zk_circuit_qap(zk_ctx* ctx, const zk_circuit* c, zk_qap** out) {
     if (!ctx || !c || !out) return ZK_ERR_ARG;
     *out = nullptr;
     return guarded(ctx, [&] { *out = circuit_to_qap(ctx, *c); });
+}
+int zk_circuit_qap_sparse(zk_ctx* ctx, const zk_circuit* c, zk_qap** out) {
+    if (!ctx || !c || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = circuit_to_qap_sparse(ctx, *c); });
 }
 int zk_qap_download_dense(zk_ctx* ctx, const zk_qap* qap, uint64_t* u, uint64_t* v, uint64_t* w, uint64_t* t) {
     if (!ctx || !qap) return ZK_ERR_ARG;

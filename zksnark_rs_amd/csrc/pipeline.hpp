@@ -12,11 +12,21 @@ struct DevCsr {
     size_t rows = 0, nnz = 0;
 };
 
+// tables of the integer-roots form (aproots.hip): factorials up to 2n, barycentric weights of R = {1..n} and of S = {n+1..2n-1},
+// N(s) = t(s) on S, NTT image of the sequence 1/d (cyclic size 2^log_m >= 2n - 2); all Montgomery
+struct ApTables {
+    size_t n = 0;
+    unsigned log_m = 0;
+    DevBuf<Fr> fact, ifact, w, ws, ntab, bhat;
+};
+
 }  // namespace zk
 
 struct zk_qap {
     zk_ctx* ctx = nullptr;
     bool dense = false;
+    int roots = 0;            // sparse form: 0 = roots of unity w^j (n = 2^log_n), 1 = the integers 1..n (any n; aproots.hip)
+    std::shared_ptr<zk::ApTables> ap;
     size_t n = 0, m = 0, input = 0;
     unsigned log_n = 0;
     // sparse form (roots w^j): by gate (prove: evaluation vectors) and by wire (setup: u_i(x))
@@ -39,6 +49,11 @@ struct zk_crs {
     zk::DevBuf<zk::G1A> alpha1, beta1, delta1;          // 1 each
     zk::DevBuf<zk::G1A> xi1, sum_gamma1, sum_delta1, xi_t1;
     zk::DevBuf<zk::G2A> beta2, gamma2, delta2, xi2;
+    // integer-roots form (CRS made by zk_setup for such a QAP): the same CRS in the Lagrange basis of R = {1..n} and of
+    // S = {n+1..2n-1}: [L_k(x)]_1, [L_k(x)]_2, [L^S_s(x) t(x)/delta]_1 -- public linear combinations of xi1 / xi2 / xi_t1
+    bool ap = false;
+    zk::DevBuf<zk::G1A> lag1, lagS_t1;
+    zk::DevBuf<zk::G2A> lag2;
     // bit-reversed copies for the roots-of-unity pipeline (built on first use); xi_t1_br has n
     // entries, the last one (coefficient n-1, never used by the reference) is infinity
     zk::DevBuf<zk::G1A> xi1_br, xi_t1_br;
@@ -49,7 +64,7 @@ struct zk_crs {
     // (built on first use for the order -- natural or bit-reversed -- the QAP kind needs)
     zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;   // t_hb1: bases xi_t | xi (H and r*B1 in one product)
     zk::MsmTable<zk::Fq2> t_xi2;
-    int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed
+    int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed, 2 Lagrange-basis points (integer roots)
     // 4-bit fixed-base tables FT[w][d] = d * 16^w * P (64 x 16 entries) for the single CRS points
     // that prove() multiplies by r, s and r*s
     zk::DevBuf<zk::G1A> ft_alpha1, ft_beta1, ft_delta1;
@@ -61,6 +76,11 @@ struct zk_crs {
 namespace zk {
 
 zk_qap* qap_upload_sparse(zk_ctx*, const zk_qap_sparse_desc&);
+zk_qap* qap_upload_rows(zk_ctx*, const zk_qap_sparse_desc&, size_t n);                  // rows over n gates, domain not set
+zk_qap* qap_upload_sparse_integers(zk_ctx*, const zk_qap_sparse_desc&, size_t n);       // aproots.hip
+void ap_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, Fr* d_LS, int* d_flag);
+Fr ap_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
+void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can);
 zk_qap* qap_upload_dense(zk_ctx*, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input);
 void qap_free(zk_qap*);
 void qap_save(zk_ctx*, const zk_qap&, const char* path);      // serialize.hip
@@ -76,7 +96,7 @@ void crs_save(zk_ctx*, const zk_crs&, const char* path);     // serialize.hip
 zk_crs* crs_load(zk_ctx*, const char* path);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
-void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n);
+void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n, bool lagrange = false);
 void crs_ensure_fixed_tables(zk_ctx*, zk_crs&);
 
 void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);

@@ -334,7 +334,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     const zk_qap& q = qap_c;
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
     ZK_REQUIRE(d_partial_out || world == 1 || xout, ZK_ERR_ARG, "prove: world > 1 needs a partial output buffer");
-    ZK_REQUIRE(!xout || !qap_c.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!xout || (!qap_c.dense && !qap_c.roots), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     ZK_REQUIRE(!q.dense || !q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
@@ -344,7 +344,9 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
-    if (!q.dense) crs_ensure_tables(ctx, crs, true, q.log_n); else crs_ensure_tables(ctx, crs, false, 0);
+    if (q.dense) crs_ensure_tables(ctx, crs, false, 0);
+    else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
+    else crs_ensure_tables(ctx, crs, true, q.log_n);
     if (q.dense && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
         unsigned lc0 = 1;
         while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
@@ -398,7 +400,23 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
-    if (!q.dense) {
+    if (!q.dense && q.roots) {
+        // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
+        const size_t M = (size_t)1 << q.ap->log_m;
+        S.uv.ensure(2 * n); S.xy.ensure(3 * M);
+        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+        Fr *ve = S.uv.p, *ue = S.uv.p + n;
+        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
+        spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
+        fr_from_mont(ctx, ve, S.vc_can.p, n);
+        launch(0, 1, crs.t_xi2, S.vc_can.p, n, &ms->b2);                 // B = sum V_k [L_k(x)]_2
+        fr_from_mont(ctx, ue, S.uc_can.p, n);
+        launch(2, 0, crs.t_xi1, S.uc_can.p, n, &ms->a);                  // A = sum U_k [L_k(x)]_1
+        fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, S.hb_can.p + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
+        ap_quotient_values(ctx, q, ue, ve, S.xy.p, S.hb_can.p);          // h on S = {n+1 .. 2n-1}
+        launch(4, 2, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
+    } else if (!q.dense) {
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         S.uv.ensure(2 * n); S.uvg.ensure(2 * n); S.xy.ensure(2 * n);
@@ -505,7 +523,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!q.dense && !q.roots, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
@@ -571,7 +589,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
                        const uint64_t* r, const uint64_t* s) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: batches need the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!q.dense && !q.roots, ZK_ERR_UNSUPPORTED, "prove: batches need the roots-of-unity (sparse) QAP form");
     ZK_REQUIRE(count >= 1 && count <= ZK_MAX_BATCH, ZK_ERR_ARG, "prove: batch size out of range");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;

@@ -72,14 +72,12 @@ static void check_flag(zk_ctx* ctx, int* d_flag, const char* what) {
     (void)ctx;
 }
 
-zk_qap* qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc& desc) {
-    ZK_REQUIRE(desc.log_n <= NTT_MAX_LOG - 1, ZK_ERR_SIZE, "sparse QAP: log_n too large");
+zk_qap* qap_upload_rows(zk_ctx* ctx, const zk_qap_sparse_desc& desc, size_t n) {
     ZK_REQUIRE(desc.m >= 1 && desc.input < desc.m && desc.m < ((size_t)1 << 31), ZK_ERR_ARG, "sparse QAP: need input < m");
     std::unique_ptr<zk_qap> q(new zk_qap());
     q->ctx = ctx;
     q->dense = false;
-    q->log_n = desc.log_n;
-    q->n = (size_t)1 << desc.log_n;
+    q->n = n;
     q->m = desc.m;
     q->input = desc.input;
     DevBuf<int> flag(1);
@@ -89,6 +87,12 @@ zk_qap* qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc& desc) {
     upload_rows(ctx, desc.w, q->m, q->n, &q->w_wire, nullptr, flag.p);
     check_flag(ctx, flag.p, "zk_qap_upload_sparse");
     return q.release();
+}
+zk_qap* qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc& desc) {
+    ZK_REQUIRE(desc.log_n <= NTT_MAX_LOG - 1, ZK_ERR_SIZE, "sparse QAP: log_n too large");
+    zk_qap* q = qap_upload_rows(ctx, desc, (size_t)1 << desc.log_n);
+    q->log_n = desc.log_n;
+    return q;
 }
 
 __global__ void k_inv_single(const Fr* in, Fr* out) {

@@ -90,7 +90,8 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
 // The reference cannot store a QAP either (QAP<P> has private fields and no serialisation, groth16/mod.rs:60-67); the container
 // holds what zk_qap_upload_sparse / zk_qap_upload_dense take, as canonical little-endian integers:
 //   offset 0   "ZKQAPv1\0"
-//          8   kind (0 = sparse rows over the roots w^j, 1 = dense coefficient matrices), n_or_log_n, m, input      4 x u64
+//          8   kind (0 = sparse rows over the roots w^j, 1 = dense coefficient matrices, 2 = sparse rows over the
+//              integer roots 1..n), n_or_log_n (log_n for kind 0, n otherwise), m, input                           4 x u64
 //         40   nnz(u), nnz(v), nnz(w)  (0 for the dense kind)                                                    3 x u64
 //         64   FNV-1a 64 of the payload
 //         72   payload  sparse: for u, v, w: ptr[m+1] (u64) | gate[nnz] (u32, padded to 8 bytes) | val[nnz] (32 B)
@@ -120,7 +121,7 @@ void qap_save(zk_ctx* ctx, const zk_qap& q, const char* path) {
     std::vector<uint64_t> payload;
     uint64_t head[9] = {0};
     std::memcpy(head, QMAGIC, 8);
-    head[1] = q.dense ? 1 : 0; head[2] = q.dense ? q.n : q.log_n; head[3] = q.m; head[4] = q.input;
+    head[1] = q.dense ? 1 : (q.roots ? 2 : 0); head[2] = (q.dense || q.roots) ? q.n : q.log_n; head[3] = q.m; head[4] = q.input;
     if (!q.dense) {
         const DevCsr* rows[3] = {&q.u_wire, &q.v_wire, &q.w_wire};
         for (int k = 0; k < 3; ++k) {
@@ -159,10 +160,10 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
     uint64_t head[9];
     ZK_REQUIRE(std::fread(head, 8, 9, f.f) == 9 && !std::memcmp(head, QMAGIC, 8), ZK_ERR_IO, "qap_load: not a ZKQAPv1 file");
     const uint64_t kind = head[1], m = head[3], input = head[4];
-    ZK_REQUIRE(kind <= 1 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
+    ZK_REQUIRE(kind <= 2 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
     size_t words;
-    if (kind == 0) {
-        ZK_REQUIRE(head[2] <= 26 && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
+    if (kind != 1) {
+        ZK_REQUIRE(head[2] <= (kind == 0 ? 26 : ((uint64_t)1 << 21)) && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
         words = 0;
         for (int k = 0; k < 3; ++k) words += (m + 1) + (head[5 + k] + 1) / 2 + head[5 + k] * 4;
     } else {
@@ -189,7 +190,7 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
         rows[k]->gate = reinterpret_cast<const uint32_t*>(at); at += (nnz + 1) / 2;
         rows[k]->val = at; at += nnz * 4;
     }
-    return qap_upload_sparse(ctx, d);
+    return kind == 2 ? qap_upload_sparse_integers(ctx, d, head[2]) : qap_upload_sparse(ctx, d);
 }
 
 // A proof on disk: magic (the version lives in it), the 259 canonical bytes, FNV-1a 64 of them.  The in-memory encoding of the
