@@ -195,9 +195,14 @@ def main():
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency", action="store_true",
+                    help="one proof at a time (--depth 1), no per-kernel event timing (two extra API calls per launch, which small "
+                         "circuits feel), no CPU baseline: ms_per_step is the latency of a lone zk_prove_dev call")
     ap.add_argument("--cpu-baseline", choices=["default", "full"], default="default",
                     help="full: also the same-algorithm CPU path at 2^20 on ONE thread (minutes)")
     args = ap.parse_args()
+    if args.latency:
+        args.depth, args.no_cpu_baseline = 1, True
 
     import torch
     import zksnark_rs_amd as zk
@@ -406,7 +411,7 @@ def main():
                     pass
             for p in run(args.warmup):
                 proof = p
-    ctx.set_option("profile", 1)
+    ctx.set_option("profile", 0 if args.latency else 1)
     ctx.profile_reset()
     degraded_now = state["degraded"] is not None    # a failed communicator is not used again: barrier through the bootstrap store
 
@@ -454,6 +459,24 @@ def main():
     for p in proofs_out:
         assert proof is None or p == proof, "non-deterministic proof bytes"
         proof = p
+    # beside the resident-witness line: the same steps with every proof's witness handed over in page-locked HOST memory, as the
+    # reference's prove(&[T]) does (mod.rs:213-217) -- 96 MB over PCIe per proof at 2^20.  Secondary object, never `value`.
+    pcie = None
+    if world == 1 and host_w is None and args.batch <= 1 and not shard_mode and not args.latency:
+        host_w = ctx.host_alloc(inst["weights"].shape)
+        host_w[...] = inst["weights"]
+        k2 = max(min(args.steps, 40), 1)
+        run(min(args.warmup, 4) or 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out2 = run(k2)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        assert all(p == proof for p in out2), "proof from a host-memory witness differs"
+        pcie = {"value": round(k2 / e2, 4), "unit": "proofs/s", "witness_from": "pinned host memory (zk_prove_submit_host)", "steps": k2,
+                "host_to_device_MB_per_proof": round(inst["weights"].nbytes / 1e6, 1)}
+        ctx.host_free(host_w)
+        host_w = None
 
     proofs = args.steps * (world if (world > 1 and not shard) else 1)   # exchange / replicas: a step is `world` proofs
     value = proofs / elapsed
@@ -520,6 +543,7 @@ def main():
                        "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             **({"replicas": replicas} if replicas else {}),
+            **({"pcie_inclusive": pcie} if pcie else {}),
             **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},

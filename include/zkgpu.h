@@ -88,7 +88,8 @@ int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
 int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out_affine[ZK_G2_WORDS]);
 
 /* Element-wise field / group kernels (diagnostic entry points used by the parity tests).
- * op: 0 add, 1 sub, 2 mul, 3 inverse of a (b ignored; ZK_ERR_DIV_BY_ZERO if any a == 0)
+ * op: 0 add, 1 sub, 2 mul, 3 inverse of a (b ignored; ZK_ERR_DIV_BY_ZERO if any a == 0), 4 the same inverse by the
+ * binary extended Euclid that closes a proof (ff.cuh inv_vartime)
  * FrLocal Add/Sub/Mul/Div: fr.rs:18-71 */
 int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

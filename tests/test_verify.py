@@ -198,3 +198,13 @@ def test_reference_doc_example(ctx):
     proof = groth16.prove(qap, (sigmag1, sigmag2), w)
     assert groth16.verify((sigmag1, sigmag2), [2, 34], proof)
     assert not groth16.verify((sigmag1, sigmag2), [2, 25], proof)
+    # the CRS halves carry the reference's fields (mod.rs:105-121): simple.zk has 2 gates, 6 wires, 2 verifier inputs
+    assert sigmag1.xi.shape == (2, 8) and sigmag1.sum_gamma.shape == (3, 8) and sigmag1.sum_delta.shape == (3, 8) and sigmag1.xi_t.shape == (1, 8)
+    assert sigmag2.xi.shape == (2, 16) and sigmag2.gamma.shape == (16,)
+    # the same program kept as sparse rows over the roots 1..n: same CRS from the same trapdoor, same proof from the same (r, s)
+    td, rs = [11, 12, 13, 14, 15], (21, 22)
+    qs = groth16.QAP.from_zk(ctx, code, sparse=True)
+    s1, s2 = groth16.setup(qap, td)
+    t1, t2 = groth16.setup(qs, td)
+    assert np.array_equal(s1.xi_t, t1.xi_t) and np.array_equal(s2.xi, t2.xi) and np.array_equal(s1.sum_delta, t1.sum_delta)
+    assert groth16.prove(qs, (t1, t2), w, rs) == groth16.prove(qap, (s1, s2), w, rs)

@@ -135,6 +135,15 @@ ZK_NI Aff<F> jac_to_affine(const Jac<F>& p) {
     return Aff<F>{p.X * zi2, p.Y * zi2 * zi};
 }
 
+// the same with the data-dependent inversion (ff.cuh inv_vartime): for single-lane callers
+template <class F>
+ZK_NI Aff<F> jac_to_affine_vartime(const Jac<F>& p) {
+    if (p.is_inf()) return Aff<F>::infinity();
+    F zi = p.Z.inv_vartime();
+    F zi2 = zi.sqr();
+    return Aff<F>{p.X * zi2, p.Y * zi2 * zi};
+}
+
 // k * P for a canonical 256-bit scalar given as 8 little-endian words; MSB-first
 // double-and-add (the algorithm bn's Mul<Fr> uses [recollection]; the group element does not
 // depend on it).

@@ -290,6 +290,79 @@ struct alignas(16) Fp {
         e[0] -= 2;  // p is odd and P[0] >= 2 for both moduli
         return pow_words(e);
     }
+    // The same inverse by the binary extended Euclid for an odd modulus (Handbook of Applied Cryptography 14.61): about
+    // 1.4 x 254 rounds of shifts and subtractions on eight words, ~25 k instructions where Fermat's 255 squarings + 127
+    // multiplications take ~130 k.  The trip count depends on the value (no secret here: the inverted Z coordinates are
+    // public once the proof is), so this is for single-lane uses -- the three inversions that close a proof -- and not for
+    // whole waves, whose lanes would all wait for the slowest one.
+    ZK_HD Fp inv_vartime() const {
+        if (is_zero()) return zero();
+        uint32_t u[8], v[8], x1[8], x2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { u[i] = l[i]; v[i] = PR::P[i]; x1[i] = 0; x2[i] = 0; }
+        x1[0] = 1;
+        auto is_one = [](const uint32_t* a) {
+            uint32_t r = a[0] ^ 1u;
+#pragma unroll
+            for (int i = 1; i < 8; ++i) r |= a[i];
+            return r == 0;
+        };
+        auto halve = [](uint32_t* a, uint32_t* x) {   // a /= 2 (a even);  x /= 2 mod p  (x + p < 2^255 fits)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+            a[7] >>= 1;
+            if (x[0] & 1) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint64_t t = (uint64_t)x[i] + PR::P[i] + c;
+                    x[i] = (uint32_t)t;
+                    c = (uint32_t)(t >> 32);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+            x[7] >>= 1;
+        };
+        auto sub = [](uint32_t* a, const uint32_t* b) {   // a -= b, returns the borrow
+            uint32_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint64_t t = (uint64_t)a[i] - b[i] - br;
+                a[i] = (uint32_t)t;
+                br = (uint32_t)(t >> 63);
+            }
+            return br;
+        };
+        auto sub_mod = [&](uint32_t* a, const uint32_t* b) {   // a = a - b mod p
+            if (sub(a, b)) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint64_t t = (uint64_t)a[i] + PR::P[i] + c;
+                    a[i] = (uint32_t)t;
+                    c = (uint32_t)(t >> 32);
+                }
+            }
+        };
+        auto geq = [](const uint32_t* a, const uint32_t* b) {
+            for (int i = 7; i >= 0; --i)
+                if (a[i] != b[i]) return a[i] > b[i];
+            return true;
+        };
+        while (!is_one(u) && !is_one(v)) {
+            while (!(u[0] & 1)) halve(u, x1);
+            while (!(v[0] & 1)) halve(v, x2);
+            if (geq(u, v)) { sub(u, v); sub_mod(x1, x2); }
+            else { sub(v, u); sub_mod(x2, x1); }
+        }
+        // y = (a R)^-1 as an integer; a^-1 R = y R^2 = montmul(montmul(y, R^2), R^2)
+        Fp y;
+        const bool first = is_one(u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y.l[i] = first ? x1[i] : x2[i];
+        return y * r2() * r2();
+    }
 };
 
 typedef Fp<FrParams> Fr;
@@ -318,6 +391,10 @@ struct Fq2 {
     }
     ZK_HD Fq2 inv() const {
         Fq d = (c0.sqr() + c1.sqr()).inv();
+        return Fq2{c0 * d, -(c1 * d)};
+    }
+    ZK_HD Fq2 inv_vartime() const {
+        Fq d = (c0.sqr() + c1.sqr()).inv_vartime();
         return Fq2{c0 * d, -(c1 * d)};
     }
     ZK_HD static Fq2 from_canonical(const Fq2& x) { return Fq2{Fq::from_canonical(x.c0), Fq::from_canonical(x.c1)}; }

@@ -15,9 +15,9 @@ __global__ void k_field_batch(int op, const F* __restrict__ a, const F* __restri
     if (!x.raw_in_range()) { atomicOr(flag, 2); return; }
     x = F::from_canonical(x);
     F r;
-    if (op == 3) {
+    if (op == 3 || op == 4) {
         if (x.is_zero()) { atomicOr(flag, 1); return; }
-        r = x.inv();
+        r = op == 3 ? x.inv() : x.inv_vartime();
     } else {
         F y = b[i];
         if (!y.raw_in_range()) { atomicOr(flag, 2); return; }
@@ -29,12 +29,12 @@ __global__ void k_field_batch(int op, const F* __restrict__ a, const F* __restri
 
 template <class F>
 void field_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    ZK_REQUIRE(a && out && (op == 3 || b) && op >= 0 && op <= 3, ZK_ERR_ARG, "zk_f*_batch: bad argument");
+    ZK_REQUIRE(a && out && (op >= 3 || b) && op >= 0 && op <= 4, ZK_ERR_ARG, "zk_f*_batch: bad argument");
     if (n == 0) return;
-    DevBuf<F> da(n), db(op == 3 ? 0 : n), dout(n);
+    DevBuf<F> da(n), db(op >= 3 ? 0 : n), dout(n);
     DevBuf<int> flag(1);
     ZK_HIP(hipMemcpyAsync(da.p, a, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
-    if (op != 3) ZK_HIP(hipMemcpyAsync(db.p, b, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
+    if (op < 3) ZK_HIP(hipMemcpyAsync(db.p, b, n * sizeof(F), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_field_batch<F>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, op, da.p, db.p, dout.p, n, flag.p);
     ZK_HIP(hipGetLastError());

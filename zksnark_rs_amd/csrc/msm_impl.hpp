@@ -583,10 +583,17 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uin
 //
 // out[a B + b] = sum_{i < f} in[(a f + i) B + b], a < A, b < B: one lane per output image, f - 1 dependent additions.
 // Columns: the row index is folded (B = K); rows: the column index is folded (B = 1); group indices ride in `a`.
+// One launch serves one pass of BOTH chains (column sums and row sums are independent): workgroups [0, j0.blocks) run job 0,
+// the rest job 1 -- half the dependent launches of the tail, which is what a lone proof of a small circuit waits for.
+struct FoldJob { const void* in; void* out; uint32_t A, f, B, blocks; };
 template <class F>
-__global__ __launch_bounds__(TAIL_THREADS) void k_msm_fold(const AccSlot<F>* __restrict__ in, AccSlot<F>* __restrict__ out, uint32_t A, uint32_t f, uint32_t B) {
+__global__ __launch_bounds__(TAIL_THREADS) void k_msm_fold(FoldJob j0, FoldJob j1) {
     ZK_LATENCY_KERNEL();
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool second = blockIdx.x >= j0.blocks;
+    const AccSlot<F>* in = reinterpret_cast<const AccSlot<F>*>(second ? j1.in : j0.in);
+    AccSlot<F>* out = reinterpret_cast<AccSlot<F>*>(second ? j1.out : j0.out);
+    const uint32_t A = second ? j1.A : j0.A, f = second ? j1.f : j0.f, B = second ? j1.B : j0.B;
+    const uint32_t j = (second ? blockIdx.x - j0.blocks : blockIdx.x) * blockDim.x + threadIdx.x;
     if (j >= A * B) return;
     const uint32_t a = j / B, b = j - a * B;
     const AccSlot<F>* src = in + (size_t)a * f * B + b;
@@ -681,15 +688,17 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.sorted.ensure(entries);
     ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
     ws.bucket_sums.ensure((size_t)buckets * sizeof(AccSlot<F>));                           // S_b as accumulator images
-    ws.fold.ensure(((size_t)buckets + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // 2 x buckets / 2 ping-pong | C | R
+    const size_t half = ((size_t)buckets + 1) / 2, quarter = ((size_t)buckets + 3) / 4;
+    ws.fold.ensure((2 * (half + quarter) + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // per chain: passes 1, 3, .. | passes 2, 4, ..; then C | R
     ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * sizeof(Jac<F>));   // terms | partial sums
     ws.heavy.ensure((size_t)buckets + 1);
     AccSlot<F>* d_first = reinterpret_cast<AccSlot<F>*>(ws.partial.p);
     AccSlot<F>* d_last = d_first + lanes;
     AccSlot<F>* d_mid = d_last + lanes;
     AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
-    AccSlot<F>* d_tmp[2] = {reinterpret_cast<AccSlot<F>*>(ws.fold.p), reinterpret_cast<AccSlot<F>*>(ws.fold.p) + (buckets + 1) / 2};
-    AccSlot<F>* d_C = reinterpret_cast<AccSlot<F>*>(ws.fold.p) + 2 * ((buckets + 1) / 2);
+    AccSlot<F>* const fold_base = reinterpret_cast<AccSlot<F>*>(ws.fold.p);
+    AccSlot<F>* d_tmp[4] = {fold_base, fold_base + half, fold_base + half + quarter, fold_base + 2 * half + quarter};
+    AccSlot<F>* d_C = fold_base + 2 * (half + quarter);
     AccSlot<F>* d_R = d_C + (size_t)groups * K;
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
     const double pt_bytes = (double)sizeof(Aff<F>);
@@ -773,24 +782,26 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
         hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
         // column sums C[g][lo] (fold the row index, <= 16 images per lane and pass), then row sums R[g][hi] (fold the column index)
-        const uint32_t FOLD = (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64));   // images per lane and pass (msm_fold option)
-        auto fold_all = [&](uint32_t count, uint32_t B, uint32_t outer, AccSlot<F>* final_out) {
-            // `count` images per output along the folded index; outer = number of (group, kept-index-major) blocks
-            const AccSlot<F>* in = d_img;
-            int tog = 0;
-            for (;;) {
-                const uint32_t f = std::min(count, FOLD);
-                AccSlot<F>* out = count == f ? final_out : d_tmp[tog];
-                const uint32_t A = outer * (count / f);
-                hipLaunchKernelGGL(k_msm_fold<F>, dim3(ceil_div((size_t)A * B, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, in, out, A, f, B);
-                if (count == f) break;
-                count /= f;
-                in = out;
-                tog ^= 1;
+        uint32_t FOLD = 2;   // images per lane and pass (msm_fold option), a power of two: the folded counts are
+        while (FOLD * 2 <= (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64))) FOLD *= 2;
+        // passes of the two chains, zipped: chain 0 = columns (count = rows, B = K, outer = groups), chain 1 = rows
+        struct Chain { uint32_t count, B, outer; const AccSlot<F>* in; AccSlot<F>* fin; AccSlot<F>* tmp[2]; int tog; bool done; };
+        Chain ch[2] = {{(uint32_t)rows, (uint32_t)K, (uint32_t)groups, d_img, d_C, {d_tmp[0], d_tmp[1]}, 0, false},
+                       {(uint32_t)K, 1u, (uint32_t)groups * (uint32_t)rows, d_img, d_R, {d_tmp[2], d_tmp[3]}, 0, false}};
+        while (!ch[0].done || !ch[1].done) {
+            FoldJob job[2];
+            for (int q = 0; q < 2; ++q) {
+                Chain& h = ch[q];
+                if (h.done) { job[q] = FoldJob{nullptr, nullptr, 0, 1, 1, 0}; continue; }
+                const uint32_t f = std::min(h.count, FOLD);
+                AccSlot<F>* out = h.count == f ? h.fin : h.tmp[h.tog];
+                const uint32_t A = h.outer * (h.count / f);
+                job[q] = FoldJob{h.in, out, A, f, h.B, (uint32_t)ceil_div((size_t)A * h.B, TAIL_THREADS)};
+                if (h.count == f) h.done = true;
+                h.count /= f; h.in = out; h.tog ^= 1;
             }
-        };
-        fold_all((uint32_t)rows, (uint32_t)K, (uint32_t)groups, d_C);
-        fold_all((uint32_t)K, 1u, (uint32_t)groups * (uint32_t)rows, d_R);
+            hipLaunchKernelGGL(k_msm_fold<F>, dim3(job[0].blocks + job[1].blocks), dim3(TAIL_THREADS), 0, st, job[0], job[1]);
+        }
         hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(TAIL_THREADS), 0, st, d_C, d_R, kbits, rows, d_seg);
         // K + rows terms per group: one workgroup while each lane has at most 4 of them, otherwise two levels
         Jac<F>* d_part = d_seg + (size_t)groups * (K + rows);

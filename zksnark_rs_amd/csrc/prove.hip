@@ -16,6 +16,7 @@
 // (r, s) are injected: the reference draws them from thread_rng (mod.rs:231).
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <vector>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
@@ -101,7 +102,7 @@ __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
 __device__ void encode_g1(const G1J& p, uint8_t* out) {
     for (int i = 0; i < 65; ++i) out[i] = 0;
     if (p.is_inf()) return;
-    G1A a = jac_to_affine(p);
+    G1A a = jac_to_affine_vartime(p);   // one lane per wave is active here
     out[0] = 4;
     put_be32(a.x, out + 1);
     put_be32(a.y, out + 33);
@@ -109,7 +110,7 @@ __device__ void encode_g1(const G1J& p, uint8_t* out) {
 __device__ void encode_g2(const G2J& p, uint8_t* out) {
     for (int i = 0; i < 129; ++i) out[i] = 0;
     if (p.is_inf()) return;
-    G2A a = jac_to_affine(p);
+    G2A a = jac_to_affine_vartime(p);
     out[0] = 4;
     put_be32(a.x.c1, out + 1);
     put_be32(a.x.c0, out + 33);
@@ -199,7 +200,7 @@ struct ProveSlot {
     Fr* h_b_rs = nullptr;          // pinned
     int batch = 0;
     hipEvent_t fork_evt = nullptr, pre_evt = nullptr, done_evt = nullptr;
-    hipEvent_t msm_done[zk_ctx::MSM_STREAMS] = {}, acc_evt[zk_ctx::MSM_STREAMS] = {};
+    hipEvent_t msm_done[zk_ctx::MSM_STREAMS] = {}, acc_evt[zk_ctx::MSM_STREAMS] = {}, scal_evt[zk_ctx::MSM_STREAMS] = {};
     bool busy = false, partial = false;
     void init() {
         ms.alloc(1); as.alloc(1); d_proof.alloc(ZK_PROOF_BYTES); flag.alloc(1);
@@ -212,6 +213,7 @@ struct ProveSlot {
         for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
             ZK_HIP(hipEventCreateWithFlags(&msm_done[k], hipEventDisableTiming));
             ZK_HIP(hipEventCreateWithFlags(&acc_evt[k], hipEventDisableTiming));
+            ZK_HIP(hipEventCreateWithFlags(&scal_evt[k], hipEventDisableTiming));
         }
     }
     ~ProveSlot() {
@@ -223,6 +225,7 @@ struct ProveSlot {
         for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
             if (msm_done[k]) (void)hipEventDestroy(msm_done[k]);
             if (acc_evt[k]) (void)hipEventDestroy(acc_evt[k]);
+            if (scal_evt[k]) (void)hipEventDestroy(scal_evt[k]);
         }
     }
 };
@@ -381,11 +384,8 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // instead of thrashing each other; sorting phases and reduction tails overlap freely.
     MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
-        if (xout) return;
-        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);   // serialize: measurement mode, no overlap at all
-        ZK_HIP(hipEventRecord(S.fork_evt, st));
-        ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
+    auto launch_now = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out, hipStream_t ms_st) {
+        ZK_HIP(hipStreamWaitEvent(ms_st, S.scal_evt[k], 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         S.ws[k].tail_stream = tail_stream_for(ctx, k);
         S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
@@ -399,6 +399,21 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         }
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
+    };
+    // The ~30 launches of an inner product are enqueued AFTER the whole SpMV / NTT stage (an event marks the point of the main
+    // stream where its scalars exist): a lone proof of a small circuit is bound by the host's enqueue rate, and with the
+    // products enqueued in between the stage's own 25 short kernels sat 2 ms apart on the timeline of a 2^16 proof.
+    std::vector<std::function<void()>> deferred;
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
+        if (xout) return;
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);   // serialize: measurement mode, no overlap at all
+        ZK_HIP(hipEventRecord(S.scal_evt[k], st));
+        if (!ctx->opt_serialize && ctx->opt_defer_msm) {
+            auto* tab = &table;
+            deferred.push_back([&, k, after, tab, scalars, count, out, ms_st] { launch_now(k, after, *tab, scalars, count, out, ms_st); });
+            return;
+        }
+        launch_now(k, after, table, scalars, count, out, ms_st);
     };
     if (!q.dense && q.roots) {
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
@@ -483,6 +498,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }
 
+    for (auto& f : deferred) f();
     // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof.  A
     // scalars-only ticket completes on its own main stream: the finish stream may hold the join of an earlier ticket's
     // inner products, which would delay this one's completion by a whole round.

@@ -28,28 +28,43 @@ class QAP:
         self.ctx, self.handle, self.circuit = ctx, handle, circuit
 
     @classmethod
-    def from_zk(cls, ctx, code):
+    def from_zk(cls, ctx, code, sparse=False):
+        """sparse: keep the root representation's rows over the roots 1..n instead of interpolating them (any size)"""
         c = Circuit(code)
-        return cls(ctx, c.qap(ctx), c)
+        return cls(ctx, c.qap_sparse(ctx) if sparse else c.qap(ctx), c)
 
 
 class _Sigma:
-    def __init__(self, ctx, crs):
-        self.ctx, self.crs = ctx, crs
+    """One half of the CRS.  The points live on the device; the reference's fields (mod.rs:105-121) are fetched on first
+    access as affine coordinates in canonical little-endian 64-bit limbs: (8,) per G1 point, (16,) per G2 point."""
+    _fields = ()
+
+    def __init__(self, ctx, crs, shared):
+        self.ctx, self.crs, self._shared = ctx, crs, shared
+
+    def __getattr__(self, name):
+        if name in type(self)._fields:
+            if "arrays" not in self._shared:
+                self._shared["arrays"] = self.ctx.crs_download(self.crs)
+            return self._shared["arrays"][name + type(self)._suffix]
+        raise AttributeError(name)
 
 
 class SigmaG1(_Sigma):
-    pass
+    _fields = ("alpha", "beta", "delta", "xi", "sum_gamma", "sum_delta", "xi_t")
+    _suffix = "_g1"
 
 
 class SigmaG2(_Sigma):
-    pass
+    _fields = ("beta", "gamma", "delta", "xi")
+    _suffix = "_g2"
 
 
 def setup(qap, trapdoor=None):
     td = trapdoor if trapdoor is not None else [random_elem() for _ in range(5)]
     crs = qap.ctx.setup(qap.handle, ints_to_limbs(list(td)))
-    return SigmaG1(qap.ctx, crs), SigmaG2(qap.ctx, crs)
+    shared = {}
+    return SigmaG1(qap.ctx, crs, shared), SigmaG2(qap.ctx, crs, shared)
 
 
 def prove(qap, sigma, weights, rs=None):
