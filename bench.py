@@ -195,6 +195,7 @@ def main():
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="zk_ctx_set_option(KEY, VALUE) before the run (A/B switches)")
     ap.add_argument("--latency", action="store_true",
                     help="one proof at a time (--depth 1), no per-kernel event timing (two extra API calls per launch, which small "
                          "circuits feel), no CPU baseline: ms_per_step is the latency of a lone zk_prove_dev call")
@@ -259,6 +260,9 @@ def main():
     if args.serialize:
         ctx.set_option("serialize", 1)
     ctx.set_option("msm_shard_points", 1 if args.shard == "points" else 0)
+    for kv in args.opt:
+        key, val = kv.split("=", 1)
+        ctx.set_option(key, int(val))
     if args.lane_entries:
         ctx.set_option("msm_lane_entries", args.lane_entries)
     if args.fold:

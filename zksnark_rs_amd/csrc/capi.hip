@@ -104,6 +104,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_alt_g2")) return &ctx->opt_alt_g2;
     if (!std::strcmp(key, "msm_acc_stream")) return &ctx->opt_acc_stream;
     if (!std::strcmp(key, "defer_msm")) return &ctx->opt_defer_msm;
+    if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
     return nullptr;

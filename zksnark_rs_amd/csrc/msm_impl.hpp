@@ -674,8 +674,15 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // counters of all bins live in LDS: refuse up front instead of wrapping silently / failing after the first launches
     ZK_REQUIRE(entries < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
     ZK_REQUIRE((size_t)bins * 4 <= 65536, ZK_ERR_SIZE, "msm: too many groups for this window size (level-1 counters exceed 64 KiB of LDS)");
-    const uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
+    // ... as long as that leaves a lane for every SIMD slot worth filling: a product with few entries (small circuits, the
+    // tails of a sharded proof) is a latency chain of per_lane dependent additions on a fraction of the chip -- 32 additions
+    // over Fq2 are 0.6 ms whether 16 or 2^16 scalars are multiplied -- so its lanes take fewer entries each, down to 4
+    uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
+    const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
+    if (fill && entries / per_lane < fill) per_lane = (uint32_t)std::max<size_t>(4, std::min<size_t>(per_lane, entries / fill) & ~(size_t)3);
     const size_t lanes = (entries + per_lane - 1) / per_lane;
+    // such an accumulation does not fill the chip either, so it is not chained behind the previous one
+    if (fill && lanes < fill) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
     const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
     const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
