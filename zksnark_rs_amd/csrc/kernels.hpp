@@ -65,6 +65,7 @@ struct MsmWorkspace {
     DevBuf<uint8_t> partial, bucket_sums, fold, seg_sums;
     hipStream_t tail_stream = nullptr;   // where the reduction tail runs (null: on the product's own stream)
     hipStream_t acc_stream = nullptr;    // where the bucket accumulation runs (null: on the product's own stream)
+    hipStream_t sort_stream = nullptr;   // where the counting sort runs (null: on the product's own stream)
     hipEvent_t sorted_evt = nullptr;     // sort -> accumulation hand-over when acc_stream is set (owned; lives as long as the context)
 };
 int msm_auto_window(size_t n);

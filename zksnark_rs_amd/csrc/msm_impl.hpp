@@ -710,6 +710,12 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
     const double pt_bytes = (double)sizeof(Aff<F>);
 
+    // The counting sort may run on another stream than the product's own (ws.sort_stream, typically the caller's main stream,
+    // where the scalars were just produced): on the product's stream it queues behind the reduction tail of the PREVIOUS proof's
+    // product, and the G2 tail -- 4 ms under the following accumulations -- ended so late that the chip idled 0.6 ms per proof
+    // waiting for the next G2 sort.
+    hipStream_t const own_st = st;
+    if (ws.sort_stream) st = ws.sort_stream;
     {
         ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
         hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
@@ -739,6 +745,12 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
         hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                            sub_bits, ws.bin_cnt.p, ws.sorted.p);
+    }
+    if (ws.sort_stream) {
+        if (!ws.sorted_evt) ZK_HIP(hipEventCreateWithFlags(&ws.sorted_evt, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(ws.sorted_evt, st));
+        st = own_st;
+        ZK_HIP(hipStreamWaitEvent(st, ws.sorted_evt, 0));
     }
     {
         // algorithmic bytes as SURVEY.md 8(d) prices an inner product: one 32-byte scalar and one affine point per (scalar, point)

@@ -408,7 +408,11 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         if (xout) return;
         hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.scal_evt[k], st));
-        if (!ctx->opt_serialize && ctx->opt_defer_msm) {
+        // large circuits: the G2 product's sort goes onto the main stream, right behind the kernel that wrote its scalars (see
+        // msm_run); it is then enqueued in place, and so is L before it (the accumulation chain follows the call order)
+        const bool sort_on_main = !ctx->opt_serialize && ctx->opt_g2_sort_main && n >= ((size_t)1 << 18) && !d_partial_out;
+        S.ws[k].sort_stream = (sort_on_main && k == 0) ? st : nullptr;
+        if (!ctx->opt_serialize && ctx->opt_defer_msm && !(sort_on_main && (k == 0 || k == 1))) {
             auto* tab = &table;
             deferred.push_back([&, k, after, tab, scalars, count, out, ms_st] { launch_now(k, after, *tab, scalars, count, out, ms_st); });
             return;
@@ -570,6 +574,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         MsmGroups grp;
         grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
         S.ws[k].tail_stream = tail_stream_for(ctx, k);
+        S.ws[k].sort_stream = nullptr;
         S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
         hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
@@ -651,6 +656,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         MsmGroups grp;
         grp.groups = count; grp.glen = glen; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
         S.ws[k].tail_stream = tail_stream_for(ctx, k);
+        S.ws[k].sort_stream = nullptr;
         S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
         hipStream_t end_st = count == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k])
                                         : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
