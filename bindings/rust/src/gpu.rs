@@ -70,9 +70,19 @@ extern "C" {
     fn zk_prove_submit_host(ctx: *mut ZkCtx, crs: *const ZkCrs, qap: *const ZkQap, weights: *const u64, m: usize,
                             r: *const u64, s: *const u64, ticket: *mut c_int) -> c_int;
     fn zk_prove_wait(ctx: *mut ZkCtx, ticket: c_int, proof_out: *mut u8) -> c_int;
-    // one process driving several GPUs: zk_comm_* in zkgpu.h
+    // several GPUs, one process (or thread) per GPU: a communicator + the scalar-exchange pipeline
     fn zk_device_count() -> c_int;
+    fn zk_comm_unique_id(id_out: *mut u8) -> c_int;
+    fn zk_comm_init(ctx: *mut ZkCtx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut ZkComm) -> c_int;
+    fn zk_comm_destroy(c: *mut ZkComm);
+    fn zk_mgpu_create(ctx: *mut ZkCtx, comm: *mut ZkComm, crs: *const ZkCrs, qap: *const ZkQap, out: *mut *mut ZkMgpu) -> c_int;
+    fn zk_mgpu_push_host(p: *mut ZkMgpu, weights: *const u64, m: usize, r: *const u64, s: *const u64) -> c_int;
+    fn zk_mgpu_pop(p: *mut ZkMgpu, proof_out: *mut u8) -> c_int;
+    fn zk_mgpu_destroy(p: *mut ZkMgpu);
+    fn zk_mgpu_last_error(p: *const ZkMgpu) -> *const c_char;
 }
+#[repr(C)] pub struct ZkComm { _p: [u8; 0] }
+#[repr(C)] pub struct ZkMgpu { _p: [u8; 0] }
 
 fn check(ctx: *mut ZkCtx, rc: c_int) {
     // the reference panics on division by zero / zero divisor (fr.rs:54,69; field/mod.rs:440); so does the shim
@@ -488,6 +498,81 @@ impl GpuProver {
 }
 impl Drop for GpuProver {
     fn drop(&mut self) { unsafe { zk_crs_free(self.crs); zk_qap_free(self.qap); } }   // self.ctx drops afterwards (field order)
+}
+
+// ------------------------------------------------------------------------------------------------
+// prove() over all GPUs of a node.  One MultiGpuProver per GPU (a thread or a process each); rank 0 draws the 128-byte id
+// with MultiGpuProver::unique_id() and hands it to the others by any channel.  A ROUND is `world` proofs, one per rank:
+// every rank pushes its own witness, the library exchanges the scalars of the four inner products so that rank g multiplies
+// its own 1/world of the CRS points for every proof of the round (RCCL over xGMI, linked into libzkgpu.so), returns the
+// 768-byte partial sums to the proofs' owners and assembles.  Every rank must make the same sequence of calls.
+// ------------------------------------------------------------------------------------------------
+pub struct MultiGpuProver { inner: GpuProver, comm: *mut ZkComm, mgpu: *mut ZkMgpu, world: usize }
+
+impl MultiGpuProver {
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        assert_eq!(unsafe { zk_comm_unique_id(id.as_mut_ptr()) }, 0, "zk_comm_unique_id failed");
+        id
+    }
+    /// `prover`: this rank's device copy of (QAP, CRS) in the roots-of-unity form (GpuProver::from_root_rep, made on the device
+    /// `ZKGPU_DEVICE` selects); collective over the `world` ranks.
+    pub fn new(prover: GpuProver, id: &[u8; 128], rank: usize, world: usize) -> Self {
+        let (mut comm, mut mgpu) = (std::ptr::null_mut(), std::ptr::null_mut());
+        unsafe {
+            check(prover.ctx.0, zk_comm_init(prover.ctx.0, id.as_ptr(), rank as c_int, world as c_int, &mut comm));
+            check(prover.ctx.0, zk_mgpu_create(prover.ctx.0, comm, prover.crs, prover.qap, &mut mgpu));
+        }
+        MultiGpuProver { inner: prover, comm, mgpu, world }
+    }
+    fn check(&self, rc: c_int) {
+        if rc != 0 {
+            panic!("{}", unsafe { std::ffi::CStr::from_ptr(zk_mgpu_last_error(self.mgpu)) }.to_string_lossy());
+        }
+    }
+    /// This rank's share of a stream of rounds: job k is the proof this rank owns in round k.  Witnesses are staged in
+    /// page-locked memory, two rounds are pushed ahead of every pop (the schedule the throughput numbers are quoted on).
+    pub fn prove_stream<'a, I>(&self, jobs: I) -> Vec<Proof<G1Local, G2Local>>
+    where I: IntoIterator<Item = (&'a [FrLocal], FrLocal, FrLocal)> {
+        let mut out = Vec::new();
+        let mut staging: [*mut c_void; 4] = [std::ptr::null_mut(); 4];   // a round's witness is read before its pop; <= 3 in flight
+        let mut cap = [0usize; 4];
+        let mut in_flight = 0usize;
+        let pop = |out: &mut Vec<Proof<G1Local, G2Local>>| {
+            let mut bytes = [0u8; 259];
+            self.check(unsafe { zk_mgpu_pop(self.mgpu, bytes.as_mut_ptr()) });
+            out.push(proof_from_bytes(&bytes));
+        };
+        for (k, (weights, r, s)) in jobs.into_iter().enumerate() {
+            if in_flight == 3 { pop(&mut out); in_flight -= 1; }
+            let slot = k % 4;
+            let need = weights.len() * 32;
+            unsafe {
+                if cap[slot] < need {
+                    if !staging[slot].is_null() { zk_host_free(staging[slot]); }
+                    assert_eq!(zk_host_alloc(need, &mut staging[slot]), 0);
+                    cap[slot] = need;
+                }
+                let dst = std::slice::from_raw_parts_mut(staging[slot] as *mut u64, weights.len() * 4);
+                for (i, c) in weights.iter().enumerate() { dst[4 * i..4 * i + 4].copy_from_slice(&fr_to_words(c)); }
+                self.check(zk_mgpu_push_host(self.mgpu, staging[slot] as *const u64, weights.len(),
+                                             fr_to_words(&r).as_ptr(), fr_to_words(&s).as_ptr()));
+            }
+            in_flight += 1;
+        }
+        while in_flight > 0 { pop(&mut out); in_flight -= 1; }
+        unsafe { for p in staging.iter() { if !p.is_null() { zk_host_free(*p); } } }
+        out
+    }
+    /// One proof per rank and call: the reference's prove(), `world` of them at a time.
+    pub fn prove(&self, weights: &[FrLocal]) -> Proof<G1Local, G2Local> {
+        self.prove_stream(std::iter::once((weights, FrLocal::random_elem(), FrLocal::random_elem()))).pop().unwrap()
+    }
+    pub fn world(&self) -> usize { self.world }
+    pub fn single(&self) -> &GpuProver { &self.inner }
+}
+impl Drop for MultiGpuProver {
+    fn drop(&mut self) { unsafe { zk_mgpu_destroy(self.mgpu); zk_comm_destroy(self.comm); } }   // self.inner (ctx, crs, qap) drops afterwards
 }
 
 // ------------------------------------------------------------------------------------------------

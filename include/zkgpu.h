@@ -295,6 +295,10 @@ int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]);
 int zk_prove_scalars_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                             const uint64_t r[4], const uint64_t s[4], int world,
                             void* d_l, void* d_v, void* d_u, void* d_h, int* ticket);
+/* the same from a host witness (see zk_prove_submit_host) */
+int zk_prove_scalars_submit_host(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+                                 const uint64_t r[4], const uint64_t s[4], int world,
+                                 void* d_l, void* d_v, void* d_u, void* d_h, int* ticket);
 /* d_l .. d_h: `sets` chunks each, as delivered by the all-to-all (chunk j = proof j's scalars for this rank's points).
  * One ticket for the batch; finish with zk_prove_wait(ctx, ticket, NULL). */
 int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int sets, int rank, int world,
@@ -351,6 +355,9 @@ int zk_mgpu_prove_sharded(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const z
 typedef struct zk_mgpu zk_mgpu;
 int zk_mgpu_create(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out);
 int zk_mgpu_push(zk_mgpu* p, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]);
+/* The same with the witness in host memory, as the reference's prove(&[T]) hands it over (mod.rs:213-217): copied into a
+ * device buffer owned by the round on the stream the proof starts on (page-locked memory from zk_host_alloc: asynchronously). */
+int zk_mgpu_push_host(zk_mgpu* p, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4]);
 int zk_mgpu_pop(zk_mgpu* p, uint8_t proof_out[ZK_PROOF_BYTES]);
 void zk_mgpu_destroy(zk_mgpu* p);
 const char* zk_mgpu_last_error(const zk_mgpu* p);

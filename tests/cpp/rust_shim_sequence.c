@@ -4,7 +4,7 @@
  * this program makes the same calls in the same order with the same argument conventions -- upload_dense, setup (zk_setup +
  * zk_crs_download), GpuProver::new (zk_qap_upload_dense + zk_crs_upload), prove_with_rs (zk_prove), verify (zk_crs_upload +
  * zk_verify), prove_stream (zk_host_alloc + zk_prove_submit_host / zk_prove_wait, two in flight), from_root_rep
- * (zk_qap_upload_sparse + zk_setup) -- and restates the shim's byte conversions in C (module bn_bytes: 32-byte big-endian <->
+ * (zk_qap_upload_sparse + zk_setup), MultiGpuProver (zk_comm_init + zk_mgpu_create / zk_mgpu_push_host / zk_mgpu_pop) -- and restates the shim's byte conversions in C (module bn_bytes: 32-byte big-endian <->
  * four little-endian words; bn's Fq2 packing, the 512-bit integer c1 * q + c0, by the same shift-subtract long division),
  * checked against values the Python twin computes (argv) and by round trips through the proof bytes.
  *
@@ -238,8 +238,43 @@ int main(int argc, char** argv) {
         ZK(zk_verify(ctx, scrs, vin, 2, sp, &ok)); CHECK(ok == 1);
         fr_small(245, vin + 4);
         ZK(zk_verify(ctx, scrs, vin, 2, sp, &ok)); CHECK(ok == 0);
-        zk_crs_free(scrs); zk_qap_free(sq);
         printf("ok from_root_rep\n");
+        /* ---- MultiGpuProver::{new, prove_stream}: zk_comm_init + zk_mgpu_create, then zk_mgpu_push_host two rounds ahead of
+         *      zk_mgpu_pop.  One rank here (a round is `world` proofs, one per rank), so every proof must equal zk_prove's bytes:
+         *      the exchange layout, the grouped inner products over this rank's points and zk_prove_combine are all on the path. ---- */
+        {
+            uint8_t id[ZK_COMM_ID_BYTES];
+            zk_comm* comm = NULL; zk_mgpu* mg = NULL;
+            void* hw = NULL;
+            CHECK(zk_device_count() >= 1);
+            ZK(zk_comm_unique_id(id));
+            ZK(zk_comm_init(ctx, id, 0, 1, &comm));
+            CHECK(zk_comm_rank(comm) == 0 && zk_comm_world(comm) == 1);
+            ZK(zk_mgpu_create(ctx, comm, scrs, sq, &mg));
+            ZK(zk_host_alloc(sizeof wit, &hw));
+            memcpy(hw, wit, sizeof wit);
+            uint8_t got[5][ZK_PROOF_BYTES];
+            int pushed = 0, popped = 0;
+            while (popped < 5) {
+                while (pushed < 5 && pushed - popped < 3) {
+                    int rc = zk_mgpu_push_host(mg, (const uint64_t*)hw, sm, (pushed & 1) ? s : r, (pushed & 1) ? r : s);
+                    if (rc != 0) { fprintf(stderr, "zk_mgpu_push_host -> %d (%s)\n", rc, zk_mgpu_last_error(mg)); exit(1); }
+                    ++pushed;
+                }
+                int rc = zk_mgpu_pop(mg, got[popped]);
+                if (rc != 0) { fprintf(stderr, "zk_mgpu_pop -> %d (%s)\n", rc, zk_mgpu_last_error(mg)); exit(1); }
+                ++popped;
+            }
+            uint8_t sp2[ZK_PROOF_BYTES];
+            ZK(zk_prove(ctx, scrs, sq, wit, sm, s, r, sp2));
+            for (int k = 0; k < 5; ++k) CHECK(memcmp(got[k], (k & 1) ? sp2 : sp, ZK_PROOF_BYTES) == 0);
+            CHECK(zk_mgpu_pop(mg, got[0]) != 0);    /* nothing pushed */
+            double t = 1.5;
+            ZK(zk_comm_barrier(comm)); ZK(zk_comm_max_f64(comm, &t)); CHECK(t == 1.5);
+            zk_mgpu_destroy(mg); zk_comm_destroy(comm); zk_host_free(hw);
+            printf("ok multi_gpu_world_1\n");
+        }
+        zk_crs_free(scrs); zk_qap_free(sq);
     }
     zk_circuit_free(circ);
     zk_ctx_destroy(ctx);

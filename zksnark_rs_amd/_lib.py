@@ -125,6 +125,8 @@ SIGNATURES = {
     "zk_prove_exchange_elems": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "zk_prove_scalars_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "zk_prove_scalars_submit_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "zk_prove_msm_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "zk_prove_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, u64p, u64p, u8p]),
@@ -147,6 +149,7 @@ SIGNATURES = {
     "zk_mgpu_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_mgpu_create_custom": (C.c_int, [C.c_void_p, C.POINTER(MgpuBackend), C.POINTER(C.c_void_p)]),
     "zk_mgpu_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p]),
+    "zk_mgpu_push_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, u64p, u64p]),
     "zk_mgpu_pop": (C.c_int, [C.c_void_p, u8p]),
     "zk_mgpu_destroy": (None, [C.c_void_p]),
     "zk_mgpu_last_error": (C.c_char_p, [C.c_void_p]),

@@ -287,6 +287,15 @@ int zk_prove_scalars_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, c
         *ticket = prove_submit(ctx, *crs, *qap, (const Fr*)d_weights, m, r, s, 0, world, nullptr, xout);
     });
 }
+int zk_prove_scalars_submit_host(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, const uint64_t* weights, size_t m,
+                                 const uint64_t r[4], const uint64_t s[4], int world,
+                                 void* d_l, void* d_v, void* d_u, void* d_h, int* ticket) {
+    if (!ctx || !crs || !qap || !weights || !r || !s || world < 1 || !d_l || !d_v || !d_u || !d_h || !ticket) return ZK_ERR_ARG;
+    return guarded(ctx, [&] {
+        Fr* xout[4] = {(Fr*)d_l, (Fr*)d_v, (Fr*)d_u, (Fr*)d_h};
+        *ticket = prove_submit_host(ctx, *crs, *qap, weights, m, r, s, world, xout);
+    });
+}
 int zk_prove_msm_submit(zk_ctx* ctx, const zk_crs* crs, const zk_qap* qap, int sets, int rank, int world,
                         const void* d_l, const void* d_v, const void* d_u, const void* d_h, void* d_partials_out, int* ticket) {
     if (!ctx || !crs || !qap || sets < 0 || world < 1 || rank < 0 || rank >= world || !d_l || !d_v || !d_u || !d_h || !d_partials_out || !ticket)

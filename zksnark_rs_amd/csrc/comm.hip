@@ -94,6 +94,7 @@ struct GpuBackend {
     zk_ctx* ctx;
     const zk_crs* crs;
     const zk_qap* qap;
+    bool host_witness = false;   // the next scalars_submit gets a host pointer (zk_mgpu_push_host)
 };
 static int gpu_elems(void* u, int world, size_t out[4]) { return zk_prove_exchange_elems(((GpuBackend*)u)->qap, world, out); }
 static void* gpu_alloc(void* u, size_t bytes) {
@@ -106,6 +107,7 @@ static void* gpu_alloc(void* u, size_t bytes) {
 static void gpu_free(void*, void* p) { (void)hipFree(p); }
 static int gpu_scalars(void* u, const void* w, size_t m, const uint64_t r[4], const uint64_t s[4], int world, void* const send[4], int* t) {
     GpuBackend* g = (GpuBackend*)u;
+    if (g->host_witness) return zk_prove_scalars_submit_host(g->ctx, g->crs, g->qap, (const uint64_t*)w, m, r, s, world, send[0], send[1], send[2], send[3], t);
     return zk_prove_scalars_submit(g->ctx, g->crs, g->qap, w, m, r, s, world, send[0], send[1], send[2], send[3], t);
 }
 static int gpu_msm(void* u, int sets, int rank, int world, void* const recv[4], void* part, int* t) {
@@ -330,7 +332,7 @@ void zk_mgpu_destroy(zk_mgpu* g) {
 }
 const char* zk_mgpu_last_error(const zk_mgpu* g) { return g ? g->last_error.c_str() : "null prover"; }
 
-int zk_mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]) {
+static int mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4], bool host) {
     if (!g || !d_weights || !r || !s) return ZK_ERR_ARG;
     return comm_guard(g->comm, &g->last_error, [&] {
         ZK_REQUIRE(g->rounds.size() < 3, ZK_ERR_ARG, "zk_mgpu_push: three rounds in flight (call zk_mgpu_pop first)");
@@ -339,10 +341,20 @@ int zk_mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4
         if (g->rounds.size() >= 2) inner_products(g, k - 2);
         zk_mgpu::Round R;
         std::memcpy(R.r, r, 32); std::memcpy(R.s, s, 32);
+        if (g->gpu) g->gpu->host_witness = host;
         be_check(g, g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars), "scalars_submit");
         g->rounds.push_back(R);
         if (g->rounds.size() >= 2) inner_products(g, k - 1);   // A(k), then B(k - 1): the scalars run ahead of the inner products
     });
+}
+
+int zk_mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]) {
+    return mgpu_push(g, d_weights, m, r, s, false);
+}
+// the witness in HOST memory (page-locked from zk_host_alloc: the copy overlaps the previous rounds' inner products); a custom
+// backend receives the pointer as it is
+int zk_mgpu_push_host(zk_mgpu* g, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4]) {
+    return mgpu_push(g, weights, m, r, s, true);
 }
 
 int zk_mgpu_pop(zk_mgpu* g, uint8_t proof_out[ZK_PROOF_BYTES]) {

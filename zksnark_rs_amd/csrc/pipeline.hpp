@@ -111,7 +111,8 @@ int prove_submit(zk_ctx*, const zk_crs&, const zk_qap&, const Fr* d_weights, siz
 void prove_exchange_elems(const zk_qap&, int world, size_t out[4]);
 int prove_msm_submit(zk_ctx*, const zk_crs&, const zk_qap&, int sets, int rank, int world,
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out);
-int prove_submit_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s);
+int prove_submit_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s,
+                      int world = 1, Fr* const* xout = nullptr);
 void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
 int prove_batch_submit(zk_ctx*, const zk_crs&, const zk_qap&, int count, const void* const* d_weights, const size_t* m,
                        const uint64_t* r, const uint64_t* s);

@@ -762,7 +762,8 @@ void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_we
 // kernels run on, so with page-locked memory (zk_host_alloc) the transfer of proof k+1 overlaps the inner products of
 // proof k and the PCIe-inclusive rate of a stream of proofs is the resident rate.  Pageable memory works too (the
 // runtime stages it; the call then blocks for the duration of the copy).
-int prove_submit_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s) {
+int prove_submit_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s,
+                      int world, Fr* const* xout) {
     ProveState& ps = prove_state(ctx);
     ProveSlot& S = ps.slot[ps.next];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
@@ -770,7 +771,7 @@ int prove_submit_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const u
     S.d_wit.ensure(std::max<size_t>(mm, 1));
     hipStream_t st = (ps.next & 1) ? ctx->main_alt : ctx->stream;
     if (mm) ZK_HIP(hipMemcpyAsync(S.d_wit.p, weights, mm * sizeof(Fr), hipMemcpyHostToDevice, st));
-    return prove_submit(ctx, crs, qap, S.d_wit.p, mm, r, s, 0, 1, nullptr);
+    return prove_submit(ctx, crs, qap, S.d_wit.p, mm, r, s, 0, world, nullptr, xout);   // xout: scalars only (multi-GPU exchange)
 }
 
 void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
