@@ -88,3 +88,46 @@ def test_rust_shim_sequence_on_the_gpu(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     for name in ("byte_conversions", "setup", "prove", "verify", "prove_stream", "from_root_rep", "multi_gpu_world_1"):
         assert "ok " + name in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_one_rank_communicator_through_rccl(tmp_path):
+    """ZK_COMM_FORCE_RCCL=1: a one-rank zk_comm is a real RCCL communicator (ncclCommInitRank with one rank, grouped self
+    send / recv, all-gather, all-reduce) -- the only way to execute the RCCL calls of csrc/comm.hip on a one-GPU box.  The C
+    program's multi-GPU section must still give zk_prove's bytes; then the same from a process that has torch (and its own
+    bundled librccl) loaded, as bench.py does."""
+    exe = build_shim(tmp_path)
+    env = dict(os.environ, ZK_COMM_FORCE_RCCL="1")
+    res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zk", "simple.zk")] + g2_generator_packed(), capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert res.returncode == 0 and "ok multi_gpu_world_1" in res.stdout, res.stdout + res.stderr
+    code = r"""
+import numpy as np, torch
+import zksnark_rs_amd as zk
+from zksnark_rs_amd.distributed import Comm, MgpuProver
+from zksnark_rs_amd.circuits import chain_rows, chain_weights
+ctx = zk.Context(0)
+comm = Comm(ctx, 0, 1, Comm.unique_id())
+a = torch.arange(4096, dtype=torch.int32, device="cuda"); b = torch.zeros_like(a)
+torch.cuda.synchronize()
+comm.all_to_all(a.data_ptr(), b.data_ptr(), a.numel() * 4); assert torch.equal(a, b)
+b.zero_(); torch.cuda.synchronize()
+comm.all_gather(a.data_ptr(), b.data_ptr(), a.numel() * 4); assert torch.equal(a, b)
+comm.barrier(); assert comm.max_f64(2.5) == 2.5
+log_n = 10
+m, l, u, v, w = chain_rows(log_n)
+rng = zk.SplitMix64(5)
+wts = chain_weights(log_n, rng.fr(), [rng.fr() for _ in range(1 << log_n)])
+qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+crs = ctx.setup(qap, zk.ints_to_limbs([rng.fr() for _ in range(5)]))
+r, s = rng.fr(), rng.fr()
+want = ctx.prove(crs, qap, wts, r, s)
+dw = torch.from_numpy(np.ascontiguousarray(wts).view(np.int64)).cuda(); torch.cuda.synchronize()
+mp = MgpuProver(ctx, comm, crs, qap)
+got = list(mp.prove_stream([(dw.data_ptr(), m, r, s)] * 4, ahead=2))
+assert got == [want] * 4
+mp.close(); comm.close()
+print("ok rccl world 1")
+"""
+    res = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0 and "ok rccl world 1" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -14,6 +14,7 @@
 // (zk_prove_scalars_submit / zk_prove_msm_submit / zk_prove_wait / zk_prove_combine); tests may substitute CPU stand-ins
 // so that the pipeline logic and the collectives' order run under world-size-2 gloo without a GPU.
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -59,13 +60,12 @@ namespace zk {
 
 // ---- transport ----------------------------------------------------------------------------------
 static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
-    if (c->world == 1) {
-        if (c->custom) { ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed"); return; }
-        ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
-        return;
-    }
     if (c->custom) {
         ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
+        return;
+    }
+    if (!c->nccl) {   // one rank, no communicator
+        ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
         return;
     }
     // chunk g of d_send goes to rank g; chunk j of d_recv comes from rank j.  xGMI is point to point (7 links per GPU): the
@@ -82,7 +82,7 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
         return;
     }
-    if (c->world == 1) { ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream)); return; }
+    if (!c->nccl) { ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream)); return; }
     ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->nccl, c->stream));
 }
 static void comm_sync(zk_comm* c) {
@@ -189,7 +189,11 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
     int rc = comm_guard(c, nullptr, [&] {
         ZK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         ZK_HIP(hipMalloc((void**)&c->d_flag, 64));
-        if (world > 1) {
+        // ZK_COMM_FORCE_RCCL=1: a one-rank communicator too goes through RCCL (self send / recv, all-gather, all-reduce) -- the
+        // only way to execute this file's RCCL calls on a one-GPU box (tests/test_gpu_bench.py)
+        const char* force = std::getenv("ZK_COMM_FORCE_RCCL");
+        if (world > 1 || (force && force[0] == '1' && id)) {
+            ZK_HIP(hipSetDevice(ctx->device));
             ncclUniqueId nid;
             std::memcpy(nid.internal, id, ZK_COMM_ID_BYTES);
             ZK_NCCL(ncclCommInitRank(&c->nccl, world, nid, rank));
@@ -225,11 +229,7 @@ int zk_comm_barrier(zk_comm* c) {
     if (!c) return ZK_ERR_ARG;
     if (c->custom) return c->ops.barrier ? c->ops.barrier(c->ops.user) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
-        if (c->world > 1) {
-            int one = 1;
-            ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, c->nccl, c->stream));
-            (void)one;
-        }
+        if (c->nccl) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, c->nccl, c->stream));
         ZK_HIP(hipStreamSynchronize(c->stream));
     });
 }
@@ -238,7 +238,7 @@ int zk_comm_max_f64(zk_comm* c, double* value) {
     if (!c || !value) return ZK_ERR_ARG;
     if (c->custom) return c->ops.max_f64 ? c->ops.max_f64(c->ops.user, value) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
-        if (c->world == 1) return;
+        if (!c->nccl) return;
         double* d = reinterpret_cast<double*>(c->d_flag) + 2;
         ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
         ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, c->nccl, c->stream));
