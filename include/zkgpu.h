@@ -142,7 +142,8 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
  * interpolated: the prover keeps U, V as values on {1..n}, the quotient as values on {n+1..2n-1}, and takes its inner
  * products with the CRS in those Lagrange bases, which zk_setup emits next to the reference's [x^i] arrays.  Costs
  * O(nnz + n log n) per proof where the dense form is O(m n); SURVEY.md 8-f4.  A CRS for such a QAP must come from
- * zk_setup on this library (zk_crs_upload / zk_crs_load carry only the reference's arrays: ZK_ERR_UNSUPPORTED at prove);
+ * zk_setup on this library or from a file zk_crs_save wrote for it (zk_crs_upload carries only the reference's arrays:
+ * ZK_ERR_UNSUPPORTED at prove);
  * batches and the multi-GPU scalar exchange need the roots-of-unity form. */
 int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out);
 
@@ -212,7 +213,9 @@ void zk_crs_free(zk_crs* crs);
 /* On-disk CRS container.  The reference has no serialisation of SigmaG1/SigmaG2
  * (groth16/mod.rs:105-121), and setup (mod.rs:134-197) draws a fresh trapdoor on every call, so a CRS must be
  * written down to be reused.  Format: "ZKCRSv1\0", n, m, input, FNV-1a-64 of the payload, then the arrays of
- * zk_crs_desc in declaration order as canonical little-endian words.  zk_crs_load range-checks every coordinate
+ * zk_crs_desc in declaration order as canonical little-endian words.  A CRS that zk_setup made for an integer-roots QAP
+ * (zk_qap_upload_sparse_integers) is written as "ZKCRSv2\0": the same, followed by its Lagrange-basis arrays, so that the
+ * reloaded CRS serves that QAP form again.  zk_crs_load reads both, range- and curve-checks every point
  * and returns ZK_ERR_IO for a missing, truncated or altered file. */
 int zk_crs_save(zk_ctx* ctx, const zk_crs* crs, const char* path);
 int zk_crs_load(zk_ctx* ctx, const char* path, zk_crs** out);

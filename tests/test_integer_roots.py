@@ -250,6 +250,19 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         ctx.qap_sparse_integers((1 << 21) + 1, 2, 0, one, one, one)
     assert e.value.status == -4
+    # CRS file: the Lagrange-basis arrays travel with it (ZKCRSv2), so a reloaded CRS serves this form again
+    ctx.crs_save(crs, tmp_path / "c.zkcrs")
+    raw = (tmp_path / "c.zkcrs").read_bytes()
+    assert raw[:8] == b"ZKCRSv2\0" and len(raw) == 40 + 64 * (3 + n + 3 + (circ.m - 3) + (n - 1)) + 128 * (3 + n) + 64 * (2 * n - 1) + 128 * n
+    crs3 = ctx.crs_load(tmp_path / "c.zkcrs")
+    assert ctx.prove(crs3, qap, weights, r, s) == good
+    assert ctx.prove(crs3, circ.qap(ctx), weights, r, s) == good
+    (tmp_path / "bad.zkcrs").write_bytes(raw[:-9] + bytes([raw[-9] ^ 1]) + raw[-8:])
+    with pytest.raises(zk.ZkError) as e:
+        ctx.crs_load(tmp_path / "bad.zkcrs")
+    assert e.value.status == -8
+    ctx.crs_save(crs2, tmp_path / "plain.zkcrs")               # a CRS without them keeps the v1 container
+    assert (tmp_path / "plain.zkcrs").read_bytes()[:8] == b"ZKCRSv1\0"
     # container: kind 2 round trip
     ctx.qap_save(qap, tmp_path / "c.zkqap")
     q2 = ctx.qap_load(tmp_path / "c.zkqap")

@@ -74,6 +74,29 @@ void crs_download(zk_ctx* ctx, const zk_crs& c, const zk_crs_out& o) {
     down_points(ctx, c.xi2, o.xi_g2, c.n);
 }
 
+// The Lagrange-basis arrays of an integer-roots CRS (aproots.hip) -- for the file container: host words <-> device.  They are
+// range- and curve-checked like every uploaded point; that they are the same CRS in another basis is the file's business (it is
+// the prover's own file, checksummed; a wrong array yields proofs that zk_verify rejects).
+void crs_download_lagrange(zk_ctx* ctx, const zk_crs& c, uint64_t* lag1, uint64_t* lagS_t1, uint64_t* lag2) {
+    ZK_REQUIRE(c.ap, ZK_ERR_ARG, "CRS holds no Lagrange-basis arrays");
+    down_points(ctx, c.lag1, lag1, c.n);
+    down_points(ctx, c.lagS_t1, lagS_t1, c.n - 1);
+    down_points(ctx, c.lag2, lag2, c.n);
+}
+void crs_attach_lagrange(zk_ctx* ctx, zk_crs& c, const uint64_t* lag1, const uint64_t* lagS_t1, const uint64_t* lag2) {
+    DevBuf<int> flag(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+    up_points(ctx, c.lag1, lag1, c.n, flag.p);
+    up_points(ctx, c.lagS_t1, lagS_t1, c.n - 1, flag.p);
+    up_points(ctx, c.lag2, lag2, c.n, flag.p);
+    int h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_REQUIRE(!(h & 2), ZK_ERR_RANGE, "zk_crs_load: coordinate >= q");
+    ZK_REQUIRE(!(h & 4), ZK_ERR_RANGE, "zk_crs_load: point not on the curve");
+    c.ap = true;
+}
+
 void crs_free(zk_crs* c) {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);

@@ -97,6 +97,8 @@ zk_crs* crs_load(zk_ctx*, const char* path);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
 void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n, bool lagrange = false);
+void crs_download_lagrange(zk_ctx*, const zk_crs&, uint64_t* lag1, uint64_t* lagS_t1, uint64_t* lag2);
+void crs_attach_lagrange(zk_ctx*, zk_crs&, const uint64_t* lag1, const uint64_t* lagS_t1, const uint64_t* lag2);
 void crs_ensure_fixed_tables(zk_ctx*, zk_crs&);
 
 void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);

@@ -12,6 +12,11 @@
 //         40   payload: alpha1 beta1 delta1 (64 B each) | xi1 (n x 64) | sum_gamma1 ((input+1) x 64) |
 //              sum_delta1 ((m-input-1) x 64) | xi_t1 ((n-1) x 64) | beta2 gamma2 delta2 (128 B each) | xi2 (n x 128)
 //
+// A CRS that zk_setup made for an integer-roots QAP (aproots.hip) also carries the same CRS in the Lagrange bases; its file is
+// "ZKCRSv2\0" with the same header and, behind the v1 payload,
+//              lag1 (n x 64) | lagS_t1 ((n-1) x 64) | lag2 (n x 128)
+// so that a reloaded CRS proves for that QAP form again.  zk_crs_load reads both versions.
+//
 // Loading range-checks every coordinate on the GPU (zk_crs_upload) and rejects truncated or altered files.
 #include <cstdio>
 #include <cstring>
@@ -23,6 +28,7 @@ namespace zk {
 
 namespace {
 constexpr char MAGIC[8] = {'Z', 'K', 'C', 'R', 'S', 'v', '1', '\0'};
+constexpr char MAGIC2[8] = {'Z', 'K', 'C', 'R', 'S', 'v', '2', '\0'};
 
 struct Layout {
     size_t n, m, input;
@@ -51,13 +57,15 @@ struct File {
 void crs_save(zk_ctx* ctx, const zk_crs& crs, const char* path) {
     ZK_REQUIRE(crs.m >= crs.input + 1 && crs.n >= 1, ZK_ERR_ARG, "crs_save: inconsistent CRS dimensions");
     Layout lay(crs.n, crs.m, crs.input);
-    std::vector<uint64_t> buf(lay.words());
+    const size_t n = crs.n, extra = crs.ap ? 8 * n + 8 * (n - 1) + 16 * n : 0;
+    std::vector<uint64_t> buf(lay.words() + extra);
     uint64_t* b = buf.data();
+    if (crs.ap) crs_download_lagrange(ctx, crs, b + lay.words(), b + lay.words() + 8 * n, b + lay.words() + 8 * n + 8 * (n - 1));
     zk_crs_out out{b + lay.off[0], b + lay.off[1], b + lay.off[2], b + lay.off[3], b + lay.off[4], b + lay.off[5], b + lay.off[6],
                    b + lay.off[7], b + lay.off[8], b + lay.off[9], b + lay.off[10]};
     crs_download(ctx, crs, out);
     uint64_t head[5];
-    std::memcpy(head, MAGIC, 8);
+    std::memcpy(head, crs.ap ? MAGIC2 : MAGIC, 8);
     head[1] = crs.n; head[2] = crs.m; head[3] = crs.input;
     head[4] = fnv1a(reinterpret_cast<const uint8_t*>(b), buf.size() * 8);
     File f(std::fopen(path, "wb"));
@@ -71,11 +79,12 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
     File f(std::fopen(path, "rb"));
     ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("crs_load: cannot open ") + path);
     uint64_t head[5];
-    ZK_REQUIRE(std::fread(head, 8, 5, f.f) == 5 && !std::memcmp(head, MAGIC, 8), ZK_ERR_IO, "crs_load: not a ZKCRSv1 file");
+    ZK_REQUIRE(std::fread(head, 8, 5, f.f) == 5 && (!std::memcmp(head, MAGIC, 8) || !std::memcmp(head, MAGIC2, 8)), ZK_ERR_IO, "crs_load: not a ZKCRSv1 / ZKCRSv2 file");
+    const bool v2 = !std::memcmp(head, MAGIC2, 8);
     const size_t n = head[1], m = head[2], input = head[3];
     ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << 26) && m >= input + 1 && m <= ((size_t)1 << 28), ZK_ERR_IO, "crs_load: implausible dimensions in the header");
     Layout lay(n, m, input);
-    std::vector<uint64_t> buf(lay.words());
+    std::vector<uint64_t> buf(lay.words() + (v2 ? 8 * n + 8 * (n - 1) + 16 * n : 0));
     ZK_REQUIRE(std::fread(buf.data(), 8, buf.size(), f.f) == buf.size(), ZK_ERR_IO, "crs_load: file is truncated");
     uint8_t extra;
     ZK_REQUIRE(std::fread(&extra, 1, 1, f.f) == 0, ZK_ERR_IO, "crs_load: trailing bytes after the payload");
@@ -83,7 +92,9 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
     const uint64_t* b = buf.data();
     zk_crs_desc d{n, m, input, b + lay.off[0], b + lay.off[1], b + lay.off[2], b + lay.off[3], b + lay.off[4], b + lay.off[5], b + lay.off[6],
                   b + lay.off[7], b + lay.off[8], b + lay.off[9], b + lay.off[10]};
-    return crs_upload(ctx, d);
+    std::unique_ptr<zk_crs, void (*)(zk_crs*)> c(crs_upload(ctx, d), crs_free);
+    if (v2) crs_attach_lagrange(ctx, *c, b + lay.words(), b + lay.words() + 8 * n, b + lay.words() + 8 * n + 8 * (n - 1));
+    return c.release();
 }
 
 // ---- QAP container ("ZKQAPv1") and proof file ("ZKPRFv1") ------------------------------------------------------------
