@@ -134,6 +134,32 @@ def gloo_comm(ctx, dist, rank, world):
     return Comm(ctx, rank, world, ops=ops)
 
 
+def loopback_comm(ctx, world):
+    """TIMING ONLY: rank 0 of a `world`-rank communicator whose collectives are device-to-device copies of the right size on
+    this GPU (chunk g of the send buffer lands in chunk g of the receive buffer).  The C pipeline then does exactly one rank's
+    work of a `world`-GPU run -- one SpMV / NTT stage per round, `world` groups of inner products over 1/world of the points,
+    one assembly -- but the proofs it returns are NOT valid (bench.py --emulate-world)."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    D2D = 3
+
+    def a2a(user, send, recv, per_rank):
+        return 1 if hip.hipMemcpy(recv, send, per_rank * world, D2D) != 0 else 0
+
+    def gather(user, send, recv, per_rank):
+        for g in range(world):
+            if hip.hipMemcpy(recv + g * per_rank, send, per_rank, D2D) != 0:
+                return 1
+        return 0
+
+    def max_f64(user, val):
+        return 0
+
+    ops = _lib.CommOps(None, _lib.A2A_FN(a2a), _lib.A2A_FN(gather), _lib.BARRIER_FN(lambda user: 0), _lib.MAXF64_FN(max_f64))
+    return Comm(ctx, 0, world, ops=ops)
+
+
 class MgpuProver:
     """zk_mgpu: the scalar-exchange prover as a pipeline inside the library.  push() hands in this rank's proof of the next
     round, pop() returns this rank's proof of the oldest round; both are collective (same call sequence on every rank)."""
