@@ -237,13 +237,10 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         ctx.setup(qap, ints_to_limbs([5, 6, 7, 8, 2 * n - 1]))
     assert e.value.status == -7
-    # batches and the scalar exchange want the roots-of-unity form
+    # batches want the roots-of-unity form
     host = np.ascontiguousarray(weights)
     with pytest.raises(zk.ZkError) as e:
         ctx.prove_batch_submit(crs, qap, [host.ctypes.data], [host.shape[0]], [r], [s])   # refused before the pointer is touched
-    assert e.value.status == -7
-    with pytest.raises(zk.ZkError) as e:
-        ctx.prove_exchange_elems(qap, 2)
     assert e.value.status == -7
     # size limit
     one = (np.zeros(3, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64))
@@ -268,3 +265,59 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     q2 = ctx.qap_load(tmp_path / "c.zkqap")
     assert (q2.n, q2.m, q2.input, q2.dense) == (n, circ.m, circ.input, False)
     assert ctx.prove(ctx.setup(q2, td), q2, weights, r, s) == good
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 37, 1000])
+def test_gpu_integer_roots_on_several_ranks(ctx, n):
+    """the multi-GPU data paths for this QAP form, all ranks of worlds 1..8 played by one device: the scalar exchange
+    (zk_prove_scalars_submit -> all-to-all by slicing -> zk_prove_msm_submit per rank -> zk_prove_combine), the latency form
+    (zk_prove_partial by windows and by point ranges) and the C pipeline at world 1"""
+    torch = pytest.importorskip("torch")
+    from zksnark_rs_amd.distributed import Comm, MgpuProver
+    rng = SplitMix64(9900 + n)
+    m, l = 3 * n + 4, min(2, 3 * n + 3)
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    proofs = [(ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)]), rng.fr(), rng.fr()),
+              (ints_to_limbs([1] + [rng.fr() for _ in range(max(l + 1, m - 3) - 1)]), rng.fr(), rng.fr())]     # the second one truncated
+    want = [ctx.prove(crs, qap, wt, r, s) for wt, r, s in proofs]
+    dws = [torch.from_numpy(np.ascontiguousarray(wt).view(np.int64)).cuda() for wt, _, _ in proofs]
+    torch.cuda.synchronize()
+    for world in (1, 2, 3, 8):
+        elems = ctx.prove_exchange_elems(qap, world)
+        assert all(e % world == 0 for e in elems) and elems[1] >= n and elems[3] >= 2 * n - 1
+        send = [[torch.zeros(32 * e, dtype=torch.uint8, device="cuda") for e in elems] for _ in proofs]
+        for j, (wt, r, s) in enumerate(proofs):
+            t = ctx.prove_scalars_submit(crs, qap, dws[j].data_ptr(), wt.shape[0], r, s, world, [x.data_ptr() for x in send[j]])
+            ctx.prove_wait(t, partial=True)
+        blobs = [[None] * world for _ in proofs]
+        for g in range(world):
+            recv = []
+            for k, e in enumerate(elems):
+                c = 32 * e // world
+                recv.append(torch.cat([send[j][k][g * c:(g + 1) * c] for j in range(len(proofs))]))
+            part = torch.zeros(len(proofs) * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            t = ctx.prove_msm_submit(crs, qap, len(proofs), g, world, [x.data_ptr() for x in recv], part.data_ptr())
+            ctx.prove_wait(t, partial=True)
+            for j in range(len(proofs)):
+                blobs[j][g] = part[j * zk.PARTIAL_BYTES:(j + 1) * zk.PARTIAL_BYTES].clone()
+        for j, (wt, r, s) in enumerate(proofs):
+            assert ctx.prove_combine(crs, torch.cat(blobs[j]).data_ptr(), world, r, s) == want[j], (world, j)
+    wt, r, s = proofs[0]
+    for by_points in (0, 1):
+        ctx.set_option("msm_shard_points", by_points)
+        try:
+            for world in (2, 3):
+                buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+                for rank in range(world):
+                    ctx.prove_partial(crs, qap, dws[0].data_ptr(), m, r, s, rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+                torch.cuda.synchronize()
+                assert ctx.prove_combine(crs, buf.data_ptr(), world, r, s) == want[0], (by_points, world)
+        finally:
+            ctx.set_option("msm_shard_points", 0)
+    comm = Comm(ctx, 0, 1)
+    mp = MgpuProver(ctx, comm, crs, qap)
+    assert list(mp.prove_stream([(dws[0].data_ptr(), m, r, s)] * 3, ahead=2)) == [want[0]] * 3
+    mp.close(); comm.close()

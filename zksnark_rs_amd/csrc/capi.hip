@@ -274,7 +274,7 @@ int zk_prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out)
 }
 int zk_prove_exchange_elems(const zk_qap* qap, int world, size_t elems_out[4]) {
     if (!qap || world < 1 || !elems_out) return ZK_ERR_ARG;
-    if (qap->dense || qap->roots) return ZK_ERR_UNSUPPORTED;
+    if (qap->dense) return ZK_ERR_UNSUPPORTED;
     prove_exchange_elems(*qap, world, elems_out);
     return ZK_OK;
 }

@@ -302,7 +302,7 @@ static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, z
 
 int zk_mgpu_create(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out) {
     if (!ctx || !c || !crs || !qap || !out) return ZK_ERR_ARG;
-    if (qap->dense || qap->roots) return ZK_ERR_UNSUPPORTED;
+    if (qap->dense) return ZK_ERR_UNSUPPORTED;
     GpuBackend* gpu = new (std::nothrow) GpuBackend{ctx, crs, qap};
     if (!gpu) return ZK_ERR_HIP;
     zk_mgpu_backend be{gpu, gpu_elems, gpu_alloc, gpu_free, gpu_scalars, gpu_msm, gpu_wait, gpu_combine};

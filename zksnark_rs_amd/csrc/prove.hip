@@ -337,7 +337,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     const zk_qap& q = qap_c;
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
     ZK_REQUIRE(d_partial_out || world == 1 || xout, ZK_ERR_ARG, "prove: world > 1 needs a partial output buffer");
-    ZK_REQUIRE(!xout || (!qap_c.dense && !qap_c.roots), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!xout || !qap_c.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs a sparse QAP form");
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     ZK_REQUIRE(!q.dense || !q.t_is_zero, ZK_ERR_DIV_BY_ZERO, "Dividend must be non-zero");   // field/mod.rs:440
@@ -423,18 +423,33 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
         const size_t M = (size_t)1 << q.ap->log_m;
         S.uv.ensure(2 * n); S.xy.ensure(3 * M);
-        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+        Fr *vc_can, *uc_can, *hb_can;
+        if (xout) {
+            // exchange layout (as below): `world` equal chunks per product, zero scalars behind the last point
+            const ExchangeDims xd = exchange_dims(q, world);
+            vc_can = xout[1]; uc_can = xout[2]; hb_can = xout[3];
+            ZK_HIP(hipMemsetAsync(xout[0], 0, xd.cl * world * sizeof(Fr), st));
+            if (n_l) ZK_HIP(hipMemcpyAsync(xout[0], d_weights + l + 1, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            if (xd.cn * world > n) {
+                ZK_HIP(hipMemsetAsync(vc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+                ZK_HIP(hipMemsetAsync(uc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+            }
+            ZK_HIP(hipMemsetAsync(hb_can + (2 * n - 1), 0, (xd.ch * world - (2 * n - 1)) * sizeof(Fr), st));
+        } else {
+            S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+            vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
+        }
         Fr *ve = S.uv.p, *ue = S.uv.p + n;
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
         spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
         spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
-        fr_from_mont(ctx, ve, S.vc_can.p, n);
-        launch(0, 1, crs.t_xi2, S.vc_can.p, n, &ms->b2);                 // B = sum V_k [L_k(x)]_2
-        fr_from_mont(ctx, ue, S.uc_can.p, n);
-        launch(2, 0, crs.t_xi1, S.uc_can.p, n, &ms->a);                  // A = sum U_k [L_k(x)]_1
-        fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, S.hb_can.p + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
-        ap_quotient_values(ctx, q, ue, ve, S.xy.p, S.hb_can.p);          // h on S = {n+1 .. 2n-1}
-        launch(4, 2, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
+        fr_from_mont(ctx, ve, vc_can, n);
+        launch(0, 1, crs.t_xi2, vc_can, n, &ms->b2);                     // B = sum V_k [L_k(x)]_2
+        fr_from_mont(ctx, ue, uc_can, n);
+        launch(2, 0, crs.t_xi1, uc_can, n, &ms->a);                      // A = sum U_k [L_k(x)]_1
+        fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
+        ap_quotient_values(ctx, q, ue, ve, S.xy.p, hb_can);              // h on S = {n+1 .. 2n-1}
+        launch(4, 2, crs.t_hb1, hb_can, 2 * n - 1, &ms->hb);
     } else if (!q.dense) {
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
@@ -543,12 +558,12 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense && !q.roots, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs a sparse QAP form");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
-    crs_ensure_tables(ctx, crs, true, q.log_n);
+    if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true); else crs_ensure_tables(ctx, crs, true, q.log_n);
     StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
@@ -586,7 +601,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         launch(1, -1, crs.t_sum_delta1, d_l, xd.cl, nl, &ms->l);
         launch(0, 1, crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
         launch(2, 0, crs.t_xi1, d_uc, xd.cn, n, &ms->a);
-        launch(4, 2, crs.t_hb1, d_hb, xd.ch, 2 * n, &ms->hb);
+        launch(4, 2, crs.t_hb1, d_hb, xd.ch, q.roots ? 2 * n - 1 : 2 * n, &ms->hb);   // integer roots: L^S t/delta (n-1) | L (n)
     }
     hipStream_t fin = ctx->finish;
     ZK_HIP(hipEventRecord(S.fork_evt, st));
