@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_instance(zk, ctx, log_n, seed, witness="uniform"):
+def build_instance(zk, ctx, log_n, seed, witness="uniform", roots="unity"):
     from zksnark_rs_amd.circuits import chain_rows, chain_weights
     rng = zk.SplitMix64(seed)
     n = 1 << log_n
@@ -46,7 +46,8 @@ def build_instance(zk, ctx, log_n, seed, witness="uniform"):
     weights = chain_weights(log_n, x, avals)
     td = zk.ints_to_limbs([rng.fr() for _ in range(5)])
     r, s = rng.fr(), rng.fr()
-    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    # the same rows over the roots w^j (the metric's workload) or over ASTParser's roots 1..n
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w) if roots == "unity" else ctx.qap_sparse_integers(n, m, l, u, v, w)
     crs = ctx.setup(qap, td)      # groth16::setup on the GPU, outside the timed region
     return dict(n=n, m=m, l=l, rows=(u, v, w), qap=qap, crs=crs, weights=weights, td=td, r=r, s=s, log_n=log_n)
 
@@ -194,6 +195,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
+    ap.add_argument("--roots", choices=["unity", "integers"], default="unity",
+                    help="QAP domain: unity = w^j (the metric's workload); integers = 1..n, what ASTParser gives the same circuit "
+                         "(zk_qap_upload_sparse_integers; N = 1, no batches; secondary measurement, no CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="zk_ctx_set_option(KEY, VALUE) before the run (A/B switches)")
     ap.add_argument("--latency", action="store_true",
@@ -204,6 +208,8 @@ def main():
     args = ap.parse_args()
     if args.latency:
         args.depth, args.no_cpu_baseline = 1, True
+    if args.roots == "integers":
+        args.no_cpu_baseline = True
 
     import torch
     import zksnark_rs_amd as zk
@@ -273,7 +279,7 @@ def main():
         ctx.set_option("msm_alt_g2", args.alt_g2)
     if args.acc_stream >= 0:
         ctx.set_option("msm_acc_stream", args.acc_stream)
-    inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness)
+    inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness, args.roots)
     d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
     m = inst["m"]
     exchange = world > 1 and args.mode == "exchange"
@@ -545,8 +551,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
             "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d)" % (args.witness, args.seed),
-            "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM"
-                                   % (args.log_n, m),
+            "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM%s"
+                                   % (args.log_n, m, "" if args.roots == "unity" else "; QAP over the integer roots 1..n"),
                        "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("point-range" if args.shard == "points" else "window", world)) if shard
                                       else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums (%s); "
                                             "a step = one round of %d proofs" % (world, "zk_comm / zk_mgpu inside libzkgpu.so" if use_zk else "torch.distributed", world)) if exchange

@@ -353,8 +353,8 @@ int zk_mgpu_prove_sharded(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const z
  * the same sequence of push / pop calls.  At most three rounds may be pushed and not yet popped; pushing two rounds ahead
  * of every pop (push, push, push, pop, push, pop, ...) keeps the SpMV / NTT stage two rounds ahead of the inner products, so
  * that neither the exchanges nor the host waits leave a GPU idle; push / pop strictly alternating is the one-round-at-a-time
- * (latency) schedule.  Per-GPU work per round is one whole proof's worth whatever `world` is.  Sparse (roots-of-unity)
- * QAP form only. */
+ * (latency) schedule.  Per-GPU work per round is one whole proof's worth whatever `world` is.  Sparse QAP forms only
+ * (roots of unity or integer roots). */
 typedef struct zk_mgpu zk_mgpu;
 int zk_mgpu_create(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out);
 int zk_mgpu_push(zk_mgpu* p, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]);
