@@ -144,7 +144,7 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
  * O(nnz + n log n) per proof where the dense form is O(m n); SURVEY.md 8-f4.  A CRS for such a QAP must come from
  * zk_setup on this library or from a file zk_crs_save wrote for it (zk_crs_upload carries only the reference's arrays:
  * ZK_ERR_UNSUPPORTED at prove);
- * zk_prove_batch_* needs the roots-of-unity form (the multi-GPU entry points take both sparse forms). */
+ * Batches and the multi-GPU entry points take both sparse forms. */
 int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out);
 
 /* Dense coefficient form, exactly the fields of QAP<CoefficientPoly<FrLocal>>: u, v, w are

@@ -237,11 +237,6 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         ctx.setup(qap, ints_to_limbs([5, 6, 7, 8, 2 * n - 1]))
     assert e.value.status == -7
-    # batches want the roots-of-unity form
-    host = np.ascontiguousarray(weights)
-    with pytest.raises(zk.ZkError) as e:
-        ctx.prove_batch_submit(crs, qap, [host.ctypes.data], [host.shape[0]], [r], [s])   # refused before the pointer is touched
-    assert e.value.status == -7
     # size limit
     one = (np.zeros(3, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64))
     with pytest.raises(zk.ZkError) as e:
@@ -321,3 +316,35 @@ def test_gpu_integer_roots_on_several_ranks(ctx, n):
     mp = MgpuProver(ctx, comm, crs, qap)
     assert list(mp.prove_stream([(dws[0].data_ptr(), m, r, s)] * 3, ahead=2)) == [want[0]] * 3
     mp.close(); comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 16, 100, 3000])
+def test_gpu_integer_roots_batches(ctx, n):
+    """zk_prove_batch_* on this QAP form (many proofs of one small ASTParser circuit): == zk_prove one by one, with a truncated
+    and an all-zero witness in the batch, batches of 1, 3 and 5, two batches in flight"""
+    torch = pytest.importorskip("torch")
+    rng = SplitMix64(9950 + n)
+    if n == 16:
+        circ = Circuit(open(os.path.join(GOLD, "zk", "deg_15.zk")).read())
+        qap, m, l = circ.qap_sparse(ctx), circ.m, circ.input
+        assert circ.n == 16
+    else:
+        m, l = 2 * n + 5, 1
+        u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+        qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    wits = [ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)]) for _ in range(5)]
+    wits[2] = wits[2][:max(l + 1, m - 2)]
+    wits[3] = np.zeros_like(wits[3])
+    rs = [rng.fr() for _ in wits]
+    ss = [rng.fr() for _ in wits]
+    want = [ctx.prove(crs, qap, wt, r, s) for wt, r, s in zip(wits, rs, ss)]
+    dws = [torch.from_numpy(np.ascontiguousarray(wt).view(np.int64)).cuda() for wt in wits]
+    torch.cuda.synchronize()
+    for count in (1, 3, 5):
+        t = ctx.prove_batch_submit(crs, qap, [d.data_ptr() for d in dws[:count]], [wt.shape[0] for wt in wits[:count]], rs[:count], ss[:count])
+        assert ctx.prove_batch_wait(t, count) == want[:count], count
+    t1 = ctx.prove_batch_submit(crs, qap, [d.data_ptr() for d in dws[:2]], [wt.shape[0] for wt in wits[:2]], rs[:2], ss[:2])
+    t2 = ctx.prove_batch_submit(crs, qap, [d.data_ptr() for d in dws[2:]], [wt.shape[0] for wt in wits[2:]], rs[2:], ss[2:])
+    assert ctx.prove_batch_wait(t1, 2) == want[:2] and ctx.prove_batch_wait(t2, 3) == want[2:]

@@ -120,11 +120,13 @@ Fr ap_t_at_x(const zk_qap& q, const uint64_t trapdoor[20]) {
 }
 
 // ---- prove: the scalars of the four inner products ----------------------------------------------------------------------
+// Batch form: blockIdx.y = proof j; its SpMV outputs sit at ue + j n / ve + j n, its three transforms at work + 3 j M.
 // buf[0] = w . Ue, buf[1] = w . Ve, buf[2] = w . (Ue . Ve), zero padded to M
 __global__ void k_ap_prep(const Fr* __restrict__ ue, const Fr* __restrict__ ve, const Fr* __restrict__ w, size_t n, size_t M, Fr* __restrict__ buf) {
     ZK_LATENCY_KERNEL();
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
+    ue += (size_t)blockIdx.y * n; ve += (size_t)blockIdx.y * n; buf += (size_t)blockIdx.y * 3 * M;
     if (j < n) {
         const Fr u = ue[j], v = ve[j], wj = w[j];
         buf[j] = wj * u;
@@ -134,33 +136,35 @@ __global__ void k_ap_prep(const Fr* __restrict__ ue, const Fr* __restrict__ ve, 
         buf[j] = buf[M + j] = buf[2 * M + j] = Fr::zero();
     }
 }
-__global__ void k_ap_mul_bhat(Fr* __restrict__ buf, const Fr* __restrict__ bhat, size_t M) {
+__global__ void k_ap_mul_bhat(Fr* __restrict__ buf, const Fr* __restrict__ bhat, size_t M, size_t total) {
     ZK_LATENCY_KERNEL();
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 3 * M) return;
+    if (j >= total) return;
     buf[j] = buf[j] * bhat[j & (M - 1)];
 }
-// h(s_i) = N(s_i) c_U c_V - c_E with c_F = buf_F[n - 1 + i]  ->  canonical
-__global__ void k_ap_h(const Fr* __restrict__ buf, const Fr* __restrict__ ntab, size_t n, size_t M, Fr* __restrict__ out) {
+// h(s_i) = N(s_i) c_U c_V - c_E with c_F = buf_F[n - 1 + i]  ->  canonical, proof j at out + j out_stride
+__global__ void k_ap_h(const Fr* __restrict__ buf, const Fr* __restrict__ ntab, size_t n, size_t M, Fr* __restrict__ out, size_t out_stride) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i + 1 >= n) return;
+    buf += (size_t)blockIdx.y * 3 * M; out += (size_t)blockIdx.y * out_stride;
     const size_t t = n - 1 + i;
     out[i] = (ntab[i] * buf[t] * buf[M + t] - buf[2 * M + t]).to_canonical();
 }
 
-// ue / ve: the SpMV outputs (n each); writes the n - 1 values of h to hb_can (canonical); `work` holds 3 M elements
-void ap_quotient_values(zk_ctx* ctx, const zk_qap& q, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can) {
+// ue / ve: the SpMV outputs (`count` x n each); writes the n - 1 values of h of proof j to hb_can + j hb_stride (canonical);
+// `work` holds 3 M count elements
+void ap_quotient_values(zk_ctx* ctx, const zk_qap& q, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can, size_t count, size_t hb_stride) {
     const size_t n = q.n;
     if (n < 2) return;
     const ApTables& t = *q.ap;
     const size_t M = (size_t)1 << t.log_m;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_ap_prep, dim3(ceil_div(M, 256)), dim3(256), 0, st, ue, ve, t.w.p, n, M, work);
-    ntt_dif(ctx, work, t.log_m, false, false, 3);
-    hipLaunchKernelGGL(k_ap_mul_bhat, dim3(ceil_div(3 * M, 256)), dim3(256), 0, st, work, t.bhat.p, M);
-    ntt_dit(ctx, work, t.log_m, true, true, nullptr, 3);
-    hipLaunchKernelGGL(k_ap_h, dim3(ceil_div(n - 1, 256)), dim3(256), 0, st, work, t.ntab.p, n, M, hb_can);
+    hipLaunchKernelGGL(k_ap_prep, dim3(ceil_div(M, 256), count), dim3(256), 0, st, ue, ve, t.w.p, n, M, work);
+    ntt_dif(ctx, work, t.log_m, false, false, 3 * count);
+    hipLaunchKernelGGL(k_ap_mul_bhat, dim3(ceil_div(3 * M * count, 256)), dim3(256), 0, st, work, t.bhat.p, M, 3 * M * count);
+    ntt_dit(ctx, work, t.log_m, true, true, nullptr, 3 * count);
+    hipLaunchKernelGGL(k_ap_h, dim3(ceil_div(n - 1, 256), count), dim3(256), 0, st, work, t.ntab.p, n, M, hb_can, hb_stride);
     ZK_HIP(hipGetLastError());
 }
 

@@ -80,7 +80,7 @@ zk_qap* qap_upload_rows(zk_ctx*, const zk_qap_sparse_desc&, size_t n);          
 zk_qap* qap_upload_sparse_integers(zk_ctx*, const zk_qap_sparse_desc&, size_t n);       // aproots.hip
 void ap_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, Fr* d_LS, int* d_flag);
 Fr ap_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
-void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can);
+void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can, size_t count = 1, size_t hb_stride = 0);
 zk_qap* qap_upload_dense(zk_ctx*, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input);
 void qap_free(zk_qap*);
 void qap_save(zk_ctx*, const zk_qap&, const char* path);      // serialize.hip

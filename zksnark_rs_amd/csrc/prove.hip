@@ -625,13 +625,13 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
                        const uint64_t* r, const uint64_t* s) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense && !q.roots, ZK_ERR_UNSUPPORTED, "prove: batches need the roots-of-unity (sparse) QAP form");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: batches need a sparse QAP form");
     ZK_REQUIRE(count >= 1 && count <= ZK_MAX_BATCH, ZK_ERR_ARG, "prove: batch size out of range");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
-    crs_ensure_tables(ctx, crs, true, q.log_n);
+    if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true); else crs_ensure_tables(ctx, crs, true, q.log_n);
     crs_ensure_fixed_tables(ctx, crs);
     if (!S.h_b_proofs) {
         ZK_HIP(hipHostMalloc((void**)&S.h_b_proofs, (size_t)ZK_MAX_BATCH * ZK_PROOF_BYTES));
@@ -687,6 +687,27 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         if (n_l[j]) ZK_HIP(hipMemcpyAsync(S.bx_l.p + (size_t)j * cl, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     }
     launch(1, -1, crs.t_sum_delta1, S.bx_l.p, cl, nl, &ms->l);
+    if (q.roots) {
+        // integer roots (aproots.hip): evaluation values as scalars of A and B, h on {n+1..2n-1} by one batched convolution
+        const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1), M = (size_t)1 << q.ap->log_m;
+        S.uv.ensure(2 * n * cnt); S.xy.ensure(3 * M * cnt); S.a_mont.ensure(amax * cnt);
+        Fr *ve = S.uv.p, *ue = S.uv.p + n * cnt;
+        for (size_t j = 0; j < cnt; ++j) {
+            Fr* a_mont = S.a_mont.p + j * amax;
+            fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
+            spmv(ctx, q.u_gate, a_mont, a_len[j], ue + j * n);
+            spmv(ctx, q.v_gate, a_mont, a_len[j], ve + j * n);
+        }
+        fr_from_mont(ctx, ve, S.bx_v.p, n * cnt);
+        launch(0, 1, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
+        fr_from_mont(ctx, ue, S.bx_u.p, n * cnt);
+        launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
+        for (size_t j = 0; j < cnt; ++j)       // bases: L^S t/delta (n-1) | L (n); group stride 2n, 2n-1 valid
+            fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+                                    S.bx_h.p + j * 2 * n + (n - 1), n);
+        ap_quotient_values(ctx, q, ue, ve, S.xy.p, S.bx_h.p, cnt, 2 * n);
+        launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n - 1, &ms->hb);
+    } else {
     auto tabs = ntt_get_tables(ctx, q.log_n);
     ntt_ensure_coset_tables(ctx, *tabs);
     // the stage of sparse_scalar_stage with a batch dimension: scratch vectors are [count][n], the element-wise kernels and
@@ -719,6 +740,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     for (size_t j = 0; j < cnt; ++j)
         h_combine(ctx, x0 + j * n, y0 + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
     launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n, &ms->hb);
+    }
 
     hipStream_t fin = ctx->finish;
     ZK_HIP(hipEventRecord(S.fork_evt, st));
