@@ -320,8 +320,10 @@ def main():
             pass
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        free_b, total_b = torch.cuda.mem_get_info()
         print(json.dumps({"diagnostic": "rank 0 of a %d-way scalar-exchange prover (local copies instead of the all-to-alls)" % W,
-                          "ms_per_round_per_rank": round(dt * 1e3, 3), "implied_proofs_per_s_at_%d_gpus" % W: round(W / dt, 2)}))
+                          "ms_per_round_per_rank": round(dt * 1e3, 3), "implied_proofs_per_s_at_%d_gpus" % W: round(W / dt, 2),
+                          "hbm_in_use_GiB": round((total_b - free_b) / 2**30, 2)}))
         return
     if args.emulate_world and world == 1:
         from zksnark_rs_amd.distributed import GpuProver, prove_sharded_stream

@@ -215,7 +215,11 @@ def test_scalar_exchange_on_one_gpu(ctx, orc, log_n):
     proofs = [(inst["weights"], inst["r"], inst["s"]), (w2, inst["s"], inst["r"])]
     want = [ctx.prove(crs, inst["qap"], w, r, s) for w, r, s in proofs]
     dws = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w, _, _ in proofs]
-    for world in (1, 2, 3, 8):
+    for world in (1, 2, 3, 8, -3):
+        # every rank multiplies from window tables of its own point ranges only (option rank_tables, the default); world -3 = three
+        # ranks once more with slices of the full tables instead
+        ctx.set_option("rank_tables", 0 if world < 0 else 1)
+        world = abs(world)
         elems = ctx.prove_exchange_elems(inst["qap"], world)
         assert all(e % world == 0 for e in elems) and elems[1] >= inst["n"] and elems[3] >= 2 * inst["n"]
         # send[j][k]: array k of the proof owned by "rank" j (only ranks 0 and 1 own a proof here)
@@ -238,6 +242,7 @@ def test_scalar_exchange_on_one_gpu(ctx, orc, log_n):
         for j, (w, r, s) in enumerate(proofs):
             gathered = torch.cat(blobs[j])
             assert ctx.prove_combine(crs, gathered.data_ptr(), world, r, s) == want[j], (world, j)
+    ctx.set_option("rank_tables", 1)
     # the pipelined driver with local exchanges (world 1): five rounds through the two-deep software pipeline
     from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
     prover = GpuExchangeProver(ctx, crs, inst["qap"], dws[0], inst["m"])

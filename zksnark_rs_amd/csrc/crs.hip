@@ -169,6 +169,55 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool l
     c.tables_c = ctx->opt_window_bits;
 }
 
+// The same tables restricted to the points rank `rank` of `world` owns in the scalar exchange: [rank c, (rank + 1) c) of every
+// product, c = cl / cn / ch (ExchangeDims, prove.hip).  Window sizes are picked for the full products, so that a rank's table is
+// a slice of what crs_ensure_tables would have built.
+void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool lagrange, int rank, int world, size_t cl, size_t cn, size_t ch) {
+    const int kind = lagrange ? 2 : (brev ? 1 : 0);
+    zk_crs::RankTables& R = c.rank_tabs;
+    if (R.rank == rank && R.world == world && R.kind == kind && R.c_opt == ctx->opt_window_bits) return;
+    ZK_REQUIRE(!lagrange || c.ap, ZK_ERR_UNSUPPORTED, "prove: an integer-roots QAP needs the CRS zk_setup made for it (Lagrange-basis points)");
+    if (brev) crs_ensure_brev(ctx, c, log_n);
+    const long o_all = ctx->opt_window_bits, o_g2 = o_all / 10000;
+    auto pick = [&](size_t count) {
+        const long o = o_all % 10000;
+        if (o <= 0) return msm_auto_window(count);
+        if (o < 100) return (int)o;
+        return (int)(count >= ((size_t)1 << 21) - 8 ? o / 100 : o % 100);
+    };
+    const size_t n = c.n, nl = c.m - c.input - 1, g = (size_t)rank;
+    auto range = [&](size_t chunk, size_t count, size_t* lo) {
+        *lo = std::min(g * chunk, count);
+        return std::min(chunk, count - *lo);
+    };
+    const G1A* b_xi1 = lagrange ? c.lag1.p : (brev ? c.xi1_br.p : c.xi1.p);
+    const G1A* b_xit = lagrange ? c.lagS_t1.p : (brev ? c.xi_t1_br.p : c.xi_t1.p);
+    const G2A* b_xi2 = lagrange ? c.lag2.p : (brev ? c.xi2_br.p : c.xi2.p);
+    size_t lo, cnt;
+    auto build1 = [&](const G1A* pts, size_t count, size_t chunk, MsmTable<Fq>& out) {
+        cnt = range(chunk, count, &lo);
+        msm_build_table<Fq>(ctx, pts + lo, cnt, pick(count), out);
+    };
+    build1(b_xi1, n, cn, R.t_xi1);
+    {
+        const size_t nt = brev ? n : n - 1;
+        DevBuf<G1A> cat(nt + n);
+        if (nt) ZK_HIP(hipMemcpyAsync(cat.p, b_xit, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(cat.p + nt, b_xi1, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        build1(cat.p, nt + n, ch, R.t_hb1);
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    build1(c.sum_delta1.p, nl, cl, R.t_sum_delta1);
+    cnt = range(cn, n, &lo);
+    msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : pick(n), R.t_xi2);
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    if (brev) {   // the tables hold the permuted points
+        c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();
+        c.has_br = false;
+    }
+    R.rank = rank; R.world = world; R.kind = kind; R.c_opt = ctx->opt_window_bits;
+}
+
 // FT[w][d] = d * 16^w * P, w < 64, d < 16 (one lane per window; built once per CRS)
 template <class F>
 __global__ void k_fixed_table(const Aff<F>* __restrict__ point, Aff<F>* __restrict__ table) {

@@ -64,6 +64,14 @@ struct zk_crs {
     // (built on first use for the order -- natural or bit-reversed -- the QAP kind needs)
     zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;   // t_hb1: bases xi_t | xi (H and r*B1 in one product)
     zk::MsmTable<zk::Fq2> t_xi2;
+    // per-rank tables of the multi-GPU scalar exchange: only the points [g c, (g+1) c) of every product that rank g of `world`
+    // multiplies (1 / world of the table memory and of the time to build them); one (rank, world) at a time
+    struct RankTables {
+        int rank = -1, world = 0, kind = -1;
+        long c_opt = -1;
+        zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;
+        zk::MsmTable<zk::Fq2> t_xi2;
+    } rank_tabs;
     int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed, 2 Lagrange-basis points (integer roots)
     // 4-bit fixed-base tables FT[w][d] = d * 16^w * P (64 x 16 entries) for the single CRS points
     // that prove() multiplies by r, s and r*s
@@ -97,6 +105,7 @@ zk_crs* crs_load(zk_ctx*, const char* path);
 void crs_free(zk_crs*);
 void crs_ensure_brev(zk_ctx*, zk_crs&, unsigned log_n);
 void crs_ensure_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n, bool lagrange = false);
+void crs_ensure_rank_tables(zk_ctx*, zk_crs&, bool brev, unsigned log_n, bool lagrange, int rank, int world, size_t cl, size_t cn, size_t ch);
 void crs_download_lagrange(zk_ctx*, const zk_crs&, uint64_t* lag1, uint64_t* lagS_t1, uint64_t* lag2);
 void crs_attach_lagrange(zk_ctx*, zk_crs&, const uint64_t* lag1, const uint64_t* lagS_t1, const uint64_t* lag2);
 void crs_ensure_fixed_tables(zk_ctx*, zk_crs&);

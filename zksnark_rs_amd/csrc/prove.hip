@@ -347,7 +347,8 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
-    if (q.dense) crs_ensure_tables(ctx, crs, false, 0);
+    if (xout) {}   // scalars only: no inner product, no table (the ranks of a scalar exchange build only their own slices)
+    else if (q.dense) crs_ensure_tables(ctx, crs, false, 0);
     else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
     if (q.dense && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
@@ -563,13 +564,17 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
-    if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true); else crs_ensure_tables(ctx, crs, true, q.log_n);
+    const ExchangeDims xd = exchange_dims(q, world);
+    // world > 1: tables of this rank's point ranges only (option rank_tables; 0 = slices of the full tables, as a lone prover has them)
+    const bool rt = world > 1 && ctx->opt_rank_tables;
+    if (rt) crs_ensure_rank_tables(ctx, crs, !q.roots, q.log_n, q.roots != 0, rank, world, xd.cl, xd.cn, xd.ch);
+    else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
+    else crs_ensure_tables(ctx, crs, true, q.log_n);
     StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
     ctx->cur_slot = ticket;
     S.batch = 0;
     S.partial = true;
-    const ExchangeDims xd = exchange_dims(q, world);
     const size_t n = q.n, nl = q.m > q.input + 1 ? q.m - q.input - 1 : 0, g = (size_t)rank;
     auto range = [&](size_t c, size_t count, size_t* lo) {   // this rank's points of a product: [lo, lo + returned count)
         *lo = std::min(g * c, count);
@@ -591,6 +596,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         S.ws[k].tail_stream = tail_stream_for(ctx, k);
         S.ws[k].sort_stream = nullptr;
         S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
+        if (rt) lo = 0;   // the rank's table starts at its first point
         hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
@@ -598,10 +604,10 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     };
     if (sets > 0) {
         MsmResults* ms = reinterpret_cast<MsmResults*>(d_partials_out);
-        launch(1, -1, crs.t_sum_delta1, d_l, xd.cl, nl, &ms->l);
-        launch(0, 1, crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
-        launch(2, 0, crs.t_xi1, d_uc, xd.cn, n, &ms->a);
-        launch(4, 2, crs.t_hb1, d_hb, xd.ch, q.roots ? 2 * n - 1 : 2 * n, &ms->hb);   // integer roots: L^S t/delta (n-1) | L (n)
+        launch(1, -1, rt ? crs.rank_tabs.t_sum_delta1 : crs.t_sum_delta1, d_l, xd.cl, nl, &ms->l);
+        launch(0, 1, rt ? crs.rank_tabs.t_xi2 : crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
+        launch(2, 0, rt ? crs.rank_tabs.t_xi1 : crs.t_xi1, d_uc, xd.cn, n, &ms->a);
+        launch(4, 2, rt ? crs.rank_tabs.t_hb1 : crs.t_hb1, d_hb, xd.ch, q.roots ? 2 * n - 1 : 2 * n, &ms->hb);   // integer roots: L^S t/delta (n-1) | L (n)
     }
     hipStream_t fin = ctx->finish;
     ZK_HIP(hipEventRecord(S.fork_evt, st));
