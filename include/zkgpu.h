@@ -78,7 +78,7 @@ long zk_get_option(const zk_ctx* ctx, const char* key);
  *   inverse=0: out[k] = sum_j in[j] * w^(jk)            == field::dft   (field/mod.rs:508-520)
  *   inverse=1: w^-1 and scaling by n^-1                 == field::idft  (field/mod.rs:524-537)
  * with w = 5^((r-1)/2^log_n).  coset=1 evaluates on / interpolates from the coset g*<w> with
- * g = 5^((r-1)/2^(log_n+1)) (forward: in[j] *= g^j first; inverse: out[j] *= g^-j last). */
+ * g = 5^((r-1)/2^(log_n+1)) (forward: in[j] *= g^j first; inverse: out[j] *= g^-j last).  log_n <= 24 (23 with coset). */
 int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset);
 
 /* sum_i scalars[i] * points[i]: the SigmaG1/SigmaG2 inner products of groth16::prove
@@ -137,7 +137,7 @@ typedef struct {
 } zk_qap_sparse_desc;
 int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** out);
 /* The same rows over the roots ASTParser emits, the integers 1..n (circuit/mod.rs:517: `roots: (1..=n)`), for any
- * n <= 2^21 (desc->log_n is ignored).  Equivalent to QAP::from(root_rep) (fr.rs:140-173) followed by the reference's
+ * n <= 2^23 (desc->log_n is ignored).  Equivalent to QAP::from(root_rep) (fr.rs:140-173) followed by the reference's
  * coefficient-form prove (mod.rs:199-290) -- the proofs are byte-identical to the dense form's -- but nothing is ever
  * interpolated: the prover keeps U, V as values on {1..n}, the quotient as values on {n+1..2n-1}, and takes its inner
  * products with the CRS in those Lagrange bases, which zk_setup emits next to the reference's [x^i] arrays.  Costs

@@ -133,6 +133,32 @@ def test_ntt_full_size_properties(ctx):
     assert np.array_equal(ctx.ntt_fr(delta), ones)
 
 
+@pytest.mark.parametrize("log_n", [23, 24])
+def test_ntt_three_passes(ctx, orc, log_n):
+    """sizes above 2^22 take one more column pass (ntt.hip): == the oracle's NTT at 2^23 (plain and coset), round trips, a
+    delta -> all ones, a shifted delta -> the powers of w at sampled positions"""
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    fa = ctx.ntt_fr(a)
+    assert np.array_equal(ctx.ntt_fr(fa, inverse=True), a)
+    if log_n == 23:
+        assert np.array_equal(fa, orc.ntt_fr(a))
+        fc = ctx.ntt_fr(a, coset=True)
+        assert np.array_equal(fc, orc.ntt_fr(a, coset=True))
+        assert np.array_equal(ctx.ntt_fr(fc, inverse=True, coset=True), a)
+    del fa
+    delta = np.zeros((n, 4), np.uint64); delta[0, 0] = 1
+    ones = np.zeros((n, 4), np.uint64); ones[:, 0] = 1
+    assert np.array_equal(ctx.ntt_fr(delta), ones)
+    delta[0, 0] = 0; delta[1, 0] = 1            # e_1 -> (w^j)_j
+    f1 = ctx.ntt_fr(delta)
+    w = zk.limbs_to_int(orc.root_of_unity(log_n))
+    for j in (0, 1, 2, 12345, (1 << 22) - 1, 1 << 22, (1 << 22) + 7, n // 2 + 3, n - 1):
+        assert zk.limbs_to_int(f1[j]) == pow(w, j, R_MODULUS), j
+
+
 @pytest.mark.parametrize("n,c", [(0, 0), (1, 0), (2, 3), (17, 4), (100, 0), (300, 7), (1000, 11), (1000, 13), (1000, 16), (3000, 17), (3000, 20), (500, 22)])
 def test_msm_matches_reference_sum(ctx, orc, n, c):
     """GPU Pippenger == n double-and-add multiplications folded sequentially (mod.rs:255-272)."""

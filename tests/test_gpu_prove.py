@@ -152,11 +152,12 @@ def test_prove_full_size_2_20(ctx, orc):
     assert got == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
 
 
-def test_prove_max_size_2_21_and_size_limit(ctx, orc):
-    """Largest supported sparse size (the coset transforms need the 2^(log_n+1)-th roots, and NTT_MAX_LOG = 22):
-    2^21 constraints, 4.2 M wires, proof == trapdoor closed form; 2^22 is refused with ZK_ERR_SIZE."""
-    log_n = 21
-    rng = SplitMix64(2121)
+def test_prove_2_22_gates_both_domains_and_size_limit(ctx, orc):
+    """Beyond the two-pass NTT (NTT_MAX_LOG = 24: sizes 2^23 and 2^24 take a third pass): 2^22 constraints, 8.4 M wires.  Over the
+    roots of unity the transforms are of size 2^22 (two passes); the same rows over the integer roots 1..n convolve at size 2^23
+    (three passes, forward and inverse).  Both proofs == their closed forms; 2^24 gates are refused with ZK_ERR_SIZE."""
+    log_n = 22
+    rng = SplitMix64(2222)
     n = 1 << log_n
     m, l, u, v, w = chain_rows(log_n)
     weights = chain_weights(log_n, rng.fr(), [rng.next() for _ in range(n)])   # 64-bit inputs keep generation fast
@@ -167,9 +168,13 @@ def test_prove_max_size_2_21_and_size_limit(ctx, orc):
     crs = ctx.setup(qap, td)
     assert ctx.prove(crs, qap, weights, r, s) == orc.trapdoor_proof_sparse(desc, td, weights, r, s)
     del crs, qap
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    crs = ctx.setup(qap, td)
+    assert ctx.prove(crs, qap, weights, r, s) == orc.trapdoor_proof_integers(desc, n, td, weights, r, s)
+    del crs, qap
     m2, l2, u2, v2, w2 = chain_rows(4)
     with pytest.raises(zk.ZkError) as e:
-        ctx.qap_sparse(22, m2, l2, u2, v2, w2)
+        ctx.qap_sparse(24, m2, l2, u2, v2, w2)
     assert e.value.status == -4
 
 

@@ -67,7 +67,7 @@ void ap_build_tables(zk_ctx* ctx, zk_qap& q) {
     // cyclic convolution size: the wanted outputs t = s - 2 in [n-1, 2n-3] must not alias, M >= 2n - 2
     unsigned lg = 1;
     while (((size_t)1 << lg) < std::max<size_t>(2 * n - 2, 2)) ++lg;
-    ZK_REQUIRE(lg <= NTT_MAX_LOG, ZK_ERR_SIZE, "integer-roots QAP: too many gates for the NTT (2n - 2 <= 2^22)");
+    ZK_REQUIRE(lg <= NTT_MAX_LOG, ZK_ERR_SIZE, "integer-roots QAP: too many gates for the NTT (2n - 2 <= 2^24)");
     t->log_m = lg;
     const size_t M = (size_t)1 << lg;
     t->bhat.alloc(M);
@@ -170,7 +170,7 @@ void ap_quotient_values(zk_ctx* ctx, const zk_qap& q, const Fr* ue, const Fr* ve
 
 // ---- upload -------------------------------------------------------------------------------------------------------
 zk_qap* qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc& desc, size_t n) {
-    ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << 21), ZK_ERR_SIZE, "integer-roots QAP: n must be in [1, 2^21]");
+    ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << (NTT_MAX_LOG - 1)), ZK_ERR_SIZE, "integer-roots QAP: n must be in [1, 2^23]");
     zk_qap* q = qap_upload_rows(ctx, desc, n);
     std::unique_ptr<zk_qap> guard(q);
     q->roots = 1;

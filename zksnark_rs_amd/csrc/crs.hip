@@ -177,6 +177,7 @@ void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, b
     zk_crs::RankTables& R = c.rank_tabs;
     if (R.rank == rank && R.world == world && R.kind == kind && R.c_opt == ctx->opt_window_bits) return;
     ZK_REQUIRE(!lagrange || c.ap, ZK_ERR_UNSUPPORTED, "prove: an integer-roots QAP needs the CRS zk_setup made for it (Lagrange-basis points)");
+    if (R.rank >= 0) ZK_HIP(hipDeviceSynchronize());   // another rank's tables are replaced (one device playing several ranks): nothing may still read them
     if (brev) crs_ensure_brev(ctx, c, log_n);
     const long o_all = ctx->opt_window_bits, o_g2 = o_all / 10000;
     auto pick = [&](size_t count) {

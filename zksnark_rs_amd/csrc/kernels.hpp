@@ -22,7 +22,7 @@ Fr host_fr_from_u64(uint64_t v);
 Fr host_fr_pow(Fr base, uint64_t e);
 
 constexpr unsigned NTT_MAX_LOCAL_LOG = 11;   // 2048-element LDS tiles (64 KiB)
-constexpr unsigned NTT_MAX_LOG = 22;
+constexpr unsigned NTT_MAX_LOG = 24;         // <= 22: at most two passes over HBM; 23, 24: one more column pass in front (ntt.hip)
 
 struct NttTables {
     unsigned log_n = 0;

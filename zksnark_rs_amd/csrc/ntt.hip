@@ -87,7 +87,7 @@ static Fr host_inv_pow2(unsigned k) {  // 2^-k
 std::shared_ptr<NttTables> ntt_get_tables(zk_ctx* ctx, unsigned log_n) {
     auto it = ctx->ntt_tables.find(log_n);
     if (it != ctx->ntt_tables.end()) return it->second;
-    ZK_REQUIRE(log_n <= NTT_MAX_LOG, ZK_ERR_SIZE, "NTT size above 2^22 is not supported");
+    ZK_REQUIRE(log_n <= NTT_MAX_LOG, ZK_ERR_SIZE, "NTT size above 2^24 is not supported");
     auto t = std::make_shared<NttTables>();
     t->log_n = log_n;
     Fr w2048 = host_root_of_unity(NTT_MAX_LOCAL_LOG);
@@ -97,12 +97,14 @@ std::shared_ptr<NttTables> ntt_get_tables(zk_ctx* ctx, unsigned log_n) {
     fr_powers(ctx, w2048.inv(), Fr::one(), t->tw_inv.p, 1024);
     if (log_n > NTT_MAX_LOCAL_LOG) {
         size_t n = (size_t)1 << log_n;
-        unsigned a = log_n - NTT_MAX_LOCAL_LOG;
+        // two passes: n = 2^a columns-transform x rows of 2^11; three passes (log_n > 22): 2^(log_n - 22) x blocks of 2^22
+        const unsigned log_r2 = log_n > 2 * NTT_MAX_LOCAL_LOG ? 2 * NTT_MAX_LOCAL_LOG : NTT_MAX_LOCAL_LOG;
+        unsigned a = log_n - log_r2;
         Fr w = host_root_of_unity(log_n);
         t->mid_fwd.alloc(n);
         t->mid_inv.alloc(n);
-        hipLaunchKernelGGL(k_mid_table, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, w, t->mid_fwd.p, a, NTT_MAX_LOCAL_LOG);
-        hipLaunchKernelGGL(k_mid_table, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, w.inv(), t->mid_inv.p, a, NTT_MAX_LOCAL_LOG);
+        hipLaunchKernelGGL(k_mid_table, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, w, t->mid_fwd.p, a, log_r2);
+        hipLaunchKernelGGL(k_mid_table, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, w.inv(), t->mid_inv.p, a, log_r2);
         ZK_HIP(hipGetLastError());
     }
     t->n_inv = host_inv_pow2(log_n);
@@ -328,7 +330,14 @@ static void launch_pass(zk_ctx* ctx, bool dit, Fr* d, const NttPass& p, size_t t
     ZK_HIP(hipGetLastError());
 }
 
-static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch) {
+__global__ void k_mul_rows(Fr* __restrict__ d, const Fr* __restrict__ f, size_t n, size_t total) {
+    ZK_LATENCY_KERNEL();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) d[i] = d[i] * f[i & (n - 1)];
+}
+
+// post: the factor applied with `scale` (null: 1 / 2^log_n) -- the blocks of a three-pass transform are scaled by 1 / n of the whole
+static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch, const Fr* post = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
@@ -340,8 +349,33 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     const Fr* tw = inverse ? tabs->tw_inv.p : tabs->tw_fwd.p;
     double pass_bytes = 64.0 * n * batch;  // read + write of every element
     if (!batch) return;
+    const Fr post_f = post ? *post : tabs->n_inv;
+    if (log_n > 2 * NTT_MAX_LOCAL_LOG) {
+        // Three passes: n = 2^a1 x 2^22.  One more column pass of 2^a1-point transforms (stride 2^22; a tile = 2^a1 rows of
+        // 2^(11 - a1) contiguous elements) with the twiddles w_n^(c brev(p)) on its store (DIF) / load (DIT), and the 2^a1
+        // contiguous blocks of 2^22 as a batch of two-pass transforms.  Same orders as below: DIF natural -> bit-reversed, DIT back.
+        const unsigned a1 = log_n - 2 * NTT_MAX_LOCAL_LOG, log_c = NTT_MAX_LOCAL_LOG - a1, log_blk = 2 * NTT_MAX_LOCAL_LOG;
+        const Fr* mid = inverse ? tabs->mid_inv.p : tabs->mid_fwd.p;
+        NttPass col{a1, log_c, log_blk - log_c, n, (size_t)1 << log_blk, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0};
+        const size_t col_tiles = ((size_t)1 << (log_blk - log_c)) * batch;
+        if (!dit) {
+            col.mid = mid;
+            launch_pass(ctx, false, d, col, col_tiles, "ntt_tile", pass_bytes);
+            ntt_core(ctx, false, d, log_blk, inverse, scale, nullptr, batch << a1, &post_f);
+        } else {
+            if (d_pre) {   // (the two-pass form fuses this into its first load; at these sizes one more pass is 1 / 4 of the transform)
+                hipLaunchKernelGGL(k_mul_rows, dim3(ceil_div(n * batch, 256)), dim3(256), 0, ctx->stream, d, d_pre, n, n * batch);
+                ZK_HIP(hipGetLastError());
+            }
+            ntt_core(ctx, true, d, log_blk, inverse, false, nullptr, batch << a1);
+            col.pre = mid;
+            col.has_post = scale ? 1 : 0;
+            launch_pass(ctx, true, d, col, col_tiles, "ntt_tile", pass_bytes);
+        }
+        return;
+    }
     if (log_n <= NTT_MAX_LOCAL_LOG) {
-        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, tabs->n_inv, scale ? 1 : 0};
+        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, post_f, scale ? 1 : 0};
         launch_pass(ctx, dit, d, p, batch, "ntt_tile", pass_bytes);
         return;
     }
@@ -349,8 +383,8 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     unsigned log_c = NTT_MAX_LOCAL_LOG > a ? NTT_MAX_LOCAL_LOG - a : 0;  // columns per tile
     size_t r2 = (size_t)1 << NTT_MAX_LOCAL_LOG;
     const Fr* mid = inverse ? tabs->mid_inv.p : tabs->mid_fwd.p;
-    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, nullptr, nullptr, tabs->n_inv, 0};
-    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, tabs->n_inv, 0};
+    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0};
+    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, post_f, 0};
     size_t col_tiles = (r2 >> log_c) * batch, row_tiles = ((size_t)1 << a) * batch;
     if (!dit) {
         col.mid = mid;
