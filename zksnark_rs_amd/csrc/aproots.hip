@@ -77,6 +77,7 @@ void ap_build_tables(zk_ctx* ctx, zk_qap& q) {
         ntt_dif(ctx, t->bhat.p, lg, false, false);
     }
     ZK_HIP(hipStreamSynchronize(st));
+    t->fact.release(); t->ifact.release();   // only the construction above reads them (64 B per gate)
     q.ap = t;
 }
 

@@ -12,7 +12,7 @@ struct DevCsr {
     size_t rows = 0, nnz = 0;
 };
 
-// tables of the integer-roots form (aproots.hip): factorials up to 2n, barycentric weights of R = {1..n} and of S = {n+1..2n-1},
+// tables of the integer-roots form (aproots.hip): (factorials up to 2n while they are built,) barycentric weights of R = {1..n} and of S = {n+1..2n-1},
 // N(s) = t(s) on S, NTT image of the sequence 1/d (cyclic size 2^log_m >= 2n - 2); all Montgomery
 struct ApTables {
     size_t n = 0;
