@@ -174,7 +174,7 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
     ZK_REQUIRE(kind <= 2 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
     size_t words;
     if (kind != 1) {
-        ZK_REQUIRE(head[2] <= (kind == 0 ? 26 : ((uint64_t)1 << 21)) && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
+        ZK_REQUIRE(head[2] <= (kind == 0 ? 26 : ((uint64_t)1 << 23)) && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
         words = 0;
         for (int k = 0; k < 3; ++k) words += (m + 1) + (head[5 + k] + 1) / 2 + head[5 + k] * 4;
     } else {
