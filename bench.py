@@ -126,7 +126,7 @@ def cpu_baseline(zk, ctx, seed, main_inst, full=False):
 
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
-PMC_FILE = "r2_pmc_traffic.json"
+PMC_FILES = {20: "r2_pmc_traffic.json", 16: "r2_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
 
 # VALU issue ceiling of gfx950 for the two instruction classes of the multiplier, from tools/ubench_valu.hip (>= 5 ms kernels, in-kernel
 # shader / wall clocks, cross-checked with SQ_INSTS_VALU and GRBM_GUI_ACTIVE: profiles/r2_ubench_valu.txt, r2_ubench_valu_pmc.txt):
@@ -141,12 +141,12 @@ VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
 ACC_INSTR = {"msm_accumulate_g1": (2242.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
 
 
-def pmc_traffic(name):
+def pmc_traffic(name, log_n=20):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this round's build (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this same command, tools/pmc_summary.py -> profiles/r2_pmc_traffic.json; FETCH_SIZE corrected
     as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: null when the file is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILES[log_n])) as f:
             return json.load(f)["kernels"][PMC_KERNEL[name]]["hbm_bytes_per_launch_corrected"]
     except Exception:
         return None
@@ -517,7 +517,8 @@ def main():
             c_used = args.window_bits or 17
             windows = 254 // c_used + 1
             gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
-            traffic = pmc_traffic(name) if (args.log_n == 20 and world == 1 and not args.window_bits) else None
+            traffic = pmc_traffic(name, args.log_n) if (args.log_n in PMC_FILES and world == 1 and not args.window_bits and args.batch <= 1
+                                                       and args.roots == "unity") else None
             winst, slow = ACC_INSTR[name]
             adds = pairs * windows
             g_inst = adds / (avg_ms * 1e-3) / 64.0 * winst / 1e9
