@@ -240,7 +240,7 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     # size limit
     one = (np.zeros(3, np.uint64), np.zeros(0, np.uint32), np.zeros((0, 4), np.uint64))
     with pytest.raises(zk.ZkError) as e:
-        ctx.qap_sparse_integers((1 << 21) + 1, 2, 0, one, one, one)
+        ctx.qap_sparse_integers((1 << 23) + 1, 2, 0, one, one, one)
     assert e.value.status == -4
     # CRS file: the Lagrange-basis arrays travel with it (ZKCRSv2), so a reloaded CRS serves this form again
     ctx.crs_save(crs, tmp_path / "c.zkcrs")
