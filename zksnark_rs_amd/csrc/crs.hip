@@ -170,8 +170,7 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool l
 }
 
 // The same tables restricted to the points rank `rank` of `world` owns in the scalar exchange: [rank c, (rank + 1) c) of every
-// product, c = cl / cn / ch (ExchangeDims, prove.hip).  Window sizes are picked for the full products, so that a rank's table is
-// a slice of what crs_ensure_tables would have built.
+// product, c = cl / cn / ch (ExchangeDims, prove.hip).
 void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool lagrange, int rank, int world, size_t cl, size_t cn, size_t ch) {
     const int kind = lagrange ? 2 : (brev ? 1 : 0);
     zk_crs::RankTables& R = c.rank_tabs;
@@ -197,7 +196,7 @@ void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, b
     size_t lo, cnt;
     auto build1 = [&](const G1A* pts, size_t count, size_t chunk, MsmTable<Fq>& out) {
         cnt = range(chunk, count, &lo);
-        msm_build_table<Fq>(ctx, pts + lo, cnt, pick(count), out);
+        msm_build_table<Fq>(ctx, pts + lo, cnt, pick(cnt), out);   // the window of the rank's own point count: `world` groups share the buckets
     };
     build1(b_xi1, n, cn, R.t_xi1);
     {
@@ -210,7 +209,7 @@ void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, b
     }
     build1(c.sum_delta1.p, nl, cl, R.t_sum_delta1);
     cnt = range(cn, n, &lo);
-    msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : pick(n), R.t_xi2);
+    msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : pick(cnt), R.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables hold the permuted points
         c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();

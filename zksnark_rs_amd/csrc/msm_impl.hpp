@@ -40,6 +40,11 @@ int msm_auto_window(size_t n) {
     // beats 16 (16 windows) by 5 % at 2^20..2^21 points; 18 has as many windows as 17, and 19/20 lose
     // again in the pipelined prover.  A narrow top window (254 - (W-1) c bits) is harmless since the
     // accumulation is balanced per lane, so small sizes just scale c with log2(n).
+    // Round 2: with the row / column reduction tail (2 independent additions per bucket, both fold chains in one launch per pass)
+    // c = 20 -- 13 windows -- wins for the products of 2^21 points and more (L and H + r B1 + s A at 2^20 gates): +1.3 .. 2.5 % on
+    // the pipelined prover against 17 on two boxes; 19 is level, 21 / 22 lose 4 / 6 %, and a wider window for the 2^20-point
+    // products (A; B in G2: 18 / 19 / 20 measured -7 / -8 / -3 %) does not pay (tools/ab_g2_window.sh).
+    if (n + 8 >= ((size_t)1 << 21)) return 20;
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
     if (lg >= 17) return 17;

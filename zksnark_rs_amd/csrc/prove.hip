@@ -271,6 +271,16 @@ static hipStream_t msm_stream_for(zk_ctx* ctx, int k, int ticket) {
     return ctx->msm_stream[k];
 }
 
+// The next submission takes the LOWEST free slot (not the next one in a ring): a caller that keeps d proofs in flight then only
+// ever touches d slots -- their buffers (2.5 GiB each at 2^20, allocated on first use) are allocated during the first d proofs
+// and never inside a steady-state region, and with two in flight consecutive proofs still alternate between slots 0 and 1 (and so
+// between the two main streams).
+static void pick_next_slot(ProveState& ps) {
+    for (int k = 0; k < ProveState::SLOTS; ++k)
+        if (!ps.slot[k].busy) { ps.next = k; return; }
+    ps.next = (ps.next + 1) % ProveState::SLOTS;   // all busy: the next submit reports it
+}
+
 static ProveState& prove_state(zk_ctx* ctx) {
     if (!ctx->prove_state) ctx->prove_state = std::make_shared<ProveState>();
     return *ctx->prove_state;
@@ -547,7 +557,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ZK_HIP(hipEventRecord(S.done_evt, fin));
     S.busy = true;
     ctx->cur_slot = -1;
-    ps.next = (ticket + 1) % ProveState::SLOTS;
+    pick_next_slot(ps);
     return ticket;
 }
 
@@ -619,7 +629,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     ZK_HIP(hipEventRecord(S.done_evt, fin));
     S.busy = true;
     ctx->cur_slot = -1;
-    ps.next = (ticket + 1) % ProveState::SLOTS;
+    pick_next_slot(ps);
     return ticket;
 }
 
@@ -765,7 +775,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     S.batch = count;
     S.busy = true;
     ctx->cur_slot = -1;
-    ps.next = (ticket + 1) % ProveState::SLOTS;
+    pick_next_slot(ps);
     return ticket;
 }
 
@@ -777,6 +787,7 @@ void prove_batch_wait(zk_ctx* ctx, int ticket, int count, uint8_t* proofs_out) {
     S.busy = false;
     S.batch = 0;
     ZK_HIP(hipEventSynchronize(S.done_evt));
+    pick_next_slot(ps);
     ctx->resolve_profile(ticket);
     ZK_REQUIRE(!*S.h_flag, ZK_ERR_RANGE, "prove: witness element >= r");
     std::memcpy(proofs_out, S.h_b_proofs, (size_t)count * ZK_PROOF_BYTES);
@@ -790,6 +801,7 @@ void prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
     ZK_REQUIRE(S.batch == 0, ZK_ERR_ARG, "prove_wait: batch ticket (use zk_prove_batch_wait)");
     S.busy = false;
     ZK_HIP(hipEventSynchronize(S.done_evt));
+    pick_next_slot(ps);
     ctx->resolve_profile(ticket);
     ZK_REQUIRE(!*S.h_flag, ZK_ERR_RANGE, "prove: witness element >= r");
     if (!S.partial && proof_out) std::memcpy(proof_out, S.h_proof, ZK_PROOF_BYTES);
