@@ -141,6 +141,22 @@ VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
 ACC_INSTR = {"msm_accumulate_g1": (2242.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
 
 
+def msm_window(count, opt=0, g2=False):
+    """The window size the library uses for a product of `count` points -- a mirror of msm_auto_window (csrc/msm_impl.hpp) and of the
+    msm_window_bits option's encoding (csrc/crs.hip: c | 100 big + small | + 10000 g2), so that the bench line can count additions."""
+    if g2 and opt // 10000 > 0:
+        return opt // 10000
+    o = opt % 10000
+    if 0 < o < 100:
+        return o
+    if o >= 100:
+        return o // 100 if count >= (1 << 21) - 8 else o % 100
+    if count + 8 >= (1 << 21):
+        return 20
+    lg = max(count, 1).bit_length() - 1
+    return 17 if lg >= 17 else 16 if lg >= 16 else 15 if lg >= 14 else 13 if lg >= 11 else 8
+
+
 def pmc_traffic(name, log_n=20):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this round's build (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this same command, tools/pmc_summary.py -> profiles/r2_pmc_traffic.json; FETCH_SIZE corrected
@@ -404,8 +420,12 @@ def main():
     # warm-up fails on any rank (a collective RCCL refuses), every rank falls back to independent provers and the
     # line says so ("degraded") instead of the job producing no number at all.
     err = None
+    # Before the W warm-up steps: PRIME untimed steps of one-off setup -- the window tables are built by the first proof, and every
+    # proof slot / exchange buffer set the steady state uses is allocated the first time it is touched (three rounds are in flight in
+    # the exchange pipeline, so W = 2 alone would leave first-use allocations inside the timed region at N > 1).
+    PRIME = 4
     try:
-        for p in run(args.warmup):
+        for p in run(args.warmup + PRIME):
             proof = p
     except Exception as e:   # noqa: BLE001 -- reported in the JSON line
         if world == 1:
@@ -428,7 +448,7 @@ def main():
                     ctx.prove_wait(t, partial=True)
                 except zk.ZkError:
                     pass
-            for p in run(args.warmup):
+            for p in run(args.warmup + PRIME):
                 proof = p
     ctx.set_option("profile", 0 if args.latency else 1)
     ctx.profile_reset()
@@ -514,8 +534,12 @@ def main():
             bytes_per_launch = e["algo_bytes"] / e["launches"]          # 96 B (G1) / 160 B (G2) per (scalar, point) pair
             pairs = bytes_per_launch / (160.0 if g2 else 96.0)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            c_used = args.window_bits or 17
-            windows = 254 // c_used + 1
+            # additions per launch = pairs x windows, windows averaged over the launches of this kernel in a proof (their point counts
+            # differ: L has m - l - 1 points, A n, H + r B1 + s A 2n; the window follows the count; at N > 1 a rank holds 1 / N of each)
+            div = world if (world > 1 and not shard) else 1
+            counts = [n] if g2 else [inst["m"] - inst["l"] - 1, n, 2 * n - (0 if args.roots == "unity" else 1)]
+            wins = [254 // msm_window(max(cnt // div, 1), args.window_bits, g2) + 1 for cnt in counts]
+            windows = sum(cnt * w_ for cnt, w_ in zip(counts, wins)) / float(sum(counts))
             gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
             traffic = pmc_traffic(name, args.log_n) if (args.log_n in PMC_FILES and world == 1 and not args.window_bits and args.batch <= 1
                                                        and args.roots == "unity") else None
@@ -538,7 +562,7 @@ def main():
                 # the bound that binds: wave-instructions issued per second against the issue ceiling of the instruction mix
                 "valu": {"achieved": round(g_inst, 1), "unit": "G wave-instr/s", "peak": round(peak_mix, 1), "frac": round(g_inst / peak_mix, 3),
                          "peak_measured_ubench": round(meas_mix, 1), "frac_of_measured_peak": round(g_inst / meas_mix, 3),
-                         "additions_per_launch": round(adds), "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
+                         "additions_per_launch": round(adds), "windows_per_product": wins, "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
                          "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
                          "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
                                  "tools/ubench_valu.hip sustains (585 / 1062 G/s).  Under this kernel the chip clocks at ~1.93 GHz "
@@ -564,7 +588,7 @@ def main():
                                                 "sums live in registers / HBM images, not LDS (2^16 XYZZ buckets = 9.4 MB against 160 KB); balanced lanes "
                                                 "instead of one wavefront per window (DESIGN 4c).  NTT tiles exchange through LDS, not wave shuffles (a 254-bit "
                                                 "element is 9 dwords).  N > 1 default = scalar exchange by point ranges; the window-sharded form is --mode shard",
-                       "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
+                       "setup_steps_before_warmup": PRIME, "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
             "roofline": roofline,
             **({"replicas": replicas} if replicas else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),
