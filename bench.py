@@ -138,7 +138,9 @@ VALU_PEAK_G = {"slow": 1024 * 2.4 / 4.0, "fast": 1024 * 2.4 / 2.0}
 VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
 # wave-instructions per lane-addition (SQ_INSTS_VALU / additions, profiles/r2_pmc_acc.txt) and the share in the 4-cycle class
 # (per mixed addition: 1467 multiply-adds + ~400 64-bit adds / shifts / mul_lo of the column bookkeeping; tools/instr_mix.py lists the loop)
-ACC_INSTR = {"msm_accumulate_g1": (2242.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
+# G1: 2243 per addition at c = 17 (the n-point product), 2293 at c = 20 (more bucket boundaries per lane: the two 2n-point products);
+# the figure below is their mean weighted by additions at 2^20 gates
+ACC_INSTR = {"msm_accumulate_g1": (2282.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
 
 
 def msm_window(count, opt=0, g2=False):
