@@ -60,6 +60,7 @@ extern "C" {
     fn zk_crs_upload(ctx: *mut ZkCtx, desc: *const ZkCrsDesc, out: *mut *mut ZkCrs) -> c_int;
     fn zk_crs_download(ctx: *mut ZkCtx, crs: *const ZkCrs, out: *const ZkCrsOut) -> c_int;
     fn zk_crs_free(c: *mut ZkCrs);
+    fn zk_qap_upload_sparse_integers(ctx: *mut ZkCtx, desc: *const ZkQapSparseDesc, n: usize, out: *mut *mut ZkQap) -> c_int;
     fn zk_setup(ctx: *mut ZkCtx, qap: *const ZkQap, trapdoor: *const u64, out: *mut *mut ZkCrs) -> c_int;
     fn zk_prove(ctx: *mut ZkCtx, crs: *const ZkCrs, qap: *const ZkQap, weights: *const u64, m: usize,
                 r: *const u64, s: *const u64, proof_out: *mut u8) -> c_int;
@@ -414,6 +415,30 @@ impl GpuProver {
             p = p * w;
         }
         assert_eq!(index.len(), n, "the number of gates must be 2^log_n");
+        Self::from_rows(rr, &index, n, Some(log_n))
+    }
+
+    /// The circuits the reference itself produces: a RootRepresentation over the roots 1, 2, .., n (ASTParser, circuit/mod.rs:517),
+    /// any n up to 2^23, with the reference's proof bytes (zk_qap_upload_sparse_integers: nothing is interpolated).  Builder
+    /// circuits (CircuitInstance, keccak) arrive here too once `From<&CircuitInstance> for DummyRep` stops pre-filling u, v, w with
+    /// num_wires empty rows before pushing the real ones (circuit/mod.rs:163-165 then :186-188 -- SURVEY F8: as shipped, the
+    /// first num_wires polynomials are zero and every proof verifies vacuously; `Vec::with_capacity` is the fix) and is
+    /// instantiated with sub_circuit_point = |id| FrLocal::from(id + 1).
+    pub fn from_root_rep_integers<R: RootRepresentation<FrLocal>>(rr: &R) -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {
+        let mut index: HashMap<[u64; 4], u32> = HashMap::new();
+        let mut k = FrLocal::from(1usize);
+        let mut n = 0usize;
+        for root in rr.roots() {
+            assert!(root == k, "zk_qap_upload_sparse_integers needs the roots 1, 2, 3, ...");
+            index.insert(fr_to_words(&root), n as u32);
+            k = k + FrLocal::from(1usize);
+            n += 1;
+        }
+        Self::from_rows(rr, &index, n, None)
+    }
+
+    fn from_rows<R: RootRepresentation<FrLocal>>(rr: &R, index: &HashMap<[u64; 4], u32>, n: usize, log_n: Option<u32>)
+        -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {
         struct Rows { ptr: Vec<u64>, gate: Vec<u32>, val: Vec<u64> }
         let collect = |rows: R::Row| -> Rows {
             let mut r = Rows { ptr: vec![0], gate: Vec::new(), val: Vec::new() };
@@ -430,12 +455,15 @@ impl GpuProver {
         let m = u.ptr.len() - 1;
         assert!(v.ptr.len() - 1 == m && wr.ptr.len() - 1 == m);      // fr.rs:157-158
         let raw = |r: &Rows| ZkSparseRows { ptr: r.ptr.as_ptr(), gate: r.gate.as_ptr(), val: r.val.as_ptr() };
-        let desc = ZkQapSparseDesc { log_n: log_n as c_uint, m, input: rr.input(), u: raw(&u), v: raw(&v), w: raw(&wr) };
+        let desc = ZkQapSparseDesc { log_n: log_n.unwrap_or(0) as c_uint, m, input: rr.input(), u: raw(&u), v: raw(&v), w: raw(&wr) };
         let ctx = Ctx::new();
         let (mut q, mut crs) = (std::ptr::null_mut(), std::ptr::null_mut());
         let td: Vec<u64> = (0..5).flat_map(|_| fr_to_words(&FrLocal::random_elem()).to_vec()).collect();   // alpha, beta, gamma, delta, x (mod.rs:139-145)
         unsafe {
-            check(ctx.0, zk_qap_upload_sparse(ctx.0, &desc, &mut q));
+            match log_n {
+                Some(_) => check(ctx.0, zk_qap_upload_sparse(ctx.0, &desc, &mut q)),
+                None => check(ctx.0, zk_qap_upload_sparse_integers(ctx.0, &desc, n, &mut q)),
+            }
             check(ctx.0, zk_setup(ctx.0, q, td.as_ptr(), &mut crs));
         }
         let sigma = download_crs(&ctx, crs, n, m, rr.input());

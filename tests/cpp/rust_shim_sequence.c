@@ -4,7 +4,7 @@
  * this program makes the same calls in the same order with the same argument conventions -- upload_dense, setup (zk_setup +
  * zk_crs_download), GpuProver::new (zk_qap_upload_dense + zk_crs_upload), prove_with_rs (zk_prove), verify (zk_crs_upload +
  * zk_verify), prove_stream (zk_host_alloc + zk_prove_submit_host / zk_prove_wait, two in flight), from_root_rep
- * (zk_qap_upload_sparse + zk_setup), MultiGpuProver (zk_comm_init + zk_mgpu_create / zk_mgpu_push_host / zk_mgpu_pop) -- and restates the shim's byte conversions in C (module bn_bytes: 32-byte big-endian <->
+ * (zk_qap_upload_sparse + zk_setup), from_root_rep_integers (zk_qap_upload_sparse_integers + zk_setup), MultiGpuProver (zk_comm_init + zk_mgpu_create / zk_mgpu_push_host / zk_mgpu_pop) -- and restates the shim's byte conversions in C (module bn_bytes: 32-byte big-endian <->
  * four little-endian words; bn's Fq2 packing, the 512-bit integer c1 * q + c0, by the same shift-subtract long division),
  * checked against values the Python twin computes (argv) and by round trips through the proof bytes.
  *
@@ -172,6 +172,28 @@ int main(int argc, char** argv) {
     g2_block_round_trip(proof + 65, proof2 + 65);
     CHECK(memcmp(proof, proof2, ZK_PROOF_BYTES) == 0);
     printf("ok prove\n");
+
+    /* ---- GpuProver::from_root_rep_integers: the parser's root representation as it is (roots 1..n), zk_circuit_rows ->
+     *      zk_qap_upload_sparse_integers + zk_setup with the same trapdoor: the same 259 bytes as the dense path above ---- */
+    {
+        size_t nnz[3];
+        uint64_t* ptr[3]; uint32_t* gate[3]; uint64_t* val[3];
+        for (int k = 0; k < 3; ++k) {
+            ZK(zk_circuit_rows(circ, k, NULL, NULL, NULL, &nnz[k]));
+            ptr[k] = calloc(m + 1, 8); gate[k] = calloc(nnz[k] + 1, 4); val[k] = calloc(4 * nnz[k] + 4, 8);
+            ZK(zk_circuit_rows(circ, k, ptr[k], gate[k], val[k], &nnz[k]));
+        }
+        zk_qap_sparse_desc sd1 = {0, m, l, {ptr[0], gate[0], val[0]}, {ptr[1], gate[1], val[1]}, {ptr[2], gate[2], val[2]}};
+        zk_qap* qs = NULL; zk_crs* cs = NULL;
+        ZK(zk_qap_upload_sparse_integers(ctx, &sd1, n, &qs));
+        ZK(zk_setup(ctx, qs, td, &cs));
+        uint8_t ps[ZK_PROOF_BYTES];
+        ZK(zk_prove(ctx, cs, qs, weights, m, r, s, ps));
+        CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
+        zk_crs_free(cs); zk_qap_free(qs);
+        for (int k = 0; k < 3; ++k) { free(ptr[k]); free(gate[k]); free(val[k]); }
+        printf("ok from_root_rep_integers\n");
+    }
 
     /* ---- gpu::verify: zk_crs_upload of the host CRS, zk_verify (lib.rs:156-190: (2, 34) accepted, (2, 25) rejected) ---- */
     zk_crs* crs_v = NULL;
