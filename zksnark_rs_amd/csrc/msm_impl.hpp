@@ -480,6 +480,19 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     typename AccOf<F>::type acc;
     acc_clear(acc);
     bool is_first = true;
+#ifdef ZK_G2_PARK_LDS
+    // experiment: over Fq2, ZZ and ZZZ of the running accumulator live in LDS (limb-major: conflict-free), see madd_xyzz_parked
+    constexpr bool PARK = sizeof(F) > sizeof(Fq);
+    __shared__ int32_t park_lds[PARK ? 2 * 18 * 256 : 1];
+    volatile int32_t* const my_park = park_lds + (PARK ? threadIdx.x : 0);
+    auto park_out = [&](typename AccOf<F>::type& a) {   // registers <- LDS before an image is written / the slow path runs
+        if (PARK) {   // both coordinates are (re)defined here on every path, so that nothing of them stays live across the loop
+            const L z = L::load(L::Elem::zero());
+            a.ZZ = a.inf ? z : park_get<L>(my_park, 0, 256);
+            a.ZZZ = a.inf ? z : park_get<L>(my_park, 1, 256);
+        }
+    };
+#endif
     // software pipeline: the next point's gather (a random line of a multi-GiB table) is in flight
     // while the current addition executes
     uint32_t k = k0;
@@ -492,6 +505,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
 #pragma unroll ACC_UNROLL
     while (k < k1) {
         if (k == bend) {   // bucket boundary: park the finished image
+#ifdef ZK_G2_PARK_LDS
+            park_out(acc);
+#endif
             if (is_first) first[tid].a = acc; else mid[b].a = acc;
             is_first = false;
             acc_clear(acc);
@@ -503,6 +519,15 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         if (!p.is_inf()) {
             L qx = L::load(p.x), qy = L::load(p.y);
             if (e & 1) qy = qy.neg();
+#ifdef ZK_G2_PARK_LDS
+            if (PARK) {
+                if (!madd_xyzz_parked(acc.X, acc.Y, acc.inf, my_park, 256, qx, qy)) {
+                    park_out(acc);
+                    acc_load(acc, jac_dbl(acc_store(acc)));
+                    park_put(my_park, 0, 256, acc.ZZ); park_put(my_park, 1, 256, acc.ZZZ);
+                }
+            } else
+#endif
             if (!acc_madd(acc, qx, qy)) {
                 // same point twice in one bucket: doubling through the generic formulas (rare)
                 acc_load(acc, jac_dbl(acc_store(acc)));
@@ -513,6 +538,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         e_next = e_next2;
         k = kn;
     }
+#ifdef ZK_G2_PARK_LDS
+    park_out(acc);
+#endif
     if (is_first) first[tid].a = acc; else last[tid].a = acc;
 }
 
