@@ -107,6 +107,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
     if (!std::strcmp(key, "g2_sort_main")) return &ctx->opt_g2_sort_main;
     if (!std::strcmp(key, "rank_tables")) return &ctx->opt_rank_tables;
+    if (!std::strcmp(key, "split_assembly")) return &ctx->opt_split_assembly;
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
     return nullptr;

@@ -102,6 +102,7 @@ struct zk_ctx {
     long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take fewer entries per lane and are not chained (msm_impl.hpp)
     long opt_g2_sort_main = 0;    // 1: at 2^18 gates and more the G2 product's counting sort runs on the main stream (measured: gaps between accumulations 0.85 -> 0.29 ms per proof, accumulations 10.75 -> 11.23 ms: same period, so off)
     long opt_rank_tables = 1;     // multi-GPU scalar exchange: window tables of this rank's point ranges only (prove_msm_submit)
+    long opt_split_assembly = 0;  // 1: A and B of a proof are closed on their products' own streams (measured: the G2 chain ends last, so B's inversion stays on the critical path and C then follows it: +0.1 ms per lone proof at 2^4 .. 2^16 -- off)
     long opt_tail_streams = 0;    // reduction tails of the inner products on two streams of their own (measured: -27 %, kept as an experiment switch)
     long opt_alt_g2 = 0;          // the G2 inner product of odd-numbered proof slots runs on the spare MSM stream
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail

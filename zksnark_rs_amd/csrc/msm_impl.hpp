@@ -662,7 +662,12 @@ __global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict
     for (int k = blockIdx.x * 256 + threadIdx.x; k < count; k += 256 * gridDim.x) acc = add_lazy(acc, jacr_load(in[k]));
     sh[threadIdx.x] = jacr_store(acc);
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
+    // lanes at and behind `share` hold infinity: the tree starts at the first level that has something to add (a small product has
+    // a few dozen terms, and every level is a full Jacobian addition on the critical path of a lone proof)
+    const int share = min(max(count - (int)blockIdx.x * 256, 1), 256);
+    int d0 = 128;
+    while (d0 >= 2 && d0 >= share) d0 >>= 1;
+    for (int d = d0; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) sh[threadIdx.x] = jacr_store(add_lazy(jacr_load(sh[threadIdx.x]), jacr_load(sh[threadIdx.x + d])));
         __syncthreads();
     }
