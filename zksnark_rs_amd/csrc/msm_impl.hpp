@@ -719,8 +719,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
     if (fill && entries / per_lane < fill) per_lane = (uint32_t)std::max<size_t>(4, std::min<size_t>(per_lane, entries / fill) & ~(size_t)3);
     const size_t lanes = (entries + per_lane - 1) / per_lane;
-    // such an accumulation does not fill the chip either, so it is not chained behind the previous one
-    if (fill && lanes < fill) acc_wait = nullptr;
+    // an accumulation that does not fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
+    if (lanes < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
     const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
     const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
