@@ -64,3 +64,17 @@ def test_product_does_not_reference_oracle():
                     text = open(os.path.join(dp, f), errors="ignore").read()
                     for b in banned:
                         assert b not in text, (os.path.join(dp, f), b)
+
+
+def test_bench_mirrors_the_window_rule():
+    """bench.py counts additions with its own copy of the window rule (msm_window); it must be the library's (host code, no GPU)"""
+    import importlib.util
+    from zksnark_rs_amd import _lib
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib = _lib.load()
+    for count in [1, 2, 15, 16, 100, 2047, 2048, 16383, 16384, 65535, 65536, 131071, 131072, 1 << 20, (1 << 21) - 9, (1 << 21) - 8, (1 << 21) - 1,
+                  1 << 21, 1 << 22, 1 << 24]:
+        assert bench.msm_window(count) == lib.zk_msm_auto_window(count), count
+    assert bench.msm_window(1 << 21, 2017) == 20 and bench.msm_window(1 << 20, 2017) == 17 and bench.msm_window(1 << 20, 172018, True) == 17

@@ -173,6 +173,8 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
     *out = nullptr;
     return guarded(ctx, [&] { *out = qap_upload_sparse(ctx, *desc); });
 }
+/* the window size msm tables of `count` points are built with when the option msm_window_bits is 0 (host code) */
+int zk_msm_auto_window(size_t count) { return msm_auto_window(count); }
 int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out) {
     if (!ctx || !desc || !out) return ZK_ERR_ARG;
     *out = nullptr;
