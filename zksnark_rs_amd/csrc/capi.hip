@@ -106,6 +106,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "defer_msm")) return &ctx->opt_defer_msm;
     if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
     if (!std::strcmp(key, "msm_unchain_lanes")) return &ctx->opt_unchain_lanes;
+    if (!std::strcmp(key, "msm_sort_bins_log")) return &ctx->opt_sort_bins_log;
     if (!std::strcmp(key, "g2_sort_main")) return &ctx->opt_g2_sort_main;
     if (!std::strcmp(key, "rank_tables")) return &ctx->opt_rank_tables;
     if (!std::strcmp(key, "split_assembly")) return &ctx->opt_split_assembly;

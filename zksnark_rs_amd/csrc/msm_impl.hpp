@@ -701,7 +701,9 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     }
     // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
     // 2^8 bins (more only to keep the sub-bucket level at 2^11 counters at most)
-    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = (1 << (c - 1 - sub_bits)) * groups;
+    // level-1 bins: 2^8 up to c = 17 (more only to keep the sub-bucket level at 2^11 counters at most); option msm_sort_bins_log
+    const int bins_log = (int)std::max<long>(4, std::min<long>(ctx->opt_sort_bins_log > 0 ? ctx->opt_sort_bins_log : 8, 12));
+    const int sub_bits = std::min(11, std::max(0, c - 1 - bins_log)), bins = (1 << (c - 1 - sub_bits)) * groups;
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
