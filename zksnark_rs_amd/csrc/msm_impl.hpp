@@ -370,7 +370,10 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
 // level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
 // them by sub-bucket inside LDS and stores runs of consecutive 4-byte entries
 constexpr int BINS_THREADS = 512;
-constexpr int BIN_STAGE = 8192;
+#ifndef ZK_BIN_STAGE
+#define ZK_BIN_STAGE 8192
+#endif
+constexpr int BIN_STAGE = ZK_BIN_STAGE;
 constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
 __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
                                                                   const uint32_t* __restrict__ part_start, int bins, int sub_bits,
@@ -429,7 +432,10 @@ __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
 constexpr int BINS_THREADS = 512;
-constexpr int BIN_STAGE = 8192;
+#ifndef ZK_BIN_STAGE
+#define ZK_BIN_STAGE 8192
+#endif
+constexpr int BIN_STAGE = ZK_BIN_STAGE;
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
