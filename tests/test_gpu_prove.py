@@ -152,6 +152,26 @@ def test_prove_full_size_2_20(ctx, orc):
     assert got == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
 
 
+def test_prove_full_size_2_20_skewed_witnesses(ctx, orc):
+    """the same size with witnesses that put most digits of the L product into a handful of buckets (inputs in {0, 1}: half of all
+    wires are bits; 32-bit inputs: the upper windows of half the scalars are empty) -- the heavy-bucket merge and the c = 20 tables of
+    the 2^21-point products on skewed data -- and an all-ones witness (every digit of every scalar the same)"""
+    log_n, n = 20, 1 << 20
+    rng = SplitMix64(2021)
+    m, l, u, v, w = chain_rows(log_n)
+    desc = ctx.sparse_desc(log_n, m, l, u, v, w)
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    for kind in ("boolean", "small"):
+        avals = [rng.next() & 1 for _ in range(n)] if kind == "boolean" else [rng.next() & 0xFFFFFFFF for _ in range(n)]
+        weights = chain_weights(log_n, rng.fr(), avals)
+        assert ctx.prove(crs, qap, weights, r, s) == orc.trapdoor_proof_sparse(desc, td, weights, r, s), kind
+    ones = np.zeros((m, 4), np.uint64); ones[:, 0] = 1          # not a satisfying witness: the closed form covers that too
+    assert ctx.prove(crs, qap, ones, r, s) == orc.trapdoor_proof_sparse(desc, td, ones, r, s)
+
+
 def test_prove_2_22_gates_both_domains_and_size_limit(ctx, orc):
     """Beyond the two-pass NTT (NTT_MAX_LOG = 24: sizes 2^23 and 2^24 take a third pass): 2^22 constraints, 8.4 M wires.  Over the
     roots of unity the transforms are of size 2^22 (two passes); the same rows over the integer roots 1..n convolve at size 2^23
