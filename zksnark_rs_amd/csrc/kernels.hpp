@@ -66,6 +66,7 @@ struct MsmWorkspace {
     hipStream_t tail_stream = nullptr;   // where the reduction tail runs (null: on the product's own stream)
     hipStream_t acc_stream = nullptr;    // where the bucket accumulation runs (null: on the product's own stream)
     hipStream_t sort_stream = nullptr;   // where the counting sort runs (null: on the product's own stream)
+    uint64_t sorted_for = 0;             // (entries, buckets) signature of the sorted list held (option ablate)
     hipEvent_t sorted_evt = nullptr;     // sort -> accumulation hand-over when acc_stream is set (owned; lives as long as the context)
 };
 int msm_auto_window(size_t n);

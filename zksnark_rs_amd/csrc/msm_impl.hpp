@@ -425,6 +425,32 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
     }
 }
 
+// level-2 scatter without the LDS stage, for many sub-buckets per bin (c = 20: 2^11): a stage of 8192 records then holds ~4 per
+// sub-bucket, the staged form stores runs of 16 bytes and pays a 2048-counter scan per stage.  Here every record goes straight to
+// the next free position of its sub-bucket (LDS counters seeded with this part's offsets): one 4-byte store per record into the
+// bin's output region, which the parts of a bin fill together while it is cache resident.
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter_direct(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                         const uint32_t* __restrict__ part_start, int bins, int sub_bits,
+                                                                         const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+    ZK_LATENCY_KERNEL();
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* pos = reinterpret_cast<uint32_t*>(smem);
+    const int subs = 1 << sub_bits;
+    uint32_t lo, hi;
+    if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
+    const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
+    for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] = row[b];
+    __syncthreads();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * BINS_THREADS) {
+        uint64_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = k + j * BINS_THREADS < hi ? records[k + j * BINS_THREADS] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j * BINS_THREADS < hi) sorted[lds_inc(pos, (uint32_t)(r[j] >> 32))] = (uint32_t)r[j];
+    }
+}
+
 #else
 __global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, uint32_t*);
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
@@ -440,6 +466,7 @@ __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_scatter_direct(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
 // ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
@@ -762,6 +789,11 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // waiting for the next G2 sort.
     hipStream_t const own_st = st;
     if (ws.sort_stream) st = ws.sort_stream;
+    // measurement aid (option ablate, bit 0): when the caller repeats the same scalars, the sorted list this workspace holds from
+    // the previous call is reused -- prices the whole sort in the pipelined prover.  Never set by the product.
+    const bool reuse_sort = (ctx->opt_ablate & 1) && ws.sorted_for == (uint64_t)entries * 31 + (uint64_t)buckets;
+    ws.sorted_for = (uint64_t)entries * 31 + (uint64_t)buckets;
+    if (!reuse_sort) {
     {
         ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
         hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
@@ -789,8 +821,13 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
         hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
+        if (ctx->opt_direct_subs > 0 && sub_bits >= ctx->opt_direct_subs)
+            hipLaunchKernelGGL(k_msm_bin_scatter_direct, dim3(grid2), dim3(BINS_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
+                               sub_bits, ws.bin_cnt.p, ws.sorted.p);
+        else
         hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                            sub_bits, ws.bin_cnt.p, ws.sorted.p);
+    }
     }
     if (ws.sort_stream) {
         if (!ws.sorted_evt) ZK_HIP(hipEventCreateWithFlags(&ws.sorted_evt, hipEventDisableTiming));
