@@ -60,8 +60,8 @@ struct MsmTable {
     int c = 0, windows = 0;
 };
 struct MsmWorkspace {
-    DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy;
-    DevBuf<uint64_t> records;
+    DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy, bin_start2, part_start2;
+    DevBuf<uint64_t> records, records2;   // records2, bin_start2, part_start2: the middle level of the three-level sort
     DevBuf<uint8_t> partial, bucket_sums, fold, seg_sums;
     hipStream_t tail_stream = nullptr;   // where the reduction tail runs (null: on the product's own stream)
     hipStream_t acc_stream = nullptr;    // where the bucket accumulation runs (null: on the product's own stream)

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restri
 }
 
 __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                const uint32_t* __restrict__ part_start, int bins, int sub_bits, uint32_t* __restrict__ cnt) {
+                                                                const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift, uint32_t* __restrict__ cnt) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int subs = 1 << sub_bits;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* 
         for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k + j * SORT2_THREADS < hi) lds_inc(lds, (uint32_t)(r[j] >> 32));
+            if (k + j * SORT2_THREADS < hi) lds_inc(lds, ((uint32_t)(r[j] >> 32) >> shift) & (uint32_t)(subs - 1));
     }
     __syncthreads();
     uint32_t* row = cnt + (size_t)blockIdx.x * subs;
@@ -375,18 +375,22 @@ constexpr int BINS_THREADS = 512;
 #endif
 constexpr int BIN_STAGE = ZK_BIN_STAGE;
 constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                  const uint32_t* __restrict__ part_start, int bins, int sub_bits,
-                                                                  const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
-    ZK_LATENCY_KERNEL();
+// REC: the output is again a list of 8-byte records (an intermediate level: sub-bucket field bits [shift, shift + sub_bits)),
+// otherwise the final 4-byte entries
+template <bool REC>
+__device__ __forceinline__ void bin_scatter_body(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                 const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
+                                                 const uint32_t* __restrict__ pos_in, void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t scratch[BINS_THREADS];
+    typedef typename std::conditional<REC, uint64_t, uint32_t>::type Ent;
     const int subs = 1 << sub_bits;
-    uint32_t* stage = reinterpret_cast<uint32_t*>(smem);
-    uint16_t* ssub = reinterpret_cast<uint16_t*>(smem + (size_t)BIN_STAGE * 4);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)BIN_STAGE * 6);
+    Ent* stage = reinterpret_cast<Ent*>(smem);
+    uint16_t* ssub = reinterpret_cast<uint16_t*>(smem + (size_t)BIN_STAGE * sizeof(Ent));
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)BIN_STAGE * (sizeof(Ent) + 2));
     uint32_t* lstart = cnt + subs;
     uint32_t* pos = lstart + subs;     // running write position per sub-bucket for this (bin, part)
+    Ent* dst = reinterpret_cast<Ent*>(out);
     uint32_t lo, hi;
     if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
     const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
@@ -394,13 +398,14 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
     for (uint32_t base = lo; base < hi; base += BIN_STAGE) {
         for (int b = threadIdx.x; b < subs; b += BINS_THREADS) cnt[b] = 0;
         __syncthreads();
-        uint32_t ent[BIN_PER_LANE], sub[BIN_PER_LANE], rank[BIN_PER_LANE];
+        Ent ent[BIN_PER_LANE];
+        uint32_t sub[BIN_PER_LANE], rank[BIN_PER_LANE];
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j) {
             const uint32_t k = base + j * BINS_THREADS + threadIdx.x;
             const uint64_t r = k < hi ? records[k] : 0;
-            ent[j] = (uint32_t)r;
-            sub[j] = (uint32_t)(r >> 32);
+            ent[j] = (Ent)r;
+            sub[j] = ((uint32_t)(r >> 32) >> shift) & (uint32_t)(subs - 1);
         }
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j)
@@ -417,12 +422,25 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < total; p += BINS_THREADS) {
             const uint32_t sb = ssub[p];
-            sorted[pos[sb] + (p - lstart[sb])] = stage[p];
+            dst[pos[sb] + (p - lstart[sb])] = stage[p];
         }
         __syncthreads();
         for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] += cnt[b];
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                  const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
+                                                                  const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+    ZK_LATENCY_KERNEL();
+    bin_scatter_body<false>(records, bin_start, part_start, bins, sub_bits, shift, pos_in, sorted);
+}
+// an intermediate level of the sort (three levels for the 2^10 and more sub-buckets per bin of c >= 19)
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter_rec(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                      const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
+                                                                      const uint32_t* __restrict__ pos_in, uint64_t* __restrict__ records_out) {
+    ZK_LATENCY_KERNEL();
+    bin_scatter_body<true>(records, bin_start, part_start, bins, sub_bits, shift, pos_in, records_out);
 }
 
 // level-2 scatter without the LDS stage, for many sub-buckets per bin (c = 20: 2^11): a stage of 8192 records then holds ~4 per
@@ -463,9 +481,10 @@ constexpr int BINS_THREADS = 512;
 #endif
 constexpr int BIN_STAGE = ZK_BIN_STAGE;
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
-__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
-__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_scatter_rec(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_scatter_direct(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
@@ -818,15 +837,41 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         const unsigned grid2 = (unsigned)(entries / target + 1) + (unsigned)bins;   // >= sum_b max(1, ceil(len_b / target))
         ws.bin_cnt.ensure((size_t)grid2 * subs);
         ws.part_start.ensure((size_t)bins + 1);
+        const int three = (ctx->opt_three_level_bits > 0 && sub_bits >= ctx->opt_three_level_bits) ? 1 : 0;
+        if (three) {
+            // Three levels: with 2^10 and more sub-buckets per bin a stage of 8192 records leaves runs of 4..8 entries per sub-bucket
+            // (16..32-byte stores) and a 2048-counter scan per stage.  The sub-bucket field is split: its high half sorts the bin's
+            // records into 2^hi groups (8-byte records again, runs of ~256), its low half then sorts every (bin, group) -- ~3 k
+            // records, one stage -- into the final 4-byte entries (runs of ~50).  Both passes keep the records' order, as the
+            // accumulation wants it.
+            const int hi_bits = sub_bits / 2, lo_bits = sub_bits - hi_bits, subs_a = 1 << hi_bits, subs_b = 1 << lo_bits;
+            const int bins2 = bins * subs_a;
+            const unsigned grid2b = (unsigned)(entries / target + 1) + (unsigned)bins2;
+            ws.bin_cnt.ensure(std::max((size_t)grid2 * subs_a, (size_t)grid2b * subs_b));
+            ws.records2.ensure(entries);
+            ws.bin_start2.ensure((size_t)bins2 + 1);
+            ws.part_start2.ensure((size_t)bins2 + 1);
+            hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
+            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs_a * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, hi_bits, lo_bits, ws.bin_cnt.p);
+            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, hi_bits, ws.bin_start2.p);
+            hipLaunchKernelGGL(k_msm_bin_scatter_rec, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 10 + (size_t)subs_a * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p,
+                               bins, hi_bits, lo_bits, ws.bin_cnt.p, ws.records2.p);
+            hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start2.p, bins2, target, ws.part_start2.p);
+            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2b), dim3(SORT2_THREADS), (size_t)subs_b * 4, st, ws.records2.p, ws.bin_start2.p, ws.part_start2.p, bins2, lo_bits, 0, ws.bin_cnt.p);
+            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins2), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start2.p, ws.part_start2.p, bins2, lo_bits, ws.start.p);
+            hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2b), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs_b * 12, st, ws.records2.p, ws.bin_start2.p, ws.part_start2.p,
+                               bins2, lo_bits, 0, ws.bin_cnt.p, ws.sorted.p);
+        } else {
         hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
-        hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
+        hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, 0, ws.bin_cnt.p);
         hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
         if (ctx->opt_direct_subs > 0 && sub_bits >= ctx->opt_direct_subs)
             hipLaunchKernelGGL(k_msm_bin_scatter_direct, dim3(grid2), dim3(BINS_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                                sub_bits, ws.bin_cnt.p, ws.sorted.p);
         else
         hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
-                           sub_bits, ws.bin_cnt.p, ws.sorted.p);
+                           sub_bits, 0, ws.bin_cnt.p, ws.sorted.p);
+        }
     }
     }
     if (ws.sort_stream) {
@@ -969,6 +1014,7 @@ void msm_init_attributes() {
     static bool done = false;
     if (done) return;
     ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE * 6 + 2048 * 12));
+    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bin_scatter_rec, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE * 10 + 2048 * 12));
     done = true;
 }
 #endif  // ZK_MSM_COMMON
