@@ -844,7 +844,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             // records into 2^hi groups (8-byte records again, runs of ~256), its low half then sorts every (bin, group) -- ~3 k
             // records, one stage -- into the final 4-byte entries (runs of ~50).  Both passes keep the records' order, as the
             // accumulation wants it.
-            const int hi_bits = sub_bits / 2, lo_bits = sub_bits - hi_bits, subs_a = 1 << hi_bits, subs_b = 1 << lo_bits;
+            const int lo_want = (int)std::max<long>(1, std::min<long>(ctx->opt_three_level_low, sub_bits - 1));
+            const int lo_bits = lo_want, hi_bits = sub_bits - lo_bits, subs_a = 1 << hi_bits, subs_b = 1 << lo_bits;
             const int bins2 = bins * subs_a;
             const unsigned grid2b = (unsigned)(entries / target + 1) + (unsigned)bins2;
             ws.bin_cnt.ensure(std::max((size_t)grid2 * subs_a, (size_t)grid2b * subs_b));
