@@ -111,6 +111,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_direct_subs")) return &ctx->opt_direct_subs;
     if (!std::strcmp(key, "msm_three_level_bits")) return &ctx->opt_three_level_bits;
     if (!std::strcmp(key, "msm_three_level_low")) return &ctx->opt_three_level_low;
+    if (!std::strcmp(key, "msm_sort_chunks_mult")) return &ctx->opt_sort_chunks_mult;
     if (!std::strcmp(key, "g2_sort_main")) return &ctx->opt_g2_sort_main;
     if (!std::strcmp(key, "rank_tables")) return &ctx->opt_rank_tables;
     if (!std::strcmp(key, "split_assembly")) return &ctx->opt_split_assembly;

@@ -106,6 +106,7 @@ struct zk_ctx {
     long opt_direct_subs = 0;     // >0: level-2 scatter without the LDS stage when a bin has 2^this sub-buckets or more (msm_impl.hpp)
     long opt_three_level_bits = 0;  // >0: bins with 2^this sub-buckets and more are sorted in two passes (three sort levels in all); measured level with two (tools/ab_three.sh): off
     long opt_three_level_low = 6;   // ... of which the last pass sorts this many bits
+    long opt_sort_chunks_mult = 1;  // level-1 sort: chunks (workgroups) per CU
     long opt_g2_sort_main = 0;    // 1: at 2^18 gates and more the G2 product's counting sort runs on the main stream (measured: gaps between accumulations 0.85 -> 0.29 ms per proof, accumulations 10.75 -> 11.23 ms: same period, so off)
     long opt_rank_tables = 1;     // multi-GPU scalar exchange: window tables of this rank's point ranges only (prove_msm_submit)
     long opt_split_assembly = 0;  // 1: A and B of a proof are closed on their products' own streams (measured: the G2 chain ends last, so B's inversion stays on the critical path and C then follows it: +0.1 ms per lone proof at 2^4 .. 2^16 -- off)

@@ -55,7 +55,10 @@ int msm_auto_window(size_t n) {
 }
 #endif  // ZK_MSM_COMMON
 
-constexpr int SORT_THREADS = 1024;
+#ifndef ZK_SORT_THREADS
+#define ZK_SORT_THREADS 1024
+#endif
+constexpr int SORT_THREADS = ZK_SORT_THREADS;
 constexpr int SORT2_THREADS = 256;   // level-2 workgroups (several per bin)
 
 // ---- table precompute: T[w][i] = 2^(c w) P_i ------------------------------------------------
@@ -369,7 +372,10 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
 
 // level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
 // them by sub-bucket inside LDS and stores runs of consecutive 4-byte entries
-constexpr int BINS_THREADS = 512;
+#ifndef ZK_BINS_THREADS
+#define ZK_BINS_THREADS 512
+#endif
+constexpr int BINS_THREADS = ZK_BINS_THREADS;
 #ifndef ZK_BIN_STAGE
 #define ZK_BIN_STAGE 8192
 #endif
@@ -475,7 +481,10 @@ __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
-constexpr int BINS_THREADS = 512;
+#ifndef ZK_BINS_THREADS
+#define ZK_BINS_THREADS 512
+#endif
+constexpr int BINS_THREADS = ZK_BINS_THREADS;
 #ifndef ZK_BIN_STAGE
 #define ZK_BIN_STAGE 8192
 #endif
@@ -756,7 +765,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // level-1 bins: 2^8 up to c = 17 (more only to keep the sub-bucket level at 2^11 counters at most); option msm_sort_bins_log
     const int bins_log = (int)std::max<long>(4, std::min<long>(ctx->opt_sort_bins_log > 0 ? ctx->opt_sort_bins_log : 8, 12));
     const int sub_bits = std::min(11, std::max(0, c - 1 - bins_log)), bins = (1 << (c - 1 - sub_bits)) * groups;
-    int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
+    int chunks = (int)std::min<size_t>((size_t)ctx->cu_count * (size_t)std::max<long>(1, std::min<long>(ctx->opt_sort_chunks_mult, 16)), (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
