@@ -153,7 +153,7 @@ def msm_window(count, opt=0, g2=False):
         return o
     if o >= 100:
         return o // 100 if count >= (1 << 21) - 8 else o % 100
-    if count + 8 >= (1 << 21):
+    if count + 8 >= (1 << 21) or (g2 and count + 8 >= (1 << 20)):
         return 20
     lg = max(count, 1).bit_length() - 1
     return 17 if lg >= 17 else 16 if lg >= 16 else 15 if lg >= 14 else 13 if lg >= 11 else 8
@@ -182,11 +182,6 @@ def main():
                          "proofs); shard = the latency form (one proof at a time, every rank repeats the NTT stage, one all-gather); "
                          "replicas = independent provers")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--lane-entries", type=int, default=0, help="msm_lane_entries tunable (0 = library default)")
-    ap.add_argument("--fold", type=int, default=0, help="msm_fold tunable (0 = library default)")
-    ap.add_argument("--tail-streams", type=int, default=-1, help="msm_tail_streams option (-1 = library default)")
-    ap.add_argument("--alt-g2", type=int, default=-1, help="msm_alt_g2 option (-1 = library default)")
-    ap.add_argument("--acc-stream", type=int, default=-1, help="msm_acc_stream option (-1 = library default)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, 1 GPU only: time rank 0's share of a W-way window-sharded proof (no collective) instead of whole proofs")
     ap.add_argument("--transport", choices=["zk", "zk-gloo", "torch"], default="zk",
@@ -200,7 +195,9 @@ def main():
                     help="what a rank owns of each inner product in --mode shard: Pippenger windows w = rank (mod N), or the "
                          "point range [count rank / N, count (rank+1) / N) with every window (5 %% faster at N = 8: 15 windows "
                          "do not divide by 8, and a rank sorts only its own scalars)")
-    ap.add_argument("--serialize", action="store_true", help="measurement mode: no kernel overlap (stand-alone kernel durations)")
+    ap.add_argument("--serialize", action="store_true",
+                    help="measurement mode: no kernel overlap (stand-alone kernel durations); needs the ZK_MEASURE build of the library "
+                         "(make -C zksnark_rs_amd/csrc measure; ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so)")
     ap.add_argument("--witness", choices=["uniform", "boolean", "small"], default="uniform",
                     help="distribution of the chain circuit's inputs a_k (the metric is quoted on 'uniform')")
     ap.add_argument("--seed", type=int, default=20260929)
@@ -217,7 +214,14 @@ def main():
                     help="QAP domain: unity = w^j (the metric's workload); integers = 1..n, what ASTParser gives the same circuit "
                          "(zk_qap_upload_sparse_integers; N = 1, no batches; secondary measurement, no CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="zk_ctx_set_option(KEY, VALUE) before the run (A/B switches)")
+    ap.add_argument("--kernel-times", action="store_true",
+                    help="event-time every launch group of a proof, not only the bucket accumulations (kernel_ms_per_proof then lists them "
+                         "all; costs ~1 %% of the rate)")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="no per-kernel event timing inside the library during the timed region (two event records per launch): the line then "
+                         "carries no roofline object; `host` reports the time the host spent enqueueing")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="zk_set_option(KEY, VALUE) before the run: measurement switches, refused unless the loaded library is the ZK_MEASURE build")
     ap.add_argument("--latency", action="store_true",
                     help="one proof at a time (--depth 1), no per-kernel event timing (two extra API calls per launch, which small "
                          "circuits feel), no CPU baseline: ms_per_step is the latency of a lone zk_prove_dev call")
@@ -281,22 +285,15 @@ def main():
         return x
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
+    if (args.serialize or args.opt) and ctx.get_option("measure_build") != 1:
+        raise SystemExit("--serialize / --opt are measurement switches: load the ZK_MEASURE build (make -C zksnark_rs_amd/csrc measure; "
+                         "ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so)")
     if args.serialize:
         ctx.set_option("serialize", 1)
     ctx.set_option("msm_shard_points", 1 if args.shard == "points" else 0)
     for kv in args.opt:
         key, val = kv.split("=", 1)
         ctx.set_option(key, int(val))
-    if args.lane_entries:
-        ctx.set_option("msm_lane_entries", args.lane_entries)
-    if args.fold:
-        ctx.set_option("msm_fold", args.fold)
-    if args.tail_streams >= 0:
-        ctx.set_option("msm_tail_streams", args.tail_streams)
-    if args.alt_g2 >= 0:
-        ctx.set_option("msm_alt_g2", args.alt_g2)
-    if args.acc_stream >= 0:
-        ctx.set_option("msm_acc_stream", args.acc_stream)
     inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness, args.roots)
     d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
     m = inst["m"]
@@ -412,7 +409,10 @@ def main():
         for _ in range(k):
             if len(inflight) == depth:
                 out.append(ctx.prove_wait(inflight.pop(0)))
+            t_s = time.perf_counter()
             inflight.append(ctx.prove_submit(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]))
+            state["submit_s"] = state.get("submit_s", 0.0) + time.perf_counter() - t_s
+            state["submits"] = state.get("submits", 0) + 1
         while inflight:
             out.append(ctx.prove_wait(inflight.pop(0)))
         return out
@@ -452,7 +452,8 @@ def main():
                     pass
             for p in run(args.warmup + PRIME):
                 proof = p
-    ctx.set_option("profile", 0 if args.latency else 1)
+    ctx.set_option("profile", 0 if (args.latency or args.no_profile) else 2 if args.kernel_times else 1)
+    state["submit_s"], state["submits"] = 0.0, 0
     ctx.profile_reset()
     degraded_now = state["degraded"] is not None    # a failed communicator is not used again: barrier through the bootstrap store
 
@@ -556,7 +557,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_over_algorithmic": round(traffic / bytes_per_launch, 2) if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch, "pairs_per_launch": round(pairs),
-                "launches": e["launches"], "share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3),
+                "launches": e["launches"],
+                **({"share_of_kernel_time": round(e["total_ms"] / total_kernel_ms, 3)} if args.kernel_times else {}),
                 "implementation_bytes_per_launch": round(gathered),
                 "note": "frac is the HBM fraction SURVEY 8(d) defines (96 B per scalar-point pair in G1, 160 B in G2).  The kernel is not "
                         "HBM-bound: it is bound by VALU issue (`valu` below).  It gathers one table entry per Pippenger window and pair "
@@ -597,6 +599,8 @@ def main():
             **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            **({"host": {"submit_ms_per_proof": round(1e3 * state["submit_s"] / state["submits"], 3),
+                         "note": "wall time of zk_prove_submit on the host (everything of a proof is enqueued inside it)"}} if state.get("submits") else {}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(zk, ctx, args.seed, inst, args.cpu_baseline == "full")

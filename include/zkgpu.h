@@ -85,8 +85,10 @@ int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int cose
  * (groth16/mod.rs:255-272,279-290), i.e. n x exp_encrypted_g1/g2 (fr.rs:114-119) folded with
  * Sum for G1Local/G2Local (fr.rs:191-198,217-223).  window_bits = 0 picks automatically. */
 /* Window size c (bits) the fixed-base tables of a product of `count` points are built with when the option msm_window_bits
- * is 0: the outcome of the sweeps in DESIGN.md 4c (17 from 2^17 points, 20 from 2^21).  Host code, no device needed. */
+ * is 0: the outcome of the sweeps in DESIGN.md 4c (G1: 17 from 2^17 points, 20 from 2^21; the G2 table: 20 from 2^20).  Host code, no
+ * device needed.  (The reference has no such notion: fr.rs:114-119 is one double-and-add per term.) */
 int zk_msm_auto_window(size_t count);
+int zk_msm_auto_window_g2(size_t count);
 int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out_affine[ZK_G1_WORDS]);
 int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out_affine[ZK_G2_WORDS]);
 

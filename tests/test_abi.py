@@ -77,4 +77,5 @@ def test_bench_mirrors_the_window_rule():
     for count in [1, 2, 15, 16, 100, 2047, 2048, 16383, 16384, 65535, 65536, 131071, 131072, 1 << 20, (1 << 21) - 9, (1 << 21) - 8, (1 << 21) - 1,
                   1 << 21, 1 << 22, 1 << 24]:
         assert bench.msm_window(count) == lib.zk_msm_auto_window(count), count
+        assert bench.msm_window(count, 0, True) == lib.zk_msm_auto_window_g2(count), count
     assert bench.msm_window(1 << 21, 2017) == 20 and bench.msm_window(1 << 20, 2017) == 17 and bench.msm_window(1 << 20, 172018, True) == 17

@@ -173,6 +173,10 @@ class Context:
     def set_option(self, key, value):
         self._check(self.lib.zk_set_option(self.ptr, key.encode(), int(value)))
 
+    def get_option(self, key):
+        """Value of an option, -1 for a key this build does not know ("measure_build": 1 in a ZK_MEASURE build of the library)."""
+        return int(self.lib.zk_get_option(self.ptr, key.encode()))
+
     # ---- building blocks ----
     def ntt_fr(self, data, inverse=False, coset=False):
         """field::dft / field::idft (field/mod.rs:508-537) on a (2^k, 4) uint64 array; returns a new array."""

@@ -101,6 +101,7 @@ SIGNATURES = {
     "zk_circuit_weights": (C.c_int, [C.c_void_p, u64p, C.c_size_t, u64p, C.c_size_t]),
     "zk_circuit_last_error": (C.c_char_p, [C.c_void_p]),
     "zk_msm_auto_window": (C.c_int, [C.c_size_t]),
+    "zk_msm_auto_window_g2": (C.c_int, [C.c_size_t]),
     "zk_circuit_qap": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_circuit_qap_sparse": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_crs_upload": (C.c_int, [C.c_void_p, C.POINTER(CrsDesc), C.POINTER(C.c_void_p)]),

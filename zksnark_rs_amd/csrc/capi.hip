@@ -2,6 +2,7 @@
 // Nothing here computes on the CPU: every entry point either launches HIP kernels or fails
 // with a status code (ZK_ERR_NO_DEVICE when no GPU is visible).
 #include <cstring>
+#include <vector>
 #include "kernels.hpp"
 #include "pipeline.hpp"
 
@@ -52,18 +53,16 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out) {
         ZK_HIP(hipStreamCreateWithPriority(&ctx->main_alt, hipStreamNonBlocking, prio_greatest));
         msm_init_attributes();
         // Streams share hardware queues per priority level (4 each by default): a FIFTH stream of a level shares a queue with another
-        // one and serialises with it (measured: reduction tails on two extra low-priority streams -27 %, the G2 product alternating
-        // onto a fifth MSM stream -5 %; at a level of their own: no loss).  Three levels are used:
+        // one and serialises with it (measured: reduction tails on two extra streams -27 %, the G2 product alternating onto a fifth
+        // MSM stream -5 %, every accumulation on one extra stream -- low priority, or masked to all but 8 / 16 / 32 compute units --
+        // -2.5 .. -5 %: DESIGN.md 4c).  Two levels are used:
         //   high  main / alternate main (SpMV + NTT stage), side (r, s multiples), finish (join, assembly, copy-out)
-        //   mid   one stream per inner product: its sort and its reduction tail (+ two optional tail streams)
-        //   low   ONE stream for every bucket accumulation -- the only kernels that fill the chip for milliseconds; at the lowest level
-        //         their thousands of pending workgroups never stand in front of a short dependent kernel in the dispatcher
+        //   mid   one stream per inner product: its sort, its accumulation and its reduction tail
         const int prio_mid = (prio_least + prio_greatest) / 2;
         for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
+            if (i == 3) continue;   // slot 3 (B in G1) was folded into the H product
             ZK_HIP(hipStreamCreateWithPriority(&ctx->msm_stream[i], hipStreamNonBlocking, prio_mid));
         }
-        ZK_HIP(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_least));
-        for (int i = 0; i < 2; ++i) ZK_HIP(hipStreamCreateWithPriority(&ctx->tail_stream[i], hipStreamNonBlocking, prio_mid));
     });
     if (rc != ZK_OK) { zk_ctx_destroy(ctx); return rc; }   // destroys whatever streams were created before the failure
     *out = ctx;
@@ -80,9 +79,6 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     ctx->msm_ws0.reset();
     for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i)
         if (ctx->msm_stream[i]) (void)hipStreamDestroy(ctx->msm_stream[i]);
-    for (int i = 0; i < 2; ++i)
-        if (ctx->tail_stream[i]) (void)hipStreamDestroy(ctx->tail_stream[i]);
-    if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
     if (ctx->finish) (void)hipStreamDestroy(ctx->finish);
     if (ctx->main_alt) (void)hipStreamDestroy(ctx->main_alt);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -97,26 +93,20 @@ const char* zk_last_error(const zk_ctx* ctx) { return ctx ? ctx->last_error.c_st
 static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_window_bits")) return &ctx->opt_window_bits;
     if (!std::strcmp(key, "profile")) return &ctx->opt_profile;
-    if (!std::strcmp(key, "msm_lane_entries")) return &ctx->opt_lane_entries;
-    if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;
-    if (!std::strcmp(key, "msm_fold")) return &ctx->opt_fold;
-    if (!std::strcmp(key, "msm_tail_streams")) return &ctx->opt_tail_streams;
-    if (!std::strcmp(key, "msm_alt_g2")) return &ctx->opt_alt_g2;
-    if (!std::strcmp(key, "msm_acc_stream")) return &ctx->opt_acc_stream;
-    if (!std::strcmp(key, "defer_msm")) return &ctx->opt_defer_msm;
-    if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
-    if (!std::strcmp(key, "msm_unchain_lanes")) return &ctx->opt_unchain_lanes;
-    if (!std::strcmp(key, "msm_sort_bins_log")) return &ctx->opt_sort_bins_log;
-    if (!std::strcmp(key, "ablate")) return &ctx->opt_ablate;
-    if (!std::strcmp(key, "msm_direct_subs")) return &ctx->opt_direct_subs;
-    if (!std::strcmp(key, "msm_three_level_bits")) return &ctx->opt_three_level_bits;
-    if (!std::strcmp(key, "msm_three_level_low")) return &ctx->opt_three_level_low;
-    if (!std::strcmp(key, "msm_sort_chunks_mult")) return &ctx->opt_sort_chunks_mult;
-    if (!std::strcmp(key, "g2_sort_main")) return &ctx->opt_g2_sort_main;
     if (!std::strcmp(key, "rank_tables")) return &ctx->opt_rank_tables;
-    if (!std::strcmp(key, "split_assembly")) return &ctx->opt_split_assembly;
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
+#ifdef ZK_MEASURE
+    // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
+    if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;
+    if (!std::strcmp(key, "ablate")) return &ctx->opt_ablate;
+    if (!std::strcmp(key, "msm_fold")) return &ctx->opt_fold;
+    if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
+    if (!std::strcmp(key, "msm_unchain_lanes")) return &ctx->opt_unchain_lanes;
+    if (!std::strcmp(key, "chain_order")) return &ctx->opt_chain_order;
+    if (!std::strcmp(key, "msm_run_entries")) return &ctx->opt_run_entries;
+    if (!std::strcmp(key, "msm_run_whole")) return &ctx->opt_run_whole;
+#endif
     return nullptr;
 }
 int zk_set_option(zk_ctx* ctx, const char* key, long value) {
@@ -128,6 +118,13 @@ int zk_set_option(zk_ctx* ctx, const char* key, long value) {
 }
 long zk_get_option(const zk_ctx* ctx, const char* key) {
     if (!ctx || !key) return -1;
+    if (!std::strcmp(key, "measure_build")) {   // 1: the library was compiled with ZK_MEASURE and accepts the measurement switches
+#ifdef ZK_MEASURE
+        return 1;
+#else
+        return 0;
+#endif
+    }
     long* s = option_slot(const_cast<zk_ctx*>(ctx), key);
     return s ? *s : -1;
 }
@@ -181,6 +178,7 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
 }
 /* the window size msm tables of `count` points are built with when the option msm_window_bits is 0 (host code) */
 int zk_msm_auto_window(size_t count) { return msm_auto_window(count); }
+int zk_msm_auto_window_g2(size_t count) { return msm_auto_window_g2(count); }
 int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out) {
     if (!ctx || !desc || !out) return ZK_ERR_ARG;
     *out = nullptr;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -96,33 +97,23 @@ struct zk_ctx {
     long opt_profile = 0;
     long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges
     long opt_long_division = 0;   // dense form: always use the reference's long division (A/B check of the Newton form)
-    long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
-    long opt_acc_stream = 0;      // 1: every bucket accumulation on ONE low-priority stream, sorts / tails mid-priority (equal at 2^20, -25 % at 2^16: off)
-    long opt_defer_msm = 1;       // enqueue the inner products after the whole SpMV / NTT stage (prove.hip)
-    long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take fewer entries per lane and are not chained (msm_impl.hpp)
-    long opt_unchain_lanes = 65536; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation
-    long opt_sort_bins_log = 0;   // log2 of the level-1 bins of the counting sort per group (0: 8)
-    long opt_ablate = 0;          // measurement aid, bit 0: reuse the previous sorted list of a workspace (repeated inputs only)
-    long opt_direct_subs = 0;     // >0: level-2 scatter without the LDS stage when a bin has 2^this sub-buckets or more (msm_impl.hpp)
-    long opt_three_level_bits = 0;  // >0: bins with 2^this sub-buckets and more are sorted in two passes (three sort levels in all); measured level with two (tools/ab_three.sh): off
-    long opt_three_level_low = 6;   // ... of which the last pass sorts this many bits
-    long opt_sort_chunks_mult = 1;  // level-1 sort: chunks (workgroups) per CU
-    long opt_g2_sort_main = 0;    // 1: at 2^18 gates and more the G2 product's counting sort runs on the main stream (measured: gaps between accumulations 0.85 -> 0.29 ms per proof, accumulations 10.75 -> 11.23 ms: same period, so off)
     long opt_rank_tables = 1;     // multi-GPU scalar exchange: window tables of this rank's point ranges only (prove_msm_submit)
-    long opt_split_assembly = 0;  // 1: A and B of a proof are closed on their products' own streams (measured: the G2 chain ends last, so B's inversion stays on the critical path and C then follows it: +0.1 ms per lone proof at 2^4 .. 2^16 -- off)
-    long opt_tail_streams = 0;    // reduction tails of the inner products on two streams of their own (measured: -27 %, kept as an experiment switch)
-    long opt_alt_g2 = 0;          // the G2 inner product of odd-numbered proof slots runs on the spare MSM stream
+    // tuning values: fixed in the product build, settable in a ZK_MEASURE build (capi.hip: option_slot)
+    long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
+    long opt_ablate = 0;          // bit 0: reuse the previous sorted list of a workspace (repeated inputs only; prices the sort)
+    long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take shorter runs (msm_impl.hpp)
+    long opt_unchain_lanes = 65536; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation
+    long opt_chain_order = 0;     // order of the accumulation chain of a proof: 0 = L, B2, A, HB; 1 = L, A, B2, HB
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
-    long opt_lane_entries = 32;   // additions per lane of the bucket accumulation (multiple of 4)
+    long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
+    long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     std::map<unsigned, std::shared_ptr<zk::NttTables>> ntt_tables;
-    static constexpr int MSM_STREAMS = 5;
+    static constexpr int MSM_STREAMS = 5;        // slots: 0 = B in G2, 1 = L, 2 = A, 3 = unused, 4 = H + r B1 + s A
     std::shared_ptr<zk::MsmWorkspace> msm_ws0;   // workspace of the stand-alone zk_msm_* entry points
     hipStream_t msm_stream[MSM_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t tail_stream[2] = {nullptr, nullptr};
-    hipStream_t acc_stream = nullptr;
     int cu_count = 256;
 
     hipEvent_t get_event() {
@@ -159,7 +150,10 @@ struct ProfScope {
     hipStream_t st;
     PendingEvent pe;
     bool on;
-    ProfScope(zk_ctx* c, const char* name, double algo_bytes, hipStream_t s = nullptr) : ctx(c), st(s ? s : c->stream), on(c->opt_profile != 0) {
+    // option profile: 0 off, 1 the bucket accumulations only (the dominant kernel; what bench.py's roofline needs -- event pairs
+    // around all ~150 launches of a proof cost 1.3 % of the pipelined rate), 2 every launch group
+    ProfScope(zk_ctx* c, const char* name, double algo_bytes, hipStream_t s = nullptr)
+        : ctx(c), st(s ? s : c->stream), on(c->opt_profile >= 2 || (c->opt_profile == 1 && !std::strncmp(name, "msm_accumulate", 14))) {
         if (on) {
             pe.name = name;
             pe.bytes = algo_bytes;

@@ -159,7 +159,7 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool l
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
     msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
-    msm_build_table<Fq2>(ctx, b_xi2, n, o_g2 > 0 ? (int)o_g2 : pick(n), c.t_xi2);
+    msm_build_table<Fq2>(ctx, b_xi2, n, o_g2 > 0 ? (int)o_g2 : (o_all % 10000 > 0 ? pick(n) : msm_auto_window_g2(n)), c.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables now hold the permuted points
         c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();
@@ -209,7 +209,7 @@ void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, b
     }
     build1(c.sum_delta1.p, nl, cl, R.t_sum_delta1);
     cnt = range(cn, n, &lo);
-    msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : pick(cnt), R.t_xi2);
+    msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : (o_all % 10000 > 0 ? pick(cnt) : msm_auto_window_g2(cnt)), R.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables hold the permuted points
         c.xi1_br.release(); c.xi_t1_br.release(); c.xi2_br.release();

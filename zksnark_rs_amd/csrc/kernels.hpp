@@ -50,7 +50,7 @@ void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
 void lazy29_batch(zk_ctx*, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n, uint64_t* out, int32_t* raw_out);
 
 // ---- msm.hip ----
-constexpr int MSM_MAX_C = 22;   // window bits; the two-level sort keeps only 2^10 + 2^(c-11) counters in LDS
+constexpr int MSM_MAX_C = 22;   // window bits; the two-level sort keeps only 2^8 + 2^(c-9) counters in LDS
 
 // T[w][i] = 2^(c w) P_i, w < windows, i < n (affine, Montgomery)
 template <class F>
@@ -60,16 +60,14 @@ struct MsmTable {
     int c = 0, windows = 0;
 };
 struct MsmWorkspace {
-    DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy, bin_start2, part_start2;
-    DevBuf<uint64_t> records, records2;   // records2, bin_start2, part_start2: the middle level of the three-level sort
-    DevBuf<uint8_t> partial, bucket_sums, fold, seg_sums;
-    hipStream_t tail_stream = nullptr;   // where the reduction tail runs (null: on the product's own stream)
-    hipStream_t acc_stream = nullptr;    // where the bucket accumulation runs (null: on the product's own stream)
-    hipStream_t sort_stream = nullptr;   // where the counting sort runs (null: on the product's own stream)
-    uint64_t sorted_for = 0;             // (entries, buckets) signature of the sorted list held (option ablate)
-    hipEvent_t sorted_evt = nullptr;     // sort -> accumulation hand-over when acc_stream is set (owned; lives as long as the context)
+    DevBuf<uint32_t> hist, total, bin_start, part_start, bin_cnt, start, sorted, heavy;
+    DevBuf<uint64_t> records;
+    DevBuf<uint32_t> runs_cnt, wg_extra, xbase, runs;   // runs of the accumulation (msm_impl.hpp): class counts | cursors | info, ..., 3 words per run
+    DevBuf<uint8_t> bucket_sums, fold, seg_sums;
+    uint64_t sorted_for = 0;             // signature of the sorted list held (option ablate, ZK_MEASURE builds)
 };
 int msm_auto_window(size_t n);
+int msm_auto_window_g2(size_t n);
 void msm_init_attributes();
 template <class F>
 void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<F>& out);
@@ -88,7 +86,7 @@ struct MsmGroups {
     int groups = 1;
     size_t glen = 0, valid = 0, out_stride = 0;
 };
-// Returns the stream the result lands on (the tail stream when the workspace names one).
+// Returns the stream the result lands on (st).
 template <class F>
 hipStream_t msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
              int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0,

@@ -398,55 +398,25 @@ ZK_HD bool madd_xyzz(XyzzR<L>& p, const L& qx, const L& qy) {
     return true;
 }
 
-// The same addition with ZZ and ZZZ parked in LDS between their two uses (experiment ZK_G2_PARK_LDS: over Fq2 the four
-// coordinates are 72 registers and the kernel spills 19 registers / 80 B per lane at the 256-register limit).  Result: NOT a way out.
-// With 36 registers fewer to carry the compiler's schedule of the unrolled multiplications simply widens: 52 spilled registers and
-// 224 B of scratch with the products in this order, 96 / 272 B with ZZ3, ZZZ3 formed last as in madd_xyzz, 117 / 368 B before the
-// parked coordinates were redefined on every path (-Rpass-analysis=kernel-resource-usage).  Kept for the record, never built.  lds: this lane's slot, limb l of
-// coordinate k at lds[(k * LIMBS + l) * stride]; volatile, so that the second read is not merged with the first.
-template <class L> struct LimbsOf;
-template <class PR> struct LimbsOf<FpR<PR>> { static constexpr int value = 9; };
-template <class PR> struct LimbsOf<Fp2R<PR>> { static constexpr int value = 18; };
-template <class PR> ZK_HD int32_t& limb_ref(FpR<PR>& x, int i) { return x.v[i]; }
-template <class PR> ZK_HD int32_t& limb_ref(Fp2R<PR>& x, int i) { return i < 9 ? x.c0.v[i] : x.c1.v[i - 9]; }
+// The same addition for an accumulator that is known NOT to be infinity (the hot loop of k_msm_accumulate: a run starts from its
+// first point, so the test never has to sit inside the loop).  Returns 0 when the sum was formed, 1 when P == Q (the caller doubles),
+// 2 when P == -Q (the sum is infinity; the accumulator is left as it was).
 template <class L>
-ZK_HD L park_get(const volatile int32_t* lds, int k, int stride) {
-    L r;
-#pragma unroll
-    for (int i = 0; i < LimbsOf<L>::value; ++i) limb_ref(r, i) = lds[(k * LimbsOf<L>::value + i) * stride];
-    return r;
-}
-template <class L>
-ZK_HD void park_put(volatile int32_t* lds, int k, int stride, L v) {
-#pragma unroll
-    for (int i = 0; i < LimbsOf<L>::value; ++i) lds[(k * LimbsOf<L>::value + i) * stride] = limb_ref(v, i);
-}
-template <class L>
-ZK_HD bool madd_xyzz_parked(L& X, L& Y, bool& inf, volatile int32_t* lds, int stride, const L& qx, const L& qy) {
-    if (inf) {
-        X = qx; Y = qy.norm(); inf = false;
-        const L one = L::load(L::Elem::one());
-        park_put(lds, 0, stride, one); park_put(lds, 1, stride, one);
-        return true;
-    }
-    L U2 = qx * park_get<L>(lds, 0, stride);
-    L S2 = qy * park_get<L>(lds, 1, stride);
-    L P = U2 - X;
-    L R = S2 - Y;
+ZK_HD int madd_xyzz_nz(XyzzR<L>& p, const L& qx, const L& qy) {
+    L U2 = qx * p.ZZ;
+    L S2 = qy * p.ZZZ;
+    L P = U2 - p.X;                          // differences of two normal forms: |limb| < 2^29
+    L R = S2 - p.Y;
     L PP = P.sqr();
-    if (PP.is_zero_mod_p()) {
-        if (R.sqr().is_zero_mod_p()) return false;
-        inf = true;
-        return true;
-    }
-    park_put(lds, 0, stride, park_get<L>(lds, 0, stride) * PP);      // ZZ3 = ZZ1 PP: PP is dead after the next two lines
+    if (PP.is_zero_mod_p()) return R.sqr().is_zero_mod_p() ? 1 : 2;
     L PPP = P * PP;
-    L Q = X * PP;
-    park_put(lds, 1, stride, park_get<L>(lds, 1, stride) * PPP);     // ZZZ3 = ZZZ1 PPP
+    L Q = p.X * PP;
     L X3 = (R.sqr() - PPP - (Q + Q)).norm();
-    Y = xyzz_ydiff(R, Q - X3, Y, PPP);
-    X = X3;
-    return true;
+    p.Y = xyzz_ydiff(R, Q - X3, p.Y, PPP);   // Q - X3: difference of two normal forms
+    p.X = X3;
+    p.ZZ = p.ZZ * PP;
+    p.ZZZ = p.ZZZ * PPP;
+    return 0;
 }
 
 // Jacobian point with the same affine image: (X ZZ^2, Y ZZZ^2, ZZZ)

@@ -17,10 +17,12 @@
 //              8-byte records by bin (high bits of the bucket id, one workgroup per scalar chunk,
 //              counters in LDS), level 2 sorts inside each bin by sub-bucket and emits the bucket
 //              offsets; signed-digit recoding happens on the fly in both level-1 passes
-//   accumulate every lane adds the same number of consecutive entries of the sorted list (gathered
-//              64 B / 128 B points) into a register-resident accumulator in the lazy radix-2^29
-//              form (lazy29.cuh) and parks the accumulator image at bucket boundaries
-//   merge      bucket sums from the parked images (a workgroup per bucket for heavy buckets)
+//   runs       every bucket is cut into ceil(size / T) runs of (nearly) equal length <= T; the runs of all buckets are
+//              listed by decreasing length (a counting sort over <= 128 length classes)
+//   accumulate lane t adds the entries of run t (gathered 64 B / 128 B points) into a register-resident
+//              accumulator in the lazy radix-2^29 form (lazy29.cuh): the 64 lanes of a wave have runs of
+//              (almost) the same length, the longest runs start first, and a bucket that is one run needs nothing more
+//   merge      buckets of several runs: sum of their images (a workgroup per bucket for heavy buckets)
 //   reduce     sum_b b*S_b by rows and columns of the bucket index (b - 1 = hi K + lo): plain sums give the K column
 //              sums C_lo and the 2^(c-1)/K row sums R_hi (2 additions per bucket, all parallel, no doubling chains),
 //              sum_b b S_b = sum_lo lo C_lo + sum_hi (hi K + 1) R_hi is left for ~2 sqrt(buckets) points
@@ -53,13 +55,26 @@ int msm_auto_window(size_t n) {
     if (lg >= 11) return 13;
     return 8;
 }
+// The G2 table: from 2^20 points on c = 20 as well.  An addition over Fq2 is three over Fq, so the saved windows (13 instead of 15)
+// weigh more against the 2^19 bucket images of the tail, and since round 3 a bucket of <= 64 entries is ONE run of the accumulation
+// with nothing to merge: same-box A/B at 2^20 gates 93.5 against 92.0 proofs/s (profiles/r3_ab.txt).  c = 20 for the n-point G1
+// product (A) as well is level (92.9).
+int msm_auto_window_g2(size_t n) {
+    if (n + 8 >= ((size_t)1 << 20)) return 20;
+    return msm_auto_window(n);
+}
 #endif  // ZK_MSM_COMMON
 
-#ifndef ZK_SORT_THREADS
-#define ZK_SORT_THREADS 1024
-#endif
-constexpr int SORT_THREADS = ZK_SORT_THREADS;
-constexpr int SORT2_THREADS = 256;   // level-2 workgroups (several per bin)
+constexpr int SORT_THREADS = 1024;   // level-1 workgroups (one per scalar chunk)
+constexpr int SORT2_THREADS = 256;   // level-2 histogram / offsets workgroups (several per bin)
+constexpr int BINS_THREADS = 512;    // level-2 scatter workgroups
+constexpr int BIN_STAGE = 8192;      // ... and the records they stage in LDS at a time
+constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
+constexpr int RUN_MAX = 128;         // longest run of the accumulation (length classes 1..RUN_MAX)
+
+// one run of the accumulation: entries [k0, k0 + len) of the bucket-sorted list, all of one bucket; the image of their sum goes to
+// slot `dest` (the bucket's own slot for its first run, a slot behind the buckets' for the others)
+struct MsmRun { uint32_t k0, len, dest, end; };
 
 // ---- table precompute: T[w][i] = 2^(c w) P_i ------------------------------------------------
 template <class F>
@@ -91,23 +106,23 @@ void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTa
 template void msm_build_table<ZK_MSM_FIELD>(zk_ctx*, const Aff<ZK_MSM_FIELD>*, size_t, int, MsmTable<ZK_MSM_FIELD>&);
 
 // ---- signed-digit recoding -------------------------------------------------------------------
-// Calls f(w, mag, neg) for every owned window with a non-zero digit.
+// Calls f(w, mag, neg) for every owned window with a non-zero digit.  The scalar is consumed by shifting the 256-bit value right
+// by c per window (8 v_alignbit): indexing its limbs with a run-time word number sent the copy to scratch and cost the level-1
+// kernels 48 B of scratch and 50 registers -- four such waves per SIMD did not fit beside the bucket accumulation's waves.
 template <class Fn>
 __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, int first, int step, Fn&& f) {
+    uint32_t l0 = k.l[0], l1 = k.l[1], l2 = k.l[2], l3 = k.l[3], l4 = k.l[4], l5 = k.l[5], l6 = k.l[6], l7 = k.l[7];
     uint32_t carry = 0;
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     int next_owned = first;
     for (int w = 0; w < windows; ++w) {
-        int pos = w * c, word = pos >> 5, off = pos & 31;
-        uint32_t raw = 0;
-        if (word < 8) {
-            raw = k.l[word] >> off;
-            if (off + c > 32 && word + 1 < 8) raw |= k.l[word + 1] << (32 - off);
-            raw &= mask;
-        }
-        raw += carry;
-        uint32_t neg = raw > half;
-        uint32_t mag = neg ? (1u << c) - raw : raw;
+        const uint32_t raw = (l0 & mask) + carry;
+        l0 = __builtin_amdgcn_alignbit(l1, l0, c); l1 = __builtin_amdgcn_alignbit(l2, l1, c);
+        l2 = __builtin_amdgcn_alignbit(l3, l2, c); l3 = __builtin_amdgcn_alignbit(l4, l3, c);
+        l4 = __builtin_amdgcn_alignbit(l5, l4, c); l5 = __builtin_amdgcn_alignbit(l6, l5, c);
+        l6 = __builtin_amdgcn_alignbit(l7, l6, c); l7 >>= c;
+        const uint32_t neg = raw > half;
+        const uint32_t mag = neg ? (1u << c) - raw : raw;
         carry = neg;
         if (w == next_owned) {
             if (mag) f(w, mag, neg);
@@ -189,9 +204,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
+#pragma unroll 1
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
+    // one scalar at a time (the compiler otherwise keeps two in flight: 50 registers, and four such waves per SIMD -- a 1024-lane
+    // workgroup -- do not fit into the 208 registers that one retired accumulation wave leaves)
+#pragma unroll 1
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
         if (il >= gvalid) continue;
@@ -201,6 +220,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     }
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * bins;
+#pragma unroll 1
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) row[b] = lds[b];
 }
 
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restri
 }
 
 __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift, uint32_t* __restrict__ cnt) {
+                                                                const uint32_t* __restrict__ part_start, int bins, int sub_bits, uint32_t* __restrict__ cnt) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int subs = 1 << sub_bits;
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* 
         for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k + j * SORT2_THREADS < hi) lds_inc(lds, ((uint32_t)(r[j] >> 32) >> shift) & (uint32_t)(subs - 1));
+            if (k + j * SORT2_THREADS < hi) lds_inc(lds, (uint32_t)(r[j] >> 32) & (uint32_t)(subs - 1));
     }
     __syncthreads();
     uint32_t* row = cnt + (size_t)blockIdx.x * subs;
@@ -372,31 +392,18 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
 
 // level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
 // them by sub-bucket inside LDS and stores runs of consecutive 4-byte entries
-#ifndef ZK_BINS_THREADS
-#define ZK_BINS_THREADS 512
-#endif
-constexpr int BINS_THREADS = ZK_BINS_THREADS;
-#ifndef ZK_BIN_STAGE
-#define ZK_BIN_STAGE 8192
-#endif
-constexpr int BIN_STAGE = ZK_BIN_STAGE;
-constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
-// REC: the output is again a list of 8-byte records (an intermediate level: sub-bucket field bits [shift, shift + sub_bits)),
-// otherwise the final 4-byte entries
-template <bool REC>
-__device__ __forceinline__ void bin_scatter_body(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                 const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
-                                                 const uint32_t* __restrict__ pos_in, void* __restrict__ out) {
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
+                                                                  const uint32_t* __restrict__ part_start, int bins, int sub_bits,
+                                                                  const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+    ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t scratch[BINS_THREADS];
-    typedef typename std::conditional<REC, uint64_t, uint32_t>::type Ent;
     const int subs = 1 << sub_bits;
-    Ent* stage = reinterpret_cast<Ent*>(smem);
-    uint16_t* ssub = reinterpret_cast<uint16_t*>(smem + (size_t)BIN_STAGE * sizeof(Ent));
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)BIN_STAGE * (sizeof(Ent) + 2));
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem);
+    uint16_t* ssub = reinterpret_cast<uint16_t*>(smem + (size_t)BIN_STAGE * 4);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + (size_t)BIN_STAGE * 6);
     uint32_t* lstart = cnt + subs;
     uint32_t* pos = lstart + subs;     // running write position per sub-bucket for this (bin, part)
-    Ent* dst = reinterpret_cast<Ent*>(out);
     uint32_t lo, hi;
     if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
     const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
@@ -404,14 +411,13 @@ __device__ __forceinline__ void bin_scatter_body(const uint64_t* __restrict__ re
     for (uint32_t base = lo; base < hi; base += BIN_STAGE) {
         for (int b = threadIdx.x; b < subs; b += BINS_THREADS) cnt[b] = 0;
         __syncthreads();
-        Ent ent[BIN_PER_LANE];
-        uint32_t sub[BIN_PER_LANE], rank[BIN_PER_LANE];
+        uint32_t ent[BIN_PER_LANE], sub[BIN_PER_LANE], rank[BIN_PER_LANE];
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j) {
             const uint32_t k = base + j * BINS_THREADS + threadIdx.x;
             const uint64_t r = k < hi ? records[k] : 0;
-            ent[j] = (Ent)r;
-            sub[j] = ((uint32_t)(r >> 32) >> shift) & (uint32_t)(subs - 1);
+            ent[j] = (uint32_t)r;
+            sub[j] = (uint32_t)(r >> 32) & (uint32_t)(subs - 1);
         }
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j)
@@ -428,50 +434,97 @@ __device__ __forceinline__ void bin_scatter_body(const uint64_t* __restrict__ re
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < total; p += BINS_THREADS) {
             const uint32_t sb = ssub[p];
-            dst[pos[sb] + (p - lstart[sb])] = stage[p];
+            sorted[pos[sb] + (p - lstart[sb])] = stage[p];
         }
         __syncthreads();
         for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] += cnt[b];
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                  const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
-                                                                  const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
-    ZK_LATENCY_KERNEL();
-    bin_scatter_body<false>(records, bin_start, part_start, bins, sub_bits, shift, pos_in, sorted);
-}
-// an intermediate level of the sort (three levels for the 2^10 and more sub-buckets per bin of c >= 19)
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter_rec(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                      const uint32_t* __restrict__ part_start, int bins, int sub_bits, int shift,
-                                                                      const uint32_t* __restrict__ pos_in, uint64_t* __restrict__ records_out) {
-    ZK_LATENCY_KERNEL();
-    bin_scatter_body<true>(records, bin_start, part_start, bins, sub_bits, shift, pos_in, records_out);
-}
 
-// level-2 scatter without the LDS stage, for many sub-buckets per bin (c = 20: 2^11): a stage of 8192 records then holds ~4 per
-// sub-bucket, the staged form stores runs of 16 bytes and pays a 2048-counter scan per stage.  Here every record goes straight to
-// the next free position of its sub-bucket (LDS counters seeded with this part's offsets): one 4-byte store per record into the
-// bin's output region, which the parts of a bin fill together while it is cache resident.
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter_direct(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
-                                                                         const uint32_t* __restrict__ part_start, int bins, int sub_bits,
-                                                                         const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
+// ---- runs of the accumulation -----------------------------------------------------------------------
+// Bucket b (entries [start[b], start[b + 1]) of the sorted list, z of them) is cut into r = ceil(z / T) runs of floor(z / r) or
+// ceil(z / r) <= T entries; one accumulation lane adds one run.  The runs are listed by DECREASING length class (ceil(z / r)):
+//   * the 64 lanes of a wave then have the same trip count (+-1) however the bucket sizes are distributed, so no lane idles;
+//   * the longest runs start first and the launch drains through its shortest ones;
+//   * a bucket that fits one run (z <= T: every bucket of a window whose 2^(c-1) buckets outnumber the entries / T) needs no
+//     merging at all -- its image is the bucket sum.  The former equal-slices form (lane t owned entries [32 t, 32 t + 32)
+//     whatever buckets they fell into) paid one full addition per lane in k_msm_merge: 4 % of a proof's instructions.
+// runs_cnt[len] = number of runs of class len (len <= RUN_MAX); wg_extra[g] = runs beyond the first of the buckets of workgroup g.
+__device__ __forceinline__ void bucket_runs(const uint32_t* __restrict__ start, int buckets, uint32_t T, uint32_t b, uint32_t& s, uint32_t& z, uint32_t& r, uint32_t& len) {
+    s = z = r = len = 0;
+    if (b >= (uint32_t)buckets) return;
+    s = start[b];
+    z = start[b + 1] - s;
+    if (!z) return;
+    r = (z + T - 1) / T;
+    len = (z + r - 1) / r;
+}
+__global__ __launch_bounds__(256) void k_msm_runs_count(const uint32_t* __restrict__ start, int buckets, uint32_t T, uint32_t* __restrict__ runs_cnt,
+                                                        uint32_t* __restrict__ wg_extra) {
     ZK_LATENCY_KERNEL();
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* pos = reinterpret_cast<uint32_t*>(smem);
-    const int subs = 1 << sub_bits;
-    uint32_t lo, hi;
-    if (!bin_slice(bin_start, part_start, bins, lo, hi)) return;
-    const uint32_t* row = pos_in + (size_t)blockIdx.x * subs;
-    for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] = row[b];
+    __shared__ uint32_t h[RUN_MAX + 2];
+    for (int i = threadIdx.x; i < RUN_MAX + 2; i += 256) h[i] = 0;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * BINS_THREADS) {
-        uint64_t r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = k + j * BINS_THREADS < hi ? records[k + j * BINS_THREADS] : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k + j * BINS_THREADS < hi) sorted[lds_inc(pos, (uint32_t)(r[j] >> 32))] = (uint32_t)r[j];
+    uint32_t s, z, r, len;
+    bucket_runs(start, buckets, T, blockIdx.x * 256 + threadIdx.x, s, z, r, len);
+    if (r) atomicAdd(&h[len], r);
+    if (r > 1) atomicAdd(&h[RUN_MAX + 1], r - 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= RUN_MAX; i += 256)
+        if (h[i]) atomicAdd(&runs_cnt[i], h[i]);
+    if (threadIdx.x == 0) wg_extra[blockIdx.x] = h[RUN_MAX + 1];
+}
+// one workgroup: cursor[len] = position of the first run of class len (classes in decreasing order), wg_xbase = exclusive scan of
+// wg_extra, info = {runs, extra images}; runs_cnt is cleared for the next product that uses this workspace
+__global__ __launch_bounds__(1024) void k_msm_runs_scan(uint32_t* __restrict__ runs_cnt, uint32_t* __restrict__ cursor, const uint32_t* __restrict__ wg_extra,
+                                                        uint32_t* __restrict__ wg_xbase, int wgs, uint32_t* __restrict__ info) {
+    ZK_LATENCY_KERNEL();
+    __shared__ uint32_t scratch[1024];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int len = RUN_MAX; len >= 1; --len) {
+            cursor[len] = run;
+            run += runs_cnt[len];
+            runs_cnt[len] = 0;
+        }
+        cursor[0] = run;
+        info[0] = run;
+    }
+    const uint32_t extras = block_exclusive_scan<1024>(wg_extra, wg_xbase, wgs, scratch);
+    if (threadIdx.x == 0) info[1] = extras;
+}
+__global__ __launch_bounds__(256) void k_msm_runs_emit(const uint32_t* __restrict__ start, int buckets, uint32_t T, uint32_t* __restrict__ cursor,
+                                                       const uint32_t* __restrict__ wg_xbase, MsmRun* __restrict__ runs, uint32_t* __restrict__ xbase) {
+    ZK_LATENCY_KERNEL();
+    __shared__ uint32_t h[RUN_MAX + 1], gb[RUN_MAX + 1], scratch[256];
+    for (int i = threadIdx.x; i <= RUN_MAX; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    uint32_t s, z, r, len;
+    bucket_runs(start, buckets, T, b, s, z, r, len);
+    const uint32_t rank = r ? atomicAdd(&h[len], r) : 0;
+    // exclusive scan of the buckets' extra runs inside the workgroup
+    const uint32_t x = r > 1 ? r - 1 : 0;
+    scratch[threadIdx.x] = x;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= d ? scratch[threadIdx.x - d] : 0;
+        __syncthreads();
+        scratch[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t xb = wg_xbase[blockIdx.x] + scratch[threadIdx.x] - x;
+    for (int i = threadIdx.x; i <= RUN_MAX; i += 256) gb[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0;
+    __syncthreads();
+    if (!r) return;
+    xbase[b] = xb;
+    const uint32_t pos = gb[len] + rank;
+    uint32_t k0 = s;
+    for (uint32_t j = 0; j < r; ++j) {
+        const uint32_t k1 = s + (uint32_t)((uint64_t)z * (j + 1) / r);
+        runs[pos + j] = MsmRun{k0, k1 - k0, j == 0 ? b : (uint32_t)buckets + xb + j - 1, k1};
+        k0 = k1;
     }
 }
 
@@ -481,181 +534,187 @@ __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
-#ifndef ZK_BINS_THREADS
-#define ZK_BINS_THREADS 512
-#endif
-constexpr int BINS_THREADS = ZK_BINS_THREADS;
-#ifndef ZK_BIN_STAGE
-#define ZK_BIN_STAGE 8192
-#endif
-constexpr int BIN_STAGE = ZK_BIN_STAGE;
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
-__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, uint32_t*);
+__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
-__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, const uint32_t*, uint32_t*);
-__global__ void k_msm_bin_scatter_rec(const uint64_t*, const uint32_t*, const uint32_t*, int, int, int, const uint32_t*, uint64_t*);
-__global__ void k_msm_bin_scatter_direct(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_runs_count(const uint32_t*, int, uint32_t, uint32_t*, uint32_t*);
+__global__ void k_msm_runs_scan(uint32_t*, uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);
+__global__ void k_msm_runs_emit(const uint32_t*, int, uint32_t, uint32_t*, const uint32_t*, MsmRun*, uint32_t*);
 #endif  // ZK_MSM_COMMON
 
-// ---- bucket accumulation: equal shares of the sorted list per lane ------------------------------
+// ---- bucket accumulation: one run per lane -------------------------------------------------------
 // waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 145 VGPRs) fits 3
 // waves; the G2 body (XYZZ over Fq2: 72 accumulator limbs + the affine point before any temporary)
 // fits 2 with 16 dwords of scratch.
 template <class F> struct AccWaves { static constexpr int value = 3; };
-#ifndef ZK_G2_ACC_WAVES
-#define ZK_G2_ACC_WAVES 2
-#endif
-template <> struct AccWaves<Fq2> { static constexpr int value = ZK_G2_ACC_WAVES; };
+template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
-// register image of an accumulator as it is parked in HBM between accumulate and merge
+// Shape of the accumulation loop per field.  The loop body is ~6 k (G1) / ~19 k (G2) instructions whose register allocation and
+// schedule the compiler finds afresh for every source form, and semantically equivalent forms differ by up to 10 % in EXECUTED
+// instructions (SQ_INSTS_VALU per addition, tools/valu_budget.py; profiles/r3_acc_shapes.txt):
+//   NZ      the accumulator is started from the run's first point and the loop body has no test for infinity
+//   DEAD    a block that parks and clears the accumulator at a position the compiler cannot know (run.end, which equals the loop's own
+//           bound: never reached) -- what is left of the bucket-boundary bookkeeping of the equal-slices form, whose presence makes
+//           the allocator keep the accumulator in place instead of copying it between the unrolled iterations
+//   UNROLL  iterations per trip
+#ifndef ZK_G1_SHAPE
+#define ZK_G1_SHAPE 0, 1, 2
+#endif
+#ifndef ZK_G2_SHAPE
+#define ZK_G2_SHAPE 1, 0, 1
+#endif
+template <bool NZ_, bool DEAD_, int UNROLL_> struct AccShapeOf { static constexpr bool NZ = NZ_, DEAD = DEAD_; static constexpr int UNROLL = UNROLL_; };
+template <class F> struct AccShape : AccShapeOf<ZK_G1_SHAPE> {};
+template <> struct AccShape<Fq2> : AccShapeOf<ZK_G2_SHAPE> {};
+
+// register image of an accumulator as it is parked in HBM between accumulate, merge and the folds
 template <class F>
 struct alignas(16) AccSlot {
     typename AccOf<F>::type a;
 };
 
-// Lane t owns entries [t E, (t+1) E) of the bucket-sorted list, whatever buckets they belong to, so every
-// lane of every wave performs the same number of additions however skewed the digit distribution is
-// (a witness full of 0/1 wires puts a large share of all digits into one bucket).  When a lane crosses a
-// bucket boundary it parks the finished accumulator image and starts a new one:
-//   first[t]  the segment that begins at the lane's first entry,
-//   last[t]   the segment that reaches the lane's last entry (when it is not also the first),
-//   mid[b]    buckets that lie strictly inside the lane's range.
-// k_msm_merge finds the images of a bucket again from the geometry alone.
+// Lane t adds the entries of run t (k_msm_runs_emit) and stores the image of their sum in the run's slot.  info[0] = number of runs.
 template <class F>
 __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
-                                                       const uint32_t* __restrict__ start, int buckets, uint32_t per_lane,
-                                                       AccSlot<F>* __restrict__ first, AccSlot<F>* __restrict__ last, AccSlot<F>* __restrict__ mid) {
-    const uint32_t total = start[buckets];
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid * per_lane >= total) return;
-    const uint32_t k0 = (uint32_t)(tid * per_lane), k1 = min(k0 + per_lane, total);
-    // bucket of the first entry: start[b] <= k0 < start[b + 1]
-    int lo = 0, hi = buckets;   // invariant: start[lo] <= k0 < start[hi]
-    while (hi - lo > 1) {
-        int mid_b = (lo + hi) >> 1;
-        if (start[mid_b] <= k0) lo = mid_b; else hi = mid_b;
-    }
-    int b = lo;
-    uint32_t bend = start[b + 1];
+                                                       const MsmRun* __restrict__ runs, const uint32_t* __restrict__ info, AccSlot<F>* __restrict__ img) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= info[0]) return;
+    const MsmRun run = runs[tid];
+    const uint32_t k1 = run.k0 + run.len;
     typedef typename LazyOf<F>::type L;
+    typedef AccShape<F> Shape;
     typename AccOf<F>::type acc;
     acc_clear(acc);
-    bool is_first = true;
-#ifdef ZK_G2_PARK_LDS
-    // experiment: over Fq2, ZZ and ZZZ of the running accumulator live in LDS (limb-major: conflict-free), see madd_xyzz_parked
-    constexpr bool PARK = sizeof(F) > sizeof(Fq);
-    __shared__ int32_t park_lds[PARK ? 2 * 18 * 256 : 1];
-    volatile int32_t* const my_park = park_lds + (PARK ? threadIdx.x : 0);
-    auto park_out = [&](typename AccOf<F>::type& a) {   // registers <- LDS before an image is written / the slow path runs
-        if (PARK) {   // both coordinates are (re)defined here on every path, so that nothing of them stays live across the loop
-            const L z = L::load(L::Elem::zero());
-            a.ZZ = a.inf ? z : park_get<L>(my_park, 0, 256);
-            a.ZZZ = a.inf ? z : park_get<L>(my_park, 1, 256);
-        }
-    };
-#endif
     // software pipeline: the next point's gather (a random line of a multi-GiB table) is in flight
     // while the current addition executes
-    uint32_t k = k0;
+    uint32_t k = run.k0;
     uint32_t e = sorted[k];
     uint32_t e_next = k + 1 < k1 ? sorted[k + 1] : 0;
     Aff<F> p = table[e >> 1];
-    // G1: two iterations per trip save the register copies of the loop-carried accumulator / prefetched point (-2 % stand-alone;
-    // four: no further gain; G2: no gain and twice the code, so it stays rolled)
-    constexpr int ACC_UNROLL = sizeof(F) > sizeof(Fq) ? 1 : 2;
-#pragma unroll ACC_UNROLL
-    while (k < k1) {
-        if (k == bend) {   // bucket boundary: park the finished image
-#ifdef ZK_G2_PARK_LDS
-            park_out(acc);
-#endif
-            if (is_first) first[tid].a = acc; else mid[b].a = acc;
-            is_first = false;
-            acc_clear(acc);
-            do { ++b; bend = start[b + 1]; } while (bend <= k);   // skip empty buckets
-        }
-        const uint32_t kn = k + 1;
-        const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
-        const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
-        if (!p.is_inf()) {
-            L qx = L::load(p.x), qy = L::load(p.y);
-            if (e & 1) qy = qy.neg();
-#ifdef ZK_G2_PARK_LDS
-            if (PARK) {
-                if (!madd_xyzz_parked(acc.X, acc.Y, acc.inf, my_park, 256, qx, qy)) {
-                    park_out(acc);
-                    acc_load(acc, jac_dbl(acc_store(acc)));
-                    park_put(my_park, 0, 256, acc.ZZ); park_put(my_park, 1, 256, acc.ZZZ);
+    uint32_t bend = run.end;      // == k1, but loaded: the compiler cannot fold the (dead) block below away (see AccShape)
+    if constexpr (Shape::NZ) {
+        auto advance = [&] {
+            const uint32_t kn = k + 1;
+            const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
+            const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            p = p_next; e = e_next; e_next = e_next2; k = kn;
+        };
+        // The accumulator starts from the run's first finite point, so that the hot loop never tests it for infinity.
+        // P + (-P) empties the accumulator and restarts from the next point.
+        while (k < k1) {
+            while (k < k1 && p.is_inf()) advance();     // points at infinity: padding entries of a table only
+            if (k >= k1) break;
+            acc.X = L::load(p.x);
+            acc.Y = L::load(p.y);
+            if (e & 1) acc.Y = acc.Y.neg().norm();
+            acc.ZZ = acc.ZZZ = L::load(F::one());
+            acc.inf = false;
+            advance();
+            bool emptied = false;
+#pragma unroll Shape::UNROLL
+            while (k < k1) {
+                if constexpr (Shape::DEAD) {
+                    if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
                 }
-            } else
-#endif
-            if (!acc_madd(acc, qx, qy)) {
-                // same point twice in one bucket: doubling through the generic formulas (rare)
-                acc_load(acc, jac_dbl(acc_store(acc)));
+                const uint32_t kn = k + 1;
+                const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
+                const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
+                if (!p.is_inf()) {
+                    L qx = L::load(p.x), qy = L::load(p.y);
+                    if (e & 1) qy = qy.neg();
+                    const int st = madd_xyzz_nz(acc, qx, qy);
+                    if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
+                    emptied = st == 2;
+                }
+                p = p_next;
+                e = e_next;
+                e_next = e_next2;
+                k = kn;
+                if (emptied) break;
             }
+            if (!emptied) break;
+            acc_clear(acc);
         }
-        p = p_next;
-        e = e_next;
-        e_next = e_next2;
-        k = kn;
+    } else {
+#pragma unroll Shape::UNROLL
+        while (k < k1) {
+            if constexpr (Shape::DEAD) {
+                if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
+            }
+            const uint32_t kn = k + 1;
+            const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
+            const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            if (!p.is_inf()) {
+                L qx = L::load(p.x), qy = L::load(p.y);
+                if (e & 1) qy = qy.neg();
+                if (!acc_madd(acc, qx, qy)) {
+                    // same point twice in one bucket: doubling through the generic formulas (rare)
+                    acc_load(acc, jac_dbl(acc_store(acc)));
+                }
+            }
+            p = p_next;
+            e = e_next;
+            e_next = e_next2;
+            k = kn;
+        }
     }
-#ifdef ZK_G2_PARK_LDS
-    park_out(acc);
-#endif
-    if (is_first) first[tid].a = acc; else last[tid].a = acc;
+    img[run.dest].a = acc;
 }
 
-// S_b = sum of the parked images of bucket b (see k_msm_accumulate).  One lane per bucket; buckets spread
-// over more than MSM_HEAVY lanes (skewed digit distributions) are queued for k_msm_merge_heavy instead.
+// S_b = sum of the images of bucket b's runs: its own slot img[b] and the r - 1 slots from img[buckets + xbase[b]] on.  One lane per
+// bucket; buckets of more than MSM_HEAVY runs (skewed digit distributions) are queued for k_msm_merge_heavy instead.  Empty buckets
+// get the image of infinity here (no run wrote their slot).
 constexpr uint32_t MSM_HEAVY = 96;
 // Workgroup size of the reduction tail (merge / fold / weigh).  ONE wave: while an accumulation fills the chip, a 256-lane
 // workgroup of a 150..250-register kernel needs all four SIMDs of a CU to have room at the same moment, which only happens in
 // the accumulation's last round (the timeline showed the previous proof's G2 tail still running 8 ms after its accumulation
 // and the next proof's sort waiting behind it on the same stream); a single wave fits wherever one accumulation wave retires.
 constexpr int TAIL_THREADS = 64;
+// Registers of the tail kernels, as waves per SIMD they are compiled for.  A wave can only start on a SIMD that has its whole
+// register allocation free: beside three waves of the G1 accumulation (3 x 152 of 512 registers) that is 56, after one of them
+// retired 208 -- and beside the G2 accumulation (2 x 256) nothing until a wave retires.  A tail wave of 246..256 registers (what the
+// Fq2 kernels take when left alone) therefore waits for TWO accumulation waves of one SIMD to retire together, which only happens when
+// an accumulation drains: the kernel trace showed the four-wave k_msm_sum_points<Fq2> taking 1.2 ms instead of 0.28 and the G2 tail
+// as a whole ending with the last accumulation of its proof.
+// (Compiling the Fq2 tail kernels for 128 registers -- 700..1350 B of scratch each -- measured level with leaving them at 246..256:
+// profiles/r3_experiments.txt.)
+template <class F> struct TailWaves { static constexpr int value = 3; };
+template <> struct TailWaves<Fq2> { static constexpr int value = 2; };
 
 template <class F>
-__device__ __forceinline__ typename AccOf<F>::type merge_head(uint32_t b, uint32_t s, uint32_t e, uint32_t t0, uint32_t per_lane, uint32_t total,
-                                                              const AccSlot<F>* first, const AccSlot<F>* last, const AccSlot<F>* mid) {
-    const uint32_t t0_end = min((t0 + 1) * per_lane, total);
-    if (s == t0 * per_lane) return first[t0].a;
-    if (e >= t0_end) return last[t0].a;
-    return mid[b].a;
-}
-
-template <class F>
-__global__ __launch_bounds__(TAIL_THREADS) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
-                                                   const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
-                                                   uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
+                                                   AccSlot<F>* __restrict__ img, uint32_t* __restrict__ heavy) {
     ZK_LATENCY_KERNEL();
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= buckets) return;
-    const uint32_t s = start[b], e = start[b + 1], total = start[buckets];
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (uint32_t)buckets) return;
+    const uint32_t z = start[b + 1] - start[b];
     typename AccOf<F>::type acc;
-    if (s == e) { acc_clear(acc); img[b].a = acc; return; }
-    const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
-    if (t1 - t0 > MSM_HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = (uint32_t)b; return; }
-    acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid);
-    for (uint32_t t = t0 + 1; t <= t1; ++t) acc = acc_add(acc, first[t].a);
+    if (!z) { acc_clear(acc); img[b].a = acc; return; }
+    const uint32_t r = (z + T - 1) / T;
+    if (r == 1) return;
+    if (r - 1 > MSM_HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = b; return; }
+    const AccSlot<F>* more = img + (size_t)buckets + xbase[b];
+    acc = img[b].a;
+    for (uint32_t j = 0; j + 1 < r; ++j) acc = acc_add(acc, more[j].a);
     img[b].a = acc;
 }
 
 constexpr int MSM_HEAVY_THREADS = 128;
 // heavy buckets: one workgroup each, lanes stride over the images, tree over LDS
 template <class F>
-__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t per_lane, const AccSlot<F>* __restrict__ first,
-                                                         const AccSlot<F>* __restrict__ last, const AccSlot<F>* __restrict__ mid, AccSlot<F>* __restrict__ img,
-                                                         const uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
+                                                         AccSlot<F>* __restrict__ img, const uint32_t* __restrict__ heavy) {
     ZK_LATENCY_KERNEL();
     __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
-    const uint32_t count = heavy[0], total = start[buckets];
+    const uint32_t count = heavy[0];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         const uint32_t b = heavy[1 + h];
-        const uint32_t s = start[b], e = start[b + 1];
-        const uint32_t t0 = s / per_lane, t1 = (e - 1) / per_lane;
+        const uint32_t z = start[b + 1] - start[b], r = (z + T - 1) / T;
+        const AccSlot<F>* more = img + (size_t)buckets + xbase[b];
         typename AccOf<F>::type acc;
-        if (threadIdx.x == 0) acc = merge_head<F>(b, s, e, t0, per_lane, total, first, last, mid); else acc_clear(acc);
-        for (uint32_t t = t0 + 1 + threadIdx.x; t <= t1; t += MSM_HEAVY_THREADS) acc = acc_add(acc, first[t].a);
+        if (threadIdx.x == 0) acc = img[b].a; else acc_clear(acc);
+        for (uint32_t j = threadIdx.x; j + 1 < r; j += MSM_HEAVY_THREADS) acc = acc_add(acc, more[j].a);
         sh[threadIdx.x].a = acc;
         __syncthreads();
         for (int d = MSM_HEAVY_THREADS / 2; d >= 1; d >>= 1) {
@@ -681,7 +740,7 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uin
 // the rest job 1 -- half the dependent launches of the tail, which is what a lone proof of a small circuit waits for.
 struct FoldJob { const void* in; void* out; uint32_t A, f, B, blocks; };
 template <class F>
-__global__ __launch_bounds__(TAIL_THREADS) void k_msm_fold(FoldJob j0, FoldJob j1) {
+__global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_fold(FoldJob j0, FoldJob j1) {
     ZK_LATENCY_KERNEL();
     const bool second = blockIdx.x >= j0.blocks;
     const AccSlot<F>* in = reinterpret_cast<const AccSlot<F>*>(second ? j1.in : j0.in);
@@ -699,7 +758,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_msm_fold(FoldJob j0, FoldJob j
 // term[group][j]: j < K: lo * C[lo] (lo = j); j = K + hi: (hi K + 1) * R[hi].  One point per lane, every lane runs the same
 // double-and-add (weight 0 gives infinity); k_msm_sum_points adds the K + rows terms of a group.
 template <class F>
-__global__ __launch_bounds__(TAIL_THREADS) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
+__global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
                                                    Jac<F>* __restrict__ term) {
     ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
@@ -713,7 +772,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_msm_weigh(const AccSlot<F>* __
 // sums points: workgroup g of G adds in[g], in[g + G], ... (256 lanes, tree over LDS in the 8 x 32 form) -> out[g]
 // blockIdx.y = group: its `count` inputs start at in + y count, its gridDim.x outputs at (bytes) out + y out_stride
 template <class F>
-__global__ __launch_bounds__(256) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
+__global__ __launch_bounds__(256, TailWaves<F>::value) void k_msm_sum_points(const Jac<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Jac<F>* sh = reinterpret_cast<Jac<F>*>(smem);
@@ -760,33 +819,34 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
         return st;
     }
-    // two-level sort: at most 2^10 bins, the rest of the bucket bits are the sub-bucket
-    // 2^8 bins (more only to keep the sub-bucket level at 2^11 counters at most)
-    // level-1 bins: 2^8 up to c = 17 (more only to keep the sub-bucket level at 2^11 counters at most); option msm_sort_bins_log
-    const int bins_log = (int)std::max<long>(4, std::min<long>(ctx->opt_sort_bins_log > 0 ? ctx->opt_sort_bins_log : 8, 12));
-    const int sub_bits = std::min(11, std::max(0, c - 1 - bins_log)), bins = (1 << (c - 1 - sub_bits)) * groups;
-    int chunks = (int)std::min<size_t>((size_t)ctx->cu_count * (size_t)std::max<long>(1, std::min<long>(ctx->opt_sort_chunks_mult, 16)), (n_used + SORT_THREADS - 1) / SORT_THREADS);
+    // two-level sort: 2^8 bins per group (fewer when the window is narrow, more only to keep the sub-bucket level at 2^11 counters)
+    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = (1 << (c - 1 - sub_bits)) * groups;
+    int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
-    // every lane adds the same number of entries (a multiple of 4; 24..48 measured equal within noise)
-    size_t entries = (size_t)owned * n_used;
-    // positions in the sorted list (start[], the scan totals, k0 / k1 of the accumulation) are 32-bit, and the level-1
+    const size_t entries = (size_t)owned * n_used;
+    // positions in the sorted list (start[], the scan totals, the runs) are 32-bit, and the level-1
     // counters of all bins live in LDS: refuse up front instead of wrapping silently / failing after the first launches
     ZK_REQUIRE(entries < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
     ZK_REQUIRE((size_t)bins * 4 <= 65536, ZK_ERR_SIZE, "msm: too many groups for this window size (level-1 counters exceed 64 KiB of LDS)");
-    // ... as long as that leaves a lane for every SIMD slot worth filling: a product with few entries (small circuits, the
-    // tails of a sharded proof) is a latency chain of per_lane dependent additions on a fraction of the chip -- 32 additions
-    // over Fq2 are 0.6 ms whether 16 or 2^16 scalars are multiplied -- so its lanes take fewer entries each, down to 4
-    uint32_t per_lane = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_lane_entries, 1024) & ~3L);
+    // Longest run T of the accumulation.  When the buckets are many and small (entries / buckets <= 64: every product of 2^20 points
+    // and more at its automatic window) T = RUN_MAX, so that a bucket is ONE run and nothing is merged -- the lanes are then as many as
+    // the non-empty buckets.  Otherwise T = msm_run_entries (32): a bucket of z entries becomes ceil(z / 32) lanes.  A product with
+    // few entries (small circuits, the tails of a sharded proof) is a latency chain of T dependent additions on a fraction of the
+    // chip -- 32 additions over Fq2 are 0.6 ms whether 16 or 2^16 scalars are multiplied -- so its runs are shorter, down to 4.
+    uint32_t T = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_run_entries, RUN_MAX) & ~3L);
     const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
-    if (fill && entries / per_lane < fill) per_lane = (uint32_t)std::max<size_t>(4, std::min<size_t>(per_lane, entries / fill) & ~(size_t)3);
-    const size_t lanes = (entries + per_lane - 1) / per_lane;
-    // an accumulation that does not fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
-    if (lanes < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
+    if (entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill) T = RUN_MAX;
+    else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
+    // upper bounds: a bucket of z entries has ceil(z / T) <= 1 + z / T runs, of which all but the first take an extra image slot
+    const size_t max_extra = entries / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries) + max_extra;
+    // an accumulation that cannot fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
+    if (std::min(max_runs, entries / std::min<size_t>(T, 32) + 1) < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
     const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
     const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
+    const int run_wgs = (int)ceil_div(buckets, 256);
 
     ws.hist.ensure((size_t)chunks * bins);
     ws.total.ensure(bins);
@@ -794,15 +854,22 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
     ws.sorted.ensure(entries);
-    ws.partial.ensure((2 * lanes + (size_t)buckets) * sizeof(AccSlot<F>));
-    ws.bucket_sums.ensure((size_t)buckets * sizeof(AccSlot<F>));                           // S_b as accumulator images
+    if (!ws.runs_cnt.p) {   // cleared once; k_msm_runs_scan leaves it cleared
+        ws.runs_cnt.alloc(2 * (RUN_MAX + 2) + 2);
+        ZK_HIP(hipMemsetAsync(ws.runs_cnt.p, 0, ws.runs_cnt.bytes(), st));
+    }
+    uint32_t* const d_cursor = ws.runs_cnt.p + (RUN_MAX + 2);
+    uint32_t* const d_info = ws.runs_cnt.p + 2 * (RUN_MAX + 2);
+    ws.wg_extra.ensure(2 * (size_t)run_wgs);
+    uint32_t* const d_wg_xbase = ws.wg_extra.p + run_wgs;
+    ws.xbase.ensure(buckets);
+    ws.runs.ensure(max_runs * 4);
+    MsmRun* const d_runs = reinterpret_cast<MsmRun*>(ws.runs.p);
+    ws.bucket_sums.ensure(((size_t)buckets + max_extra) * sizeof(AccSlot<F>));              // S_b as accumulator images | extra runs
     const size_t half = ((size_t)buckets + 1) / 2, quarter = ((size_t)buckets + 3) / 4;
     ws.fold.ensure((2 * (half + quarter) + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // per chain: passes 1, 3, .. | passes 2, 4, ..; then C | R
     ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * sizeof(Jac<F>));   // terms | partial sums
     ws.heavy.ensure((size_t)buckets + 1);
-    AccSlot<F>* d_first = reinterpret_cast<AccSlot<F>*>(ws.partial.p);
-    AccSlot<F>* d_last = d_first + lanes;
-    AccSlot<F>* d_mid = d_last + lanes;
     AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
     AccSlot<F>* const fold_base = reinterpret_cast<AccSlot<F>*>(ws.fold.p);
     AccSlot<F>* d_tmp[4] = {fold_base, fold_base + half, fold_base + half + quarter, fold_base + 2 * half + quarter};
@@ -811,135 +878,75 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     Jac<F>* d_seg = reinterpret_cast<Jac<F>*>(ws.seg_sums.p);
     const double pt_bytes = (double)sizeof(Aff<F>);
 
-    // The counting sort may run on another stream than the product's own (ws.sort_stream, typically the caller's main stream,
-    // where the scalars were just produced): on the product's stream it queues behind the reduction tail of the PREVIOUS proof's
-    // product, and the G2 tail -- 4 ms under the following accumulations -- ended so late that the chip idled 0.6 ms per proof
-    // waiting for the next G2 sort.
-    hipStream_t const own_st = st;
-    if (ws.sort_stream) st = ws.sort_stream;
-    // measurement aid (option ablate, bit 0): when the caller repeats the same scalars, the sorted list this workspace holds from
-    // the previous call is reused -- prices the whole sort in the pipelined prover.  Never set by the product.
-    const bool reuse_sort = (ctx->opt_ablate & 1) && ws.sorted_for == (uint64_t)entries * 31 + (uint64_t)buckets;
-    ws.sorted_for = (uint64_t)entries * 31 + (uint64_t)buckets;
+#ifdef ZK_MEASURE
+    // measurement aid (option ablate, bit 0; ZK_MEASURE builds only): when the caller repeats the same scalars, the sorted list this
+    // workspace holds from the previous call is reused -- prices the whole sort in the pipelined prover
+    const bool reuse_sort = (ctx->opt_ablate & 1) && ws.sorted_for == (uint64_t)entries * 31 + (uint64_t)buckets + ((uint64_t)T << 48);
+    ws.sorted_for = (uint64_t)entries * 31 + (uint64_t)buckets + ((uint64_t)T << 48);
+#else
+    const bool reuse_sort = false;
+#endif
     if (!reuse_sort) {
-    {
-        ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
-        hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
-                           (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p);
-    }
-    {
-        ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
-        hipLaunchKernelGGL(k_msm_bin_totals, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.total.p);
-        hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.bin_start.p, bins);
-        hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.bin_start.p);
-    }
-    {
-        ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
-                           sub_bits, (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p, ws.records.p);
-    }
-    {
-        ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
-        // ~2048 level-2 workgroups in all, dealt to the bins in proportion to their records (at least BIN_STAGE records each)
-        const int subs = 1 << sub_bits;
-        const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries + 2047) / 2048);
-        const unsigned grid2 = (unsigned)(entries / target + 1) + (unsigned)bins;   // >= sum_b max(1, ceil(len_b / target))
-        ws.bin_cnt.ensure((size_t)grid2 * subs);
-        ws.part_start.ensure((size_t)bins + 1);
-        const int three = (ctx->opt_three_level_bits > 0 && sub_bits >= ctx->opt_three_level_bits) ? 1 : 0;
-        if (three) {
-            // Three levels: with 2^10 and more sub-buckets per bin a stage of 8192 records leaves runs of 4..8 entries per sub-bucket
-            // (16..32-byte stores) and a 2048-counter scan per stage.  The sub-bucket field is split: its high half sorts the bin's
-            // records into 2^hi groups (8-byte records again, runs of ~256), its low half then sorts every (bin, group) -- ~3 k
-            // records, one stage -- into the final 4-byte entries (runs of ~50).  Both passes keep the records' order, as the
-            // accumulation wants it.
-            const int lo_want = (int)std::max<long>(1, std::min<long>(ctx->opt_three_level_low, sub_bits - 1));
-            const int lo_bits = lo_want, hi_bits = sub_bits - lo_bits, subs_a = 1 << hi_bits, subs_b = 1 << lo_bits;
-            const int bins2 = bins * subs_a;
-            const unsigned grid2b = (unsigned)(entries / target + 1) + (unsigned)bins2;
-            ws.bin_cnt.ensure(std::max((size_t)grid2 * subs_a, (size_t)grid2b * subs_b));
-            ws.records2.ensure(entries);
-            ws.bin_start2.ensure((size_t)bins2 + 1);
-            ws.part_start2.ensure((size_t)bins2 + 1);
-            hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
-            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs_a * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, hi_bits, lo_bits, ws.bin_cnt.p);
-            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, hi_bits, ws.bin_start2.p);
-            hipLaunchKernelGGL(k_msm_bin_scatter_rec, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 10 + (size_t)subs_a * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p,
-                               bins, hi_bits, lo_bits, ws.bin_cnt.p, ws.records2.p);
-            hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start2.p, bins2, target, ws.part_start2.p);
-            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2b), dim3(SORT2_THREADS), (size_t)subs_b * 4, st, ws.records2.p, ws.bin_start2.p, ws.part_start2.p, bins2, lo_bits, 0, ws.bin_cnt.p);
-            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins2), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start2.p, ws.part_start2.p, bins2, lo_bits, ws.start.p);
-            hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2b), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs_b * 12, st, ws.records2.p, ws.bin_start2.p, ws.part_start2.p,
-                               bins2, lo_bits, 0, ws.bin_cnt.p, ws.sorted.p);
-        } else {
-        hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
-        hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, 0, ws.bin_cnt.p);
-        hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
-        if (ctx->opt_direct_subs > 0 && sub_bits >= ctx->opt_direct_subs)
-            hipLaunchKernelGGL(k_msm_bin_scatter_direct, dim3(grid2), dim3(BINS_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
-                               sub_bits, ws.bin_cnt.p, ws.sorted.p);
-        else
-        hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
-                           sub_bits, 0, ws.bin_cnt.p, ws.sorted.p);
+        {
+            ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
+            hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
+                               (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p);
         }
-    }
-    }
-    if (ws.sort_stream) {
-        if (!ws.sorted_evt) ZK_HIP(hipEventCreateWithFlags(&ws.sorted_evt, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(ws.sorted_evt, st));
-        st = own_st;
-        ZK_HIP(hipStreamWaitEvent(st, ws.sorted_evt, 0));
+        {
+            ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
+            hipLaunchKernelGGL(k_msm_bin_totals, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.total.p);
+            hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.total.p, ws.bin_start.p, bins);
+            hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.bin_start.p);
+        }
+        {
+            ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
+            hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+                               sub_bits, (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p, ws.records.p);
+        }
+        {
+            ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
+            // ~2048 level-2 workgroups in all, dealt to the bins in proportion to their records (at least BIN_STAGE records each)
+            const int subs = 1 << sub_bits;
+            const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries + 2047) / 2048);
+            const unsigned grid2 = (unsigned)(entries / target + 1) + (unsigned)bins;   // >= sum_b max(1, ceil(len_b / target))
+            ws.bin_cnt.ensure((size_t)grid2 * subs);
+            ws.part_start.ensure((size_t)bins + 1);
+            hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
+            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
+            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
+            hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
+                               sub_bits, ws.bin_cnt.p, ws.sorted.p);
+        }
+        {
+            ProfScope ps(ctx, "msm_runs", 8.0 * buckets + 12.0 * max_runs, st);
+            hipLaunchKernelGGL(k_msm_runs_count, dim3(run_wgs), dim3(256), 0, st, ws.start.p, buckets, T, ws.runs_cnt.p, ws.wg_extra.p);
+            hipLaunchKernelGGL(k_msm_runs_scan, dim3(1), dim3(1024), 0, st, ws.runs_cnt.p, d_cursor, ws.wg_extra.p, d_wg_xbase, run_wgs, d_info);
+            hipLaunchKernelGGL(k_msm_runs_emit, dim3(run_wgs), dim3(256), 0, st, ws.start.p, buckets, T, d_cursor, d_wg_xbase, d_runs, ws.xbase.p);
+        }
     }
     {
         // algorithmic bytes as SURVEY.md 8(d) prices an inner product: one 32-byte scalar and one affine point per (scalar, point)
         // pair -- 96 B in G1, 160 B in G2 -- whatever the window count.  (What this implementation actually gathers is W times
-        // that: a 4-byte index and a 64 / 128-byte table entry per window and pair, plus one parked image per lane; bench.py
+        // that: a 4-byte index and a 64 / 128-byte table entry per window and pair, plus one image per run; bench.py
         // reports that figure and the PMC-measured traffic beside the 8(d) number.)
-        // All bucket accumulations of a context run in submission order on ONE low-priority stream (ws.acc_stream), the sort before
-        // and the reduction tail after it on the product's own stream at a higher priority: the accumulation's thousands of pending
-        // workgroups then never stand in front of the short dependent kernels in the dispatcher.
-        hipStream_t ast = ws.acc_stream ? ws.acc_stream : st;
-        if (ws.acc_stream) {
-            if (!ws.sorted_evt) ZK_HIP(hipEventCreateWithFlags(&ws.sorted_evt, hipEventDisableTiming));
-            ZK_HIP(hipEventRecord(ws.sorted_evt, st));
-            ZK_HIP(hipStreamWaitEvent(ast, ws.sorted_evt, 0));
-        }
-        if (acc_wait) ZK_HIP(hipStreamWaitEvent(ast, acc_wait, 0));
+        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         {
-            ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, ast);
-            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(lanes, 256)), dim3(256), 0, ast, tab.table.p + point_offset, ws.sorted.p, ws.start.p, buckets, per_lane,
-                               d_first, d_last, d_mid);
+            ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, st);
+            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), 0, st, tab.table.p + point_offset, ws.sorted.p, d_runs, d_info, d_img);
         }
-        if (acc_done) ZK_HIP(hipEventRecord(acc_done, ast));
-        if (ws.acc_stream) {
-            if (!acc_done) {   // no caller event: reuse the workspace's
-                ZK_HIP(hipEventRecord(ws.sorted_evt, ast));
-                ZK_HIP(hipStreamWaitEvent(st, ws.sorted_evt, 0));
-            } else {
-                ZK_HIP(hipStreamWaitEvent(st, acc_done, 0));
-            }
-        }
-    }
-    // The reduction tail runs on its own stream when the caller provides one (ws.tail_stream): on `st` it would sit in front of
-    // the NEXT proof's sort of this product, and under the following accumulations the 150..250-register tail kernels only get
-    // scheduled in the gaps -- the timeline showed the G2 tail of proof k-1 ending 1.6 ms into proof k, its sort starting only
-    // then and the chip idling 0.9 ms per proof for it.
-    if (ws.tail_stream && acc_done) {
-        ZK_HIP(hipStreamWaitEvent(ws.tail_stream, acc_done, 0));
-        st = ws.tail_stream;
+        if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     }
     {
-        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (lanes + 5.0 * buckets), st);
+        ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (max_extra + 5.0 * buckets), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
-        // heavy buckets are outliers when the average bucket spans few lanes (a small grid that mostly finds nothing
-        // to do); with few buckets and many entries (small windows) nearly every bucket is heavy
-        // (a narrow top window makes 2^(top bits) buckets heavy at once -- 64..128 at c = 19 -- so the small grid is not THAT small:
-        // surplus workgroups read the count and leave)
-        const unsigned heavy_grid = lanes / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, per_lane, d_first, d_last, d_mid, d_img, ws.heavy.p);
-        // column sums C[g][lo] (fold the row index, <= 16 images per lane and pass), then row sums R[g][hi] (fold the column index)
-        uint32_t FOLD = 2;   // images per lane and pass (msm_fold option), a power of two: the folded counts are
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p);
+        // heavy buckets are outliers when the average bucket is a few runs (a small grid that mostly finds nothing to do -- surplus
+        // workgroups read the count and leave; a narrow top window makes 2^(top bits) buckets heavy at once); with few buckets and many
+        // entries (small windows) nearly every bucket is heavy
+        const unsigned heavy_grid = entries / T / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
+        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p);
+        // column sums C[g][lo] (fold the row index, FOLD images per lane and pass), then row sums R[g][hi] (fold the column index)
+        uint32_t FOLD = 2;   // images per lane and pass (msm_fold option), a power of two
         while (FOLD * 2 <= (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64))) FOLD *= 2;
         // passes of the two chains, zipped: chain 0 = columns (count = rows, B = K, outer = groups), chain 1 = rows
         struct Chain { uint32_t count, B, outer; const AccSlot<F>* in; AccSlot<F>* fin; AccSlot<F>* tmp[2]; int tog; bool done; };
@@ -970,48 +977,6 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             hipLaunchKernelGGL(k_msm_sum_points<F>, dim3(1, groups), dim3(256), 256 * sizeof(Jac<F>), st, d_seg, terms, d_out, grp.out_stride);
         }
     }
-#ifdef ZK_MSM_SELFCHECK
-    if (groups == 1) {
-        // debugging aid (never in the product build): recompute the tail on the host from the device's bucket images
-        ZK_HIP(hipStreamSynchronize(st));
-        std::vector<AccSlot<F>> h_img(buckets), h_C(K), h_R(rows);
-        Jac<F> h_out;
-        ZK_HIP(hipMemcpy(h_img.data(), d_img, sizeof(AccSlot<F>) * buckets, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(h_C.data(), d_C, sizeof(AccSlot<F>) * K, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(h_R.data(), d_R, sizeof(AccSlot<F>) * rows, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(&h_out, d_out, sizeof(Jac<F>), hipMemcpyDeviceToHost));
-        auto same = [](const Jac<F>& a, const Jac<F>& b) {
-            if (a.is_inf() || b.is_inf()) return a.is_inf() && b.is_inf();
-            Aff<F> x = jac_to_affine(a), y = jac_to_affine(b);
-            return x.x == y.x && x.y == y.y;
-        };
-        int badC = 0, badR = 0, nonempty = 0;
-        for (int b = 0; b < buckets; ++b) nonempty += !h_img[b].a.inf;
-        for (int lo = 0; lo < K; ++lo) {
-            auto acc = h_img[lo].a;
-            for (int hi = 1; hi < rows; ++hi) acc = acc_add(acc, h_img[(size_t)hi * K + lo].a);
-            if (!same(acc_store(acc), acc_store(h_C[lo].a))) { if (badC < 4) fprintf(stderr, "  C[%d] differs (dev inf %d host inf %d)\n", lo, (int)h_C[lo].a.inf, (int)acc.inf); ++badC; }
-        }
-        for (int hi = 0; hi < rows; ++hi) {
-            auto acc = h_img[(size_t)hi * K].a;
-            for (int lo = 1; lo < K; ++lo) acc = acc_add(acc, h_img[(size_t)hi * K + lo].a);
-            if (!same(acc_store(acc), acc_store(h_R[hi].a))) { if (badR < 4) fprintf(stderr, "  R[%d] differs (dev inf %d host inf %d)\n", hi, (int)h_R[hi].a.inf, (int)acc.inf); ++badR; }
-        }
-        int badW = 0;
-        std::vector<Jac<F>> h_term(K + rows);
-        ZK_HIP(hipMemcpy(h_term.data(), d_seg, sizeof(Jac<F>) * (K + rows), hipMemcpyDeviceToHost));
-        JacR<F> total = jacr_load(Jac<F>::infinity());
-        for (int j = 0; j < K + rows; ++j) {
-            const JacR<F> t = j < K ? mul_small_lazy(jacr_load(acc_store(h_C[j].a)), (uint32_t)j)
-                                    : mul_small_lazy(jacr_load(acc_store(h_R[j - K].a)), ((uint32_t)(j - K) << kbits) + 1u);
-            if (!same(jacr_store(t), h_term[j])) { if (badW < 4) fprintf(stderr, "  term %d differs\n", j); ++badW; }
-            total = add_lazy(total, jacr_load(h_term[j]));
-        }
-        const bool okOut = same(jacr_store(total), h_out);
-        fprintf(stderr, "[selfcheck %s] c=%d buckets=%d nonempty=%d K=%d rows=%d: C bad %d, R bad %d, weighted bad %d, final %s\n", g2 ? "G2" : "G1", c, buckets, nonempty, K, rows,
-                badC, badR, badW, okOut ? "ok" : "BAD");
-    }
-#endif
     ZK_HIP(hipGetLastError());
     return st;
 }
@@ -1024,7 +989,6 @@ void msm_init_attributes() {
     static bool done = false;
     if (done) return;
     ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE * 6 + 2048 * 12));
-    ZK_HIP(hipFuncSetAttribute((const void*)k_msm_bin_scatter_rec, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_STAGE * 10 + 2048 * 12));
     done = true;
 }
 #endif  // ZK_MSM_COMMON
@@ -1051,7 +1015,7 @@ void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
         pts_to_mont<Aff<F>>(ctx, dp.p, dp.p, n, flag.p);
         fr_to_mont(ctx, ds.p, tmp.p, n, flag.p);   // range check of the scalars (digits use the canonical integers)
     }
-    int c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : msm_auto_window(n));
+    int c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : (sizeof(F) > sizeof(Fq) ? msm_auto_window_g2(n) : msm_auto_window(n)));
     MsmTable<F> tab;
     msm_build_table<F>(ctx, dp.p, n, c, tab);
     if (!ctx->msm_ws0) ctx->msm_ws0 = std::make_shared<MsmWorkspace>();

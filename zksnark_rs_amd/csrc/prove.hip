@@ -131,17 +131,6 @@ __device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms,
     if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
     if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
 }
-// One output point of the proof: which = 0: A (needs the A product), 1: B (the G2 product), 2: C (L and H + r B1 + s A).  A and B
-// are closed on their products' own streams as soon as these finish -- B's Fq2 inversion is the longest of the three and would
-// otherwise start only after the last product of the proof (0.15 ms of a lone proof's 1.2 ms at 16 gates).
-__global__ __launch_bounds__(64) void k_assemble_part(int which, const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
-                                                      const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
-    ZK_LATENCY_KERNEL();
-    if (threadIdx.x) return;
-    if (which == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
-    else if (which == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    else encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
-}
 __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
                                                   const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
     ZK_LATENCY_KERNEL();
@@ -266,21 +255,8 @@ struct StreamSwap {
     ~StreamSwap() { c->stream = saved; c->cur_slot = -1; }
 };
 
-// MSM stream k -> the stream of its reduction tail: one for the G2 product (k = 0), one shared by the three G1 products;
-// null (tail on the product's own stream) in the measurement mode and when the option msm_tail_streams is 0
-static hipStream_t tail_stream_for(zk_ctx* ctx, int k) {
-    if (ctx->opt_serialize || !ctx->opt_tail_streams) return nullptr;
-    return ctx->tail_stream[k == 0 ? 0 : 1];
-}
-
-// Stream of inner product k of the proof in slot `ticket`.  The G2 product (k = 0) alternates between two streams (index 3 is
-// free since B in G1 was folded into the H product): its reduction tail is the longest chain of a proof -- ~5 ms under the
-// following accumulations -- and on ONE stream the next proof's G2 sort waits behind it (sort + accumulation + tail of the G2
-// product came to ~10.3 ms of a 12 ms period, and the timeline showed the chip idle 0.9 ms per proof waiting for that sort).
-static hipStream_t msm_stream_for(zk_ctx* ctx, int k, int ticket) {
-    if (k == 0 && ctx->opt_alt_g2 && (ticket & 1)) return ctx->msm_stream[3];
-    return ctx->msm_stream[k];
-}
+// Stream of inner product k (0 = B in G2, 1 = L, 2 = A, 4 = H + r B1 + s A): its sort, its accumulation and its reduction tail
+static hipStream_t msm_stream_for(zk_ctx* ctx, int k) { return ctx->msm_stream[k]; }
 
 // The next submission takes the LOWEST free slot (not the next one in a ring): a caller that keeps d proofs in flight then only
 // ever touches d slots -- their buffers (2.5 GiB each at 2^20, allocated on first use) are allocated during the first d proofs
@@ -406,12 +382,9 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // instead of thrashing each other; sorting phases and reduction tails overlap freely.
     MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    const bool split_assembly = !d_partial_out && !xout && !ctx->opt_serialize && ctx->opt_split_assembly;   // a whole proof: A and B are closed beside the products
     auto launch_now = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out, hipStream_t ms_st) {
         ZK_HIP(hipStreamWaitEvent(ms_st, S.scal_evt[k], 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
-        S.ws[k].tail_stream = tail_stream_for(ctx, k);
-        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
         hipStream_t end_st;
         if (world > 1 && ctx->opt_shard_points) {
             // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
@@ -420,32 +393,28 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         } else {
             end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k]);
         }
-        if (split_assembly && (k == 0 || k == 2)) {
-            ZK_HIP(hipStreamWaitEvent(end_st, S.pre_evt, 0));
-            hipLaunchKernelGGL(k_assemble_part, dim3(1), dim3(64), 0, end_st, k == 2 ? 0 : 1, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
-            ZK_HIP(hipGetLastError());
-        }
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
     // The ~30 launches of an inner product are enqueued AFTER the whole SpMV / NTT stage (an event marks the point of the main
     // stream where its scalars exist): a lone proof of a small circuit is bound by the host's enqueue rate, and with the
     // products enqueued in between the stage's own 25 short kernels sat 2 ms apart on the timeline of a 2^16 proof.
-    std::vector<std::function<void()>> deferred;
-    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out) {
+    // They are enqueued in the order of the accumulation chain (option chain_order): every accumulation waits for the one before it.
+    std::vector<std::pair<int, std::function<void(int)>>> deferred;
+    auto launch = [&](int k, int, auto& table, const Fr* scalars, size_t count, auto* out) {
         if (xout) return;
-        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);   // serialize: measurement mode, no overlap at all
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.scal_evt[k], st));
-        // large circuits: the G2 product's sort goes onto the main stream, right behind the kernel that wrote its scalars (see
-        // msm_run); it is then enqueued in place, and so is L before it (the accumulation chain follows the call order)
-        const bool sort_on_main = !ctx->opt_serialize && ctx->opt_g2_sort_main && n >= ((size_t)1 << 18) && !d_partial_out;
-        S.ws[k].sort_stream = (sort_on_main && k == 0) ? st : nullptr;
-        if (!ctx->opt_serialize && ctx->opt_defer_msm && !(sort_on_main && (k == 0 || k == 1))) {
-            auto* tab = &table;
-            deferred.push_back([&, k, after, tab, scalars, count, out, ms_st] { launch_now(k, after, *tab, scalars, count, out, ms_st); });
-            return;
-        }
-        launch_now(k, after, table, scalars, count, out, ms_st);
+        auto* tab = &table;
+        deferred.emplace_back(k, [&, k, tab, scalars, count, out, ms_st](int after) { launch_now(k, after, *tab, scalars, count, out, ms_st); });
+    };
+    auto run_deferred = [&] {
+        static const int orders[2][4] = {{1, 0, 2, 4}, {1, 2, 0, 4}};   // MSM slots: 1 = L, 0 = B in G2, 2 = A, 4 = H + r B1 + s A
+        const int* order = orders[ctx->opt_chain_order == 1 ? 1 : 0];
+        int prev = -1;
+        for (int pos = 0; pos < 4; ++pos)
+            for (auto& d : deferred)
+                if (d.first == order[pos]) { d.second(prev); prev = d.first; }
     };
     if (!q.dense && q.roots) {
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
@@ -545,7 +514,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }
 
-    for (auto& f : deferred) f();
+    run_deferred();
     // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof.  A
     // scalars-only ticket completes on its own main stream: the finish stream may hold the join of an earlier ticket's
     // inner products, which would delay this one's completion by a whole round.
@@ -565,8 +534,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
         {
             ProfScope pscope(ctx, "assemble", 0, fin);
-            if (split_assembly) hipLaunchKernelGGL(k_assemble_part, dim3(1), dim3(64), 0, fin, 2, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
-            else hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
+            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
         }
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
@@ -613,7 +581,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
     // reduction tails (group j = proof j with its own 2^(c-1) buckets); chain L -> B2 -> A -> H as in a whole proof
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out) {
-        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
@@ -621,9 +589,6 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         const size_t valid = range(chunk, count, &lo);
         MsmGroups grp;
         grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        S.ws[k].tail_stream = tail_stream_for(ctx, k);
-        S.ws[k].sort_stream = nullptr;
-        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
         if (rt) lo = 0;   // the rank's table starts at its first point
         hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
@@ -698,15 +663,12 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     }
     MsmResults* ms = reinterpret_cast<MsmResults*>(S.b_partials.p);
     auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t glen, size_t valid, auto* out) {
-        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k, ticket);
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         MsmGroups grp;
         grp.groups = count; grp.glen = glen; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        S.ws[k].tail_stream = tail_stream_for(ctx, k);
-        S.ws[k].sort_stream = nullptr;
-        S.ws[k].acc_stream = (ctx->opt_serialize || !ctx->opt_acc_stream) ? nullptr : ctx->acc_stream;
         hipStream_t end_st = count == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k])
                                         : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
