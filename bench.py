@@ -323,8 +323,12 @@ def main():
             xp = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
             stream = lambda k: prove_exchange_stream(xp, None, 0, W, [(inst["r"], inst["s"])] * k)   # noqa: E731
         else:                              # the C pipeline (zk_mgpu_push / zk_mgpu_pop) over a loop-back transport
-            from zksnark_rs_amd.distributed import MgpuProver, loopback_comm
-            lb = loopback_comm(ctx, W)
+            from zksnark_rs_amd.distributed import Comm, MgpuProver, loopback_comm
+            if args.transport == "zk":     # the library's own loop-back (copies on the collectives' stream): stream-ordered hand-overs
+                os.environ["ZK_COMM_LOOPBACK"] = "1"
+                lb = Comm(ctx, 0, W, bytes(zk.COMM_ID_BYTES) if hasattr(zk, "COMM_ID_BYTES") else bytes(128))
+            else:                          # zk-gloo: a caller's transport (Python callbacks), hand-overs through the host
+                lb = loopback_comm(ctx, W)
             mp = MgpuProver(ctx, lb, inst["crs"], inst["qap"])
             stream = lambda k: mp.prove_stream([(d_w.data_ptr(), m, inst["r"], inst["s"])] * k, ahead=2)   # noqa: E731
         for _ in stream(args.warmup):
@@ -336,7 +340,8 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         free_b, total_b = torch.cuda.mem_get_info()
-        print(json.dumps({"diagnostic": "rank 0 of a %d-way scalar-exchange prover (local copies instead of the all-to-alls)" % W,
+        print(json.dumps({"diagnostic": "rank 0 of a %d-way scalar-exchange prover (local copies instead of the all-to-alls; %s)"
+                                        % (W, "stream-ordered hand-overs" if args.transport == "zk" else "hand-overs through the host"),
                           "ms_per_round_per_rank": round(dt * 1e3, 3), "implied_proofs_per_s_at_%d_gpus" % W: round(W / dt, 2),
                           "hbm_in_use_GiB": round((total_b - free_b) / 2**30, 2)}))
         return

@@ -345,6 +345,66 @@ def test_scalar_exchange_full_size_2_20(ctx, orc):
         assert ctx.prove_combine(crs, gathered.data_ptr(), world, r, s) == want[j], j
 
 
+def test_window_sharded_full_size_2_20(ctx, orc):
+    """BASELINE configs[4] as it is worded: the 2^20 proof with the Pippenger WINDOWS of every inner product sharded over the ranks
+    (rank g accumulates the windows w = g mod world; msm_shard_points = 0), worlds 2 and 8 played on one device, the all-gather
+    replaced by writing into one buffer: zk_prove_combine of the partial sums == the closed-form trapdoor proof."""
+    torch = pytest.importorskip("torch")
+    inst = chain_instance(ctx, 20, 2021)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    want = orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
+    dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
+    ctx.set_option("msm_shard_points", 0)
+    try:
+        for world in (2, 8):
+            buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            for rank in range(world):
+                ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+            torch.cuda.synchronize()
+            assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want, world
+    finally:
+        ctx.set_option("msm_shard_points", 0)
+
+
+def test_mgpu_pipeline_stream_ordered(ctx, orc, monkeypatch):
+    """zk_mgpu over the library's own transport (one rank: copies on the collectives' stream): the stages are handed over by events,
+    tickets are released without waiting, a pop is the round's one host synchronisation.  Same bytes as zk_prove and as the
+    host-synchronous hand-over (ZK_MGPU_HOST_HANDOVER=1); a witness element >= r fails ITS pop only and the pipeline goes on."""
+    torch = pytest.importorskip("torch")
+    from zksnark_rs_amd.distributed import Comm, MgpuProver
+    inst = chain_instance(ctx, 12, 77)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    rng = zk.SplitMix64(78)
+    jobs_rs = [(rng.fr(), rng.fr()) for _ in range(7)]
+    want = [ctx.prove(crs, inst["qap"], inst["weights"], r, s) for r, s in jobs_rs]
+    dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
+    bad = inst["weights"].copy()
+    bad[5] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)   # >= r
+    dbad = torch.from_numpy(bad.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    for host_handover in ("0", "1"):
+        if host_handover == "1":
+            monkeypatch.setenv("ZK_MGPU_HOST_HANDOVER", "1")
+        comm = Comm(ctx, 0, 1)
+        mp = MgpuProver(ctx, comm, crs, inst["qap"])
+        got = list(mp.prove_stream([(dw.data_ptr(), inst["m"], r, s) for r, s in jobs_rs], ahead=2))
+        assert got == want, host_handover
+        got = list(mp.prove_stream([(dw.data_ptr(), inst["m"], r, s) for r, s in jobs_rs[:2]], ahead=0))
+        assert got == want[:2], host_handover
+        if host_handover == "0":
+            # proof 1 of 3 has a witness element out of range: its pop reports it, the others are unaffected
+            for k, d in enumerate((dw, dbad, dw)):
+                mp.push(d.data_ptr(), inst["m"], *jobs_rs[k])
+            assert mp.pop() == want[0]
+            with pytest.raises(zk.ZkError) as e:
+                mp.pop()
+            assert e.value.status == -6
+            assert mp.pop() == want[2]
+            assert list(mp.prove_stream([(dw.data_ptr(), inst["m"], r, s) for r, s in jobs_rs[3:5]], ahead=1)) == want[3:5]
+        mp.close()
+        comm.close()
+
+
 @pytest.mark.parametrize("window_bits", [4, 7, 12, 18])
 def test_prove_batch_window_sizes(orc, window_bits):
     """Grouped inner products (batches) with forced Pippenger windows from 4 to 18 bits: 2^3 .. 2^17 buckets per group,

@@ -29,6 +29,7 @@ struct zk_comm {
     bool custom = false;
     zk_comm_ops ops{};
     ncclComm_t nccl = nullptr;
+    bool loopback = false;          // TIMING ONLY (ZK_COMM_LOOPBACK=1): several ranks played by device-to-device copies on this stream
     hipStream_t stream = nullptr;   // collectives run here, never on the compute streams
     int* d_flag = nullptr;          // barrier / max-reduce scratch (device)
 };
@@ -48,6 +49,15 @@ struct zk_mgpu {
     std::deque<Round> rounds;       // pushed and not yet popped, oldest first
     size_t first = 0;               // round number of rounds.front()
     std::string last_error;
+    bool failed = false;            // a stage or a collective failed: the pipeline state is unknown, every later call is refused
+    // stream-ordered hand-overs (the library's own GPU stages over the library's own transport, see inner_products): events of round
+    // k at index k % 3 -- scalars written, scalars exchanged, inner products done -- and the pinned landing places of the range flag
+    // and of the proof
+    bool ordered = false;
+    hipEvent_t ev_scal[3] = {}, ev_a2a[3] = {}, ev_msm[3] = {};
+    bool a2a_recorded[3] = {};
+    int* h_flag = nullptr;          // 3 ints, pinned
+    uint8_t* h_proof = nullptr;     // ZK_PROOF_BYTES, pinned
 };
 
 namespace zk {
@@ -64,8 +74,8 @@ static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
         return;
     }
-    if (!c->nccl) {   // one rank, no communicator
-        ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->nccl) {   // one rank, no communicator (loopback: the copies a `world`-rank exchange would receive, same sizes)
+        ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank * (c->loopback ? (size_t)c->world : 1), hipMemcpyDeviceToDevice, c->stream));
         return;
     }
     // chunk g of d_send goes to rank g; chunk j of d_recv comes from rank j.  xGMI is point to point (7 links per GPU): the
@@ -82,7 +92,11 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
         return;
     }
-    if (!c->nccl) { ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream)); return; }
+    if (!c->nccl) {
+        for (int g = 0; g < (c->loopback ? c->world : 1); ++g)
+            ZK_HIP(hipMemcpyAsync((uint8_t*)d_recv + (size_t)g * bytes_per_rank, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
+        return;
+    }
     ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->nccl, c->stream));
 }
 static void comm_sync(zk_comm* c) {
@@ -130,11 +144,38 @@ static int gpu_combine(void* u, const void* part_recv, int world, const uint64_t
 static void be_check(zk_mgpu* g, int rc, const char* what) {
     if (rc != 0) throw StatusError{rc, std::string("zk_mgpu: ") + what + " failed"};
 }
+//
+// Hand-overs between the stages.  With a caller's transport or caller's stages (the gloo / CPU stand-in tests) they go through the
+// host: wait for the ticket, run the collective, wait for it, submit the next stage.  With the library's own stages over the
+// library's own transport (g->ordered) nothing between A, B and F blocks the host: the collectives' stream waits for an event
+// recorded behind the scalars, the inner products' streams wait for an event recorded behind the all-to-alls, the partial-sum
+// exchange and the assembly follow the inner products' event on the collectives' stream, and the scalars of round k + 2 wait for the
+// exchange of round k (which reads the send buffers they overwrite).  Tickets are released as soon as their work is enqueued
+// (prove_release); the one host synchronisation of a round is at the end of zk_mgpu_pop, which returns the proof bytes.
 static void inner_products(zk_mgpu* g, size_t k) {
     zk_mgpu::Round& R = g->rounds[k - g->first];
     if (R.ip_done) return;
     const int set = (int)(k & 1), world = g->comm->world;
+    if (g->ordered) {
+        zk_comm* c = g->comm;
+        zk_ctx* ctx = g->gpu->ctx;
+        const int e = (int)(k % 3);
+        ZK_HIP(hipStreamWaitEvent(c->stream, g->ev_scal[e], 0));
+        for (int a = 0; a < 4; ++a) comm_all_to_all(c, g->send[set][a], g->recv[set][a], g->elems[a] / world * 32);
+        ZK_HIP(hipEventRecord(g->ev_a2a[e], c->stream));
+        g->a2a_recorded[e] = true;
+        ctx->submit_wait_evt = g->ev_a2a[e];
+        const int rc = g->be.msm_submit(g->be.user, world, c->rank, world, g->recv[set], g->part_send[set], &R.t_msm);
+        ctx->submit_wait_evt = nullptr;
+        be_check(g, rc, "msm_submit");
+        ZK_HIP(hipEventRecord(g->ev_msm[e], prove_ticket_stream(ctx, R.t_msm)));
+        prove_release(ctx, R.t_msm, nullptr);
+        R.t_msm = -1;
+        R.ip_done = true;
+        return;
+    }
     be_check(g, g->be.wait(g->be.user, R.t_scalars), "wait (scalars)");
+    R.t_scalars = -1;
     for (int a = 0; a < 4; ++a) comm_all_to_all(g->comm, g->send[set][a], g->recv[set][a], g->elems[a] / world * 32);
     comm_sync(g->comm);
     be_check(g, g->be.msm_submit(g->be.user, world, g->comm->rank, world, g->recv[set], g->part_send[set], &R.t_msm), "msm_submit");
@@ -187,12 +228,24 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
     if (!c) return ZK_ERR_HIP;
     c->ctx = ctx; c->rank = rank; c->world = world;
     int rc = comm_guard(c, nullptr, [&] {
-        ZK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // The collectives' stream is created at the HIGH priority level.  Streams of one level share ~4 hardware queues, and a fifth
+        // stream of a level serialises with another: the mid level holds the four inner-product streams, and of the
+        // high level's main, alternate main, side and finish streams the side stream has no work in the multi-GPU pipeline (the
+        // assembly of a round runs on THIS stream, behind the partial-sum exchange) -- so four streams of the level are in use
+        // whatever the mode.  RCCL's send / receive kernels are then dispatched ahead of pending accumulation workgroups.
+        int prio_least = 0, prio_greatest = 0;
+        ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        ZK_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
         ZK_HIP(hipMalloc((void**)&c->d_flag, 64));
         // ZK_COMM_FORCE_RCCL=1: a one-rank communicator too goes through RCCL (self send / recv, all-gather, all-reduce) -- the
         // only way to execute this file's RCCL calls on a one-GPU box (tests/test_gpu_bench.py)
         const char* force = std::getenv("ZK_COMM_FORCE_RCCL");
-        if (world > 1 || (force && force[0] == '1' && id)) {
+        // ZK_COMM_LOOPBACK=1 (bench.py --emulate-world): rank 0 of `world` ranks with copies in place of the collectives -- one rank's
+        // work of a `world`-GPU run through the same code path (stream-ordered hand-overs included); the proofs are NOT valid
+        const char* loop = std::getenv("ZK_COMM_LOOPBACK");
+        if (world > 1 && loop && loop[0] == '1' && rank == 0) {
+            c->loopback = true;
+        } else if (world > 1 || (force && force[0] == '1' && id)) {
             ZK_HIP(hipSetDevice(ctx->device));
             ncclUniqueId nid;
             std::memcpy(nid.internal, id, ZK_COMM_ID_BYTES);
@@ -295,6 +348,19 @@ static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, z
             ZK_REQUIRE(g->part_send[set] && g->part_recv[set], ZK_ERR_HIP, "zk_mgpu: buffer allocation failed");
         }
     });
+    if (rc == ZK_OK && gpu && !c->custom && c->stream && !std::getenv("ZK_MGPU_HOST_HANDOVER")) {
+        rc = comm_guard(c, &g->last_error, [&] {
+            for (int e = 0; e < 3; ++e) {
+                ZK_HIP(hipEventCreateWithFlags(&g->ev_scal[e], hipEventDisableTiming));
+                ZK_HIP(hipEventCreateWithFlags(&g->ev_a2a[e], hipEventDisableTiming));
+                ZK_HIP(hipEventCreateWithFlags(&g->ev_msm[e], hipEventDisableTiming));
+            }
+            ZK_HIP(hipHostMalloc((void**)&g->h_flag, 3 * sizeof(int)));
+            ZK_HIP(hipHostMalloc((void**)&g->h_proof, ZK_PROOF_BYTES));
+            std::memset(g->h_flag, 0, 3 * sizeof(int));
+            g->ordered = true;
+        });
+    }
     if (rc != ZK_OK) { zk_mgpu_destroy(g); return rc; }
     *out = g;
     return ZK_OK;
@@ -315,10 +381,19 @@ int zk_mgpu_create_custom(zk_comm* c, const zk_mgpu_backend* be, zk_mgpu** out) 
 
 void zk_mgpu_destroy(zk_mgpu* g) {
     if (!g) return;
-    for (auto& R : g->rounds) {   // tickets still in flight
-        if (R.t_msm >= 0) (void)g->be.wait(g->be.user, R.t_msm);
-        else if (R.t_scalars >= 0 && !R.ip_done) (void)g->be.wait(g->be.user, R.t_scalars);
+    if (g->gpu) {   // whatever is still enqueued (released tickets, collectives) must end before the buffers go
+        (void)hipSetDevice(g->gpu->ctx->device);
+        (void)hipDeviceSynchronize();
     }
+    for (auto& R : g->rounds) {   // tickets still held
+        if (R.t_msm >= 0) (void)g->be.wait(g->be.user, R.t_msm);
+        if (R.t_scalars >= 0) (void)g->be.wait(g->be.user, R.t_scalars);
+    }
+    for (int e = 0; e < 3; ++e)
+        for (hipEvent_t ev : {g->ev_scal[e], g->ev_a2a[e], g->ev_msm[e]})
+            if (ev) (void)hipEventDestroy(ev);
+    if (g->h_flag) (void)hipHostFree(g->h_flag);
+    if (g->h_proof) (void)hipHostFree(g->h_proof);
     for (int set = 0; set < 2; ++set) {
         for (int a = 0; a < 4; ++a) {
             if (g->send[set][a]) g->be.free(g->be.user, g->send[set][a]);
@@ -334,18 +409,36 @@ const char* zk_mgpu_last_error(const zk_mgpu* g) { return g ? g->last_error.c_st
 
 static int mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4], bool host) {
     if (!g || !d_weights || !r || !s) return ZK_ERR_ARG;
-    return comm_guard(g->comm, &g->last_error, [&] {
-        ZK_REQUIRE(g->rounds.size() < 3, ZK_ERR_ARG, "zk_mgpu_push: three rounds in flight (call zk_mgpu_pop first)");
+    if (g->failed) { g->last_error = "zk_mgpu: an earlier stage or collective failed; destroy the prover"; return ZK_ERR_COMM; }
+    if (g->rounds.size() >= 3) { g->last_error = "zk_mgpu_push: three rounds in flight (call zk_mgpu_pop first)"; return ZK_ERR_ARG; }
+    const int rc = comm_guard(g->comm, &g->last_error, [&] {
         const size_t k = g->first + g->rounds.size();
-        // the send buffers of set k % 2 were last used by round k - 2: its exchange must be complete (it normally is, from push(k - 1))
+        // the send buffers of set k % 2 were last used by round k - 2: its exchange must be issued (it normally is, from push(k - 1))
         if (g->rounds.size() >= 2) inner_products(g, k - 2);
         zk_mgpu::Round R;
         std::memcpy(R.r, r, 32); std::memcpy(R.s, s, 32);
         if (g->gpu) g->gpu->host_witness = host;
-        be_check(g, g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars), "scalars_submit");
+        if (g->ordered) {
+            zk_ctx* ctx = g->gpu->ctx;
+            const int e = (int)(k % 3), e2 = (int)((k + 1) % 3);   // (k - 2) % 3 == (k + 1) % 3
+            // ... and complete before the scalars of this round overwrite what it sends: ordered on the device, not by the host
+            if (k >= 2 && g->a2a_recorded[e2]) ctx->submit_wait_evt = g->ev_a2a[e2];
+            const int st = g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars);
+            ctx->submit_wait_evt = nullptr;
+            be_check(g, st, "scalars_submit");
+            ZK_HIP(hipEventRecord(g->ev_scal[e], prove_ticket_stream(ctx, R.t_scalars)));
+            prove_release(ctx, R.t_scalars, &g->h_flag[e]);
+            R.t_scalars = -1;
+        } else {
+            be_check(g, g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars), "scalars_submit");
+        }
         g->rounds.push_back(R);
         if (g->rounds.size() >= 2) inner_products(g, k - 1);   // A(k), then B(k - 1): the scalars run ahead of the inner products
     });
+    // A failed stage leaves tickets, buffers and -- worst -- the other ranks' collectives in an unknown state: the prover refuses
+    // every later call (the peers block in their collective until the caller tears the job down; RCCL has no poison message).
+    if (rc != ZK_OK) g->failed = true;
+    return rc;
 }
 
 int zk_mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t r[4], const uint64_t s[4]) {
@@ -359,21 +452,39 @@ int zk_mgpu_push_host(zk_mgpu* g, const uint64_t* weights, size_t m, const uint6
 
 int zk_mgpu_pop(zk_mgpu* g, uint8_t proof_out[ZK_PROOF_BYTES]) {
     if (!g || !proof_out) return ZK_ERR_ARG;
-    return comm_guard(g->comm, &g->last_error, [&] {
-        ZK_REQUIRE(!g->rounds.empty(), ZK_ERR_ARG, "zk_mgpu_pop: nothing pushed");
+    if (g->failed) { g->last_error = "zk_mgpu: an earlier stage or collective failed; destroy the prover"; return ZK_ERR_COMM; }
+    if (g->rounds.empty()) { g->last_error = "zk_mgpu_pop: nothing pushed"; return ZK_ERR_ARG; }
+    const int rc = comm_guard(g->comm, &g->last_error, [&] {
         const size_t k = g->first;
         // the collectives must be issued in round order on every rank: B(k), then B(k+1) if it was pushed, then F(k)
         inner_products(g, k);
         if (g->rounds.size() >= 2) inner_products(g, k + 1);
         zk_mgpu::Round R = g->rounds.front();
         const int set = (int)(k & 1), world = g->comm->world;
+        if (g->ordered) {
+            zk_comm* c = g->comm;
+            const int e = (int)(k % 3);
+            ZK_HIP(hipStreamWaitEvent(c->stream, g->ev_msm[e], 0));
+            comm_all_to_all(c, g->part_send[set], g->part_recv[set], ZK_PARTIAL_BYTES);
+            prove_combine_on(g->gpu->ctx, *g->gpu->crs, g->part_recv[set], world, R.r, R.s, c->stream, g->h_proof);
+            ZK_HIP(hipStreamSynchronize(c->stream));   // the round's one host synchronisation
+            g->rounds.pop_front();
+            g->first = k + 1;
+            g->gpu->ctx->resolve_profile(-2);
+            ZK_REQUIRE(!g->h_flag[e], ZK_ERR_RANGE, "prove: witness element >= r");
+            std::memcpy(proof_out, g->h_proof, ZK_PROOF_BYTES);
+            return;
+        }
         be_check(g, g->be.wait(g->be.user, R.t_msm), "wait (inner products)");
+        g->rounds.front().t_msm = -1;
         comm_all_to_all(g->comm, g->part_send[set], g->part_recv[set], ZK_PARTIAL_BYTES);
         comm_sync(g->comm);
         g->rounds.pop_front();
         g->first = k + 1;
         be_check(g, g->be.combine(g->be.user, g->part_recv[set], world, R.r, R.s, proof_out), "combine");
     });
+    if (rc != ZK_OK && rc != ZK_ERR_RANGE) g->failed = true;   // a witness out of range fails its own proof only: the round completed on every rank
+    return rc;
 }
 
 }  // extern "C"

@@ -91,6 +91,7 @@ struct zk_ctx {
     hipStream_t finish = nullptr;  // join + assembly + copy-out of a proof
     hipStream_t main_alt = nullptr;  // second main stream: odd-numbered proof slots run their SpMV / NTT stage here
     std::shared_ptr<zk::ProveState> prove_state;
+    hipEvent_t submit_wait_evt = nullptr;   // consumed by the next prove_submit / prove_msm_submit: its first kernels wait for this event (comm.hip)
     int cur_slot = -1;
     std::string last_error;
     long opt_window_bits = 0;
@@ -128,6 +129,7 @@ struct zk_ctx {
         std::vector<zk::PendingEvent> keep;
         for (auto& pe : pending) {
             if (slot >= -1 && pe.slot != slot) { keep.push_back(pe); continue; }
+            if (hipEventQuery(pe.e1) != hipSuccess) { keep.push_back(pe); continue; }   // still in flight (a slot released without waiting)
             float ms = 0;
             if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
                 auto& e = prof[pe.name];

@@ -125,6 +125,12 @@ int prove_msm_submit(zk_ctx*, const zk_crs&, const zk_qap&, int sets, int rank, 
 int prove_submit_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t* r, const uint64_t* s,
                       int world = 1, Fr* const* xout = nullptr);
 void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
+// stream-ordered use of tickets (comm.hip): the stream a ticket completes on, and release of its slot WITHOUT waiting (h_flag_pinned,
+// may be null: where the witness range flag of a scalars ticket is copied once the ticket is complete)
+hipStream_t prove_ticket_stream(zk_ctx*, int ticket);
+void prove_release(zk_ctx*, int ticket, int* h_flag_pinned);
+// prove_combine without the host synchronisation: everything on `st`, the proof lands in h_proof_pinned
+void prove_combine_on(zk_ctx*, const zk_crs&, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], hipStream_t st, uint8_t* h_proof_pinned);
 int prove_batch_submit(zk_ctx*, const zk_crs&, const zk_qap&, int count, const void* const* d_weights, const size_t* m,
                        const uint64_t* r, const uint64_t* s);
 void prove_batch_wait(zk_ctx*, int ticket, int count, uint8_t* proofs_out);

@@ -202,6 +202,7 @@ struct ProveSlot {
     hipEvent_t fork_evt = nullptr, pre_evt = nullptr, done_evt = nullptr;
     hipEvent_t msm_done[zk_ctx::MSM_STREAMS] = {}, acc_evt[zk_ctx::MSM_STREAMS] = {}, scal_evt[zk_ctx::MSM_STREAMS] = {};
     bool busy = false, partial = false;
+    hipStream_t fin_stream = nullptr;   // the stream done_evt was recorded on
     void init() {
         ms.alloc(1); as.alloc(1); d_proof.alloc(ZK_PROOF_BYTES); flag.alloc(1);
         ZK_HIP(hipMemset(ms.p, 0, sizeof(MsmResults)));   // `spare` is never written but travels with the partial sums
@@ -365,6 +366,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     S.batch = 0;
     S.partial = d_partial_out != nullptr || xout != nullptr;
 
+    if (ctx->submit_wait_evt) { ZK_HIP(hipStreamWaitEvent(st, ctx->submit_wait_evt, 0)); ctx->submit_wait_evt = nullptr; }
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
     S.a_mont.ensure(std::max<size_t>(a_len, 1));
     fr_to_mont(ctx, d_weights, S.a_mont.p, a_len, S.flag.p);
@@ -541,6 +543,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     }
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.fin_stream = fin;
     S.busy = true;
     ctx->cur_slot = -1;
     pick_next_slot(ps);
@@ -576,6 +579,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         *lo = std::min(g * c, count);
         return std::min(c, count - *lo);
     };
+    if (ctx->submit_wait_evt) { ZK_HIP(hipStreamWaitEvent(st, ctx->submit_wait_evt, 0)); ctx->submit_wait_evt = nullptr; }
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
     ZK_HIP(hipMemsetAsync(d_partials_out, 0, (size_t)sets * ZK_PARTIAL_BYTES, st));
     // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
@@ -610,6 +614,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
             if (k != 3) ZK_HIP(hipStreamWaitEvent(fin, S.msm_done[k], 0));
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.fin_stream = fin;
     S.busy = true;
     ctx->cur_slot = -1;
     pick_next_slot(ps);
@@ -752,6 +757,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ZK_HIP(hipMemcpyAsync(S.h_b_proofs, S.b_proofs.p, (size_t)count * ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
+    S.fin_stream = fin;
     S.batch = count;
     S.busy = true;
     ctx->cur_slot = -1;
@@ -787,6 +793,26 @@ void prove_wait(zk_ctx* ctx, int ticket, uint8_t* proof_out) {
     if (!S.partial && proof_out) std::memcpy(proof_out, S.h_proof, ZK_PROOF_BYTES);
 }
 
+hipStream_t prove_ticket_stream(zk_ctx* ctx, int ticket) {
+    ProveState& ps = prove_state(ctx);
+    ZK_REQUIRE(ticket >= 0 && ticket < ProveState::SLOTS && ps.slot[ticket].busy, ZK_ERR_ARG, "prove: no proof in flight for this ticket");
+    return ps.slot[ticket].fin_stream;
+}
+
+// Frees the slot of a ticket whose work is enqueued but not necessarily complete.  Safe because of the stream discipline of this
+// file: whatever a later ticket on the same slot enqueues goes onto the same main stream (slot parity), the same inner-product
+// streams and the same finish stream as this ticket's work, behind it.  The caller orders its own consumers with an event it records
+// on prove_ticket_stream().
+void prove_release(zk_ctx* ctx, int ticket, int* h_flag_pinned) {
+    ProveState& ps = prove_state(ctx);
+    ZK_REQUIRE(ticket >= 0 && ticket < ProveState::SLOTS && ps.slot[ticket].busy, ZK_ERR_ARG, "prove: no proof in flight for this ticket");
+    ProveSlot& S = ps.slot[ticket];
+    ZK_REQUIRE(S.batch == 0, ZK_ERR_ARG, "prove_release: batch ticket");
+    if (h_flag_pinned) ZK_HIP(hipMemcpyAsync(h_flag_pinned, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, S.fin_stream));
+    S.busy = false;
+    pick_next_slot(ps);
+}
+
 void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
                uint8_t* proof_out, int rank, int world, void* d_partial_out) {
     int t = prove_submit(ctx, crs, qap, d_weights, m, r, s, rank, world, d_partial_out, nullptr);
@@ -814,20 +840,26 @@ void prove_host(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const uint64_
     prove_wait(ctx, t, proof_out);
 }
 
-void prove_combine(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
+void prove_combine_on(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], hipStream_t st,
+                      uint8_t* h_proof_pinned) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
     ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
     crs_ensure_fixed_tables(ctx, crs);
     ProveState& ps = prove_state(ctx);
-    // on the side stream: a pipelined caller has the next proofs' stages queued on the main streams already, and the
-    // finish stream holds their joins (it would make this proof's assembly wait for the NEXT proof's inner products)
-    hipStream_t st = ctx->side;
     launch_pre(ctx, crs, st, rc, sc, ps.comb_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, ps.comb_ms.p);
     hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.comb_proof.p);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipMemcpyAsync(ps.comb_h_proof, ps.comb_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(h_proof_pinned, ps.comb_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+}
+
+void prove_combine(zk_ctx* ctx, const zk_crs& crs, const void* d_partials, int world, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out) {
+    ProveState& ps = prove_state(ctx);
+    // on the side stream: a pipelined caller has the next proofs' stages queued on the main streams already, and the
+    // finish stream holds their joins (it would make this proof's assembly wait for the NEXT proof's inner products)
+    hipStream_t st = ctx->side;
+    prove_combine_on(ctx, crs, d_partials, world, r, s, st, ps.comb_h_proof);
     ZK_HIP(hipStreamSynchronize(st));
     std::memcpy(proof_out, ps.comb_h_proof, ZK_PROOF_BYTES);
 }
