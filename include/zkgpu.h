@@ -162,6 +162,16 @@ void zk_qap_free(zk_qap* qap);
 /* Dimensions of a device QAP, and its dense coefficient matrices back on the host (dense form only;
  * any pointer may be NULL = skip).  Layout as zk_qap_upload_dense. */
 int zk_qap_dims(const zk_qap* qap, size_t* n, size_t* m, size_t* input, int* dense);
+/* Which device form a QAP handle holds (a container read by zk_qap_load does not say otherwise): 0 = sparse rows over the roots of
+ * unity w^j, n = 2^k (zk_qap_upload_sparse); 1 = the dense m x n coefficient matrices of QAP<CoefficientPoly<FrLocal>>
+ * (groth16/mod.rs:60-67; zk_qap_upload_dense, zk_circuit_qap); 2 = sparse rows over the integers 1..n, the roots ASTParser emits
+ * (circuit/mod.rs:517; zk_qap_upload_sparse_integers). */
+int zk_qap_kind(const zk_qap* qap);
+/* The first stage of groth16::prove on its own (diagnostic entry point of the parity tests): u_sum = sum_i qap.u[i] * weights[i]
+ * (groth16/mod.rs:233-253 -- zip with the weights, CoefficientPoly: Mul<T> coefficient_poly.rs:132-146, Sum :75-91); which = 0 / 1 / 2
+ * for u / v / w.  Dense form: out = the n coefficients of the sum.  Sparse forms: out = its n values on the QAP's domain (w^j or
+ * j + 1, j < n), u and v only (the prover never evaluates W).  4 words per element, canonical; weights beyond m_qap are ignored. */
+int zk_qap_weighted_sum(zk_ctx* ctx, const zk_qap* qap, const uint64_t* weights, size_t m, int which, uint64_t* out);
 int zk_qap_download_dense(zk_ctx* ctx, const zk_qap* qap, uint64_t* u, uint64_t* v, uint64_t* w, uint64_t* t);
 
 /* ------------------------------------------------------------------------------------------

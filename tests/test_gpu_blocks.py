@@ -6,11 +6,15 @@ exp_encrypted_test fr.rs:240-246), Sum/Add for G1Local/G2Local (fr.rs:175-223),
 field::dft/idft (field/mod.rs:508-537; reference tests dft_test/idft_test :606-635),
 the SigmaG1/SigmaG2 inner products of prove (mod.rs:255-272).
 """
+import os
+
 import numpy as np
 import pytest
 
 import zksnark_rs_amd as zk
-from zksnark_rs_amd import SplitMix64, ints_to_limbs, R_MODULUS, Q_MODULUS
+from zksnark_rs_amd import SplitMix64, ints_to_limbs, limbs_to_int, R_MODULUS, Q_MODULUS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -230,3 +234,64 @@ def test_msm_linearity_large(ctx, orc):
     sa, sb = ctx.msm_g1(p1, a), ctx.msm_g1(p1, b)
     sab = ctx.msm_g1(p1, ctx.fr_batch("add", a, b))
     assert np.array_equal(ctx.g1_add_batch(sa.reshape(1, 8), sb.reshape(1, 8))[0], sab)
+
+
+# ---- the first stage of prove on its own: u_sum = sum_i qap.u[i] * weights[i] ------------------------------------------
+def _weighted_sum_dense(mat, weights):
+    """Restatement of the reference's fold (groth16/mod.rs:233-253): zip(qap.u, weights) -- the shorter one ends it --, every
+    polynomial scaled by its weight (Mul<T>, coefficient_poly.rs:132-146) and the results summed coefficient-wise (Sum, :75-91)."""
+    m, n = mat.shape[0], mat.shape[1]
+    acc = [0] * n
+    for i in range(min(m, weights.shape[0])):
+        a = limbs_to_int(weights[i])
+        for j in range(n):
+            acc[j] = (acc[j] + a * limbs_to_int(mat[i, j])) % zk.R_MODULUS
+    return ints_to_limbs(acc).reshape(n, 4)
+
+
+@pytest.mark.parametrize("prog", ["simple.zk", "deg_15.zk"])
+def test_dense_matvec_block(ctx, orc, prog):
+    """k_dense_matvec alone (zk_qap_weighted_sum) on the reference's own programs: u_sum, v_sum, w_sum == the fold restated above,
+    with a witness of exactly m, fewer and more than m elements (zip truncation)."""
+    code = open(os.path.join(ROOT, "tests", "golden", "zk", prog)).read()
+    q = orc.zk_qap_dense(code)
+    qap = ctx.qap_dense(q["u"], q["v"], q["w"], q["t"], q["input"])
+    rng = zk.SplitMix64(233)
+    for count in (q["m"], q["m"] - 2, q["m"] + 3, 1):
+        wts = ints_to_limbs([rng.fr() for _ in range(count)]).reshape(count, 4)
+        for which, key in enumerate(("u", "v", "w")):
+            assert np.array_equal(ctx.qap_weighted_sum(qap, wts, which), _weighted_sum_dense(q[key], wts)), (prog, count, key)
+    zero = np.zeros((q["m"], 4), dtype=np.uint64)
+    assert not ctx.qap_weighted_sum(qap, zero, 0).any()
+
+
+@pytest.mark.parametrize("roots", ["unity", "integers"])
+def test_spmv_block(ctx, roots):
+    """k_spmv alone: the values of u_sum and v_sum on the QAP's domain == sum over the rows' (wire, gate, value) entries, restated
+    here, for random sparse rows (wires that feed many gates, empty wires, repeated (wire, gate) entries) over both domains."""
+    rng = zk.SplitMix64(253)
+    n, m, l = (64, 150, 3) if roots == "unity" else (50, 150, 3)
+
+    def rows():
+        ptr, gate, val = [0], [], []
+        for wire in range(m):
+            cnt = 0 if wire % 7 == 3 else (n if wire == 5 else rng.next() % 5)
+            for _ in range(cnt):
+                gate.append(rng.next() % n)
+                val.append(rng.fr())
+            ptr.append(len(gate))
+        return (np.array(ptr, dtype=np.uint64), np.array(gate, dtype=np.uint32), ints_to_limbs(val).reshape(-1, 4) if val else np.zeros((0, 4), np.uint64))
+
+    u, v, w = rows(), rows(), rows()
+    qap = ctx.qap_sparse(6, m, l, u, v, w) if roots == "unity" else ctx.qap_sparse_integers(n, m, l, u, v, w)
+    for count in (m, m - 5, m + 2):
+        wts = ints_to_limbs([rng.fr() for _ in range(count)]).reshape(count, 4)
+        for which, (ptr, gate, val) in enumerate((u, v)):
+            acc = [0] * n
+            for wire in range(min(m, count)):
+                a = limbs_to_int(wts[wire])
+                for e in range(int(ptr[wire]), int(ptr[wire + 1])):
+                    acc[gate[e]] = (acc[gate[e]] + a * limbs_to_int(val[e])) % zk.R_MODULUS
+            assert np.array_equal(ctx.qap_weighted_sum(qap, wts, which), ints_to_limbs(acc).reshape(n, 4)), (roots, count, which)
+    with pytest.raises(zk.ZkError):
+        ctx.qap_weighted_sum(qap, wts, 2)        # W is not held by gate in the sparse forms

@@ -7,6 +7,8 @@ test_oracle_kats) and, up to BASELINE's 2^20, against the closed-form trapdoor p
 """
 import os
 
+import sys
+
 import numpy as np
 import pytest
 
@@ -535,6 +537,29 @@ def test_crs_file_round_trip(ctx, orc, tmp_path):
         with pytest.raises(zk.ZkError) as e:
             ctx.crs_upload(n, m, l, bad)
         assert e.value.status == RANGE, (key, e.value.status)
+
+
+@pytest.mark.parametrize("log_n", [6, 13])
+def test_crs_upload_refuses_g2_points_outside_the_subgroup(ctx, log_n):
+    """a point ON the twist but outside the order-r subgroup (composite cofactor 2q - r) in xi_g2 / a single G2 element is
+    refused (small-subgroup leak of witness scalars through B = sum v_k P_k).  2^6 points: every point multiplied by r;
+    2^13 points: two random linear combinations through an MSM (crs.hip g2_subgroup_check)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_verify import twist_point_outside_g2
+    inst = chain_instance(ctx, log_n, 900 + log_n)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    arrs = ctx.crs_download(crs)
+    n, m, l = inst["n"], inst["m"], inst["l"]
+    assert ctx.crs_upload(n, m, l, arrs) is not None            # the genuine CRS passes
+    P = twist_point_outside_g2(31 + log_n)
+    words = ints_to_limbs([P[0][0], P[0][1], P[1][0], P[1][1]]).reshape(16)
+    for key, idx in (("xi_g2", n // 2), ("xi_g2", 0), ("delta_g2", 0)):
+        bad = {k: (None if v is None else np.array(v, copy=True)) for k, v in arrs.items()}
+        bad[key].reshape(-1, 16)[idx] = words
+        with pytest.raises(zk.ZkError) as e:
+            ctx.crs_upload(n, m, l, bad)
+        assert e.value.status == -6, (key, idx, e.value.status)
 
 
 def test_pipelined_submit_wait(ctx, orc):

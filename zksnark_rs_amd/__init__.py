@@ -324,6 +324,14 @@ class Context:
         c.n, c.m, c.input = n, m, input
         return c
 
+    def qap_weighted_sum(self, qap, weights, which):
+        """sum_i weights[i] * u_i / v_i / w_i (which = 0 / 1 / 2; mod.rs:233-253): coefficients (dense QAP) or values on the domain
+        (sparse QAP, u and v only) as an (n, 4) uint64 array."""
+        w, wp = _u64(np.asarray(weights).reshape(-1, 4))
+        out = np.zeros((qap.n, 4), dtype=np.uint64)
+        self._check(self.lib.zk_qap_weighted_sum(self.ptr, qap.ptr, wp, w.shape[0], which, out.ctypes.data_as(_lib.u64p)))
+        return out
+
     def qap_save(self, qap, path):
         """Write the QAP container (zk_qap_save): sparse rows or dense matrices."""
         self._check(self.lib.zk_qap_save(self.ptr, qap.ptr, str(path).encode()))
@@ -335,8 +343,10 @@ class Context:
         n, m, l, dense = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
         self._check(self.lib.zk_qap_dims(p, C.byref(n), C.byref(m), C.byref(l), C.byref(dense)))
         q.n, q.m, q.input, q.dense = n.value, m.value, l.value, bool(dense.value)
-        if not q.dense:
-            q.log_n = q.n.bit_length() - 1
+        kind = self.lib.zk_qap_kind(p)
+        q.roots = "integers" if kind == 2 else ("unity" if kind == 0 else None)
+        if kind == 0:
+            q.log_n = q.n.bit_length() - 1      # roots of unity: n = 2^log_n
         return q
 
     def crs_save(self, crs, path):

@@ -93,6 +93,8 @@ SIGNATURES = {
     "zk_qap_upload_dense": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_free": (None, [C.c_void_p]),
     "zk_qap_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "zk_qap_kind": (C.c_int, [C.c_void_p]),
+    "zk_qap_weighted_sum": (C.c_int, [C.c_void_p, C.c_void_p, u64p, C.c_size_t, C.c_int, u64p]),
     "zk_qap_download_dense": (C.c_int, [C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p]),
     "zk_circuit_parse": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "zk_circuit_free": (None, [C.c_void_p]),

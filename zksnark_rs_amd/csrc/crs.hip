@@ -2,6 +2,7 @@
 // upload, download, the bit-reversed copies used by the roots-of-unity pipeline, and
 // groth16::setup (/root/reference/src/groth16/mod.rs:134-197) on the GPU with the trapdoor
 // injected (the reference draws it from thread_rng, mod.rs:139-145).
+#include <random>
 #include "pipeline.hpp"
 
 namespace zk {
@@ -15,6 +16,60 @@ static void up_points(zk_ctx* ctx, DevBuf<A>& d, const uint64_t* src, size_t cou
     ZK_HIP(hipMemcpyAsync(d.p, src, count * sizeof(A), hipMemcpyHostToDevice, ctx->stream));
     pts_to_mont<A>(ctx, d.p, d.p, count, d_flag);
     pts_check_on_curve<A>(ctx, d.p, count, d_flag);
+}
+
+// ---- uploaded G2 points must lie in the r-torsion subgroup --------------------------------------------------
+// The twist E'(Fq2) has order r (2q - r) with 2q - r = 10069 . 5864401 . 1875725156269 . (a 181-bit prime): an on-curve point
+// with a component of small order d would make B = sum v_k P_k leak v_k mod d (small-subgroup attack on the witness scalars).
+// Single points and short arrays are multiplied by r one by one; a long array is checked through two random linear combinations
+// sum rho_i P_i (64-bit rho_i, one MSM each) whose result is multiplied by r: a component outside the subgroup survives a
+// combination with probability >= 1 - 1 / 10069, so two independent ones miss it with probability < 1e-8.
+__global__ void k_random_scalars64(uint64_t seed, Fr* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);     // SplitMix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    Fr k = Fr::zero();
+    k.l[0] = (uint32_t)z | 1u;
+    k.l[1] = (uint32_t)(z >> 32);
+    out[i] = k;
+}
+// flag |= 8 unless r * P is infinity; one point per lane (Jacobian input: stride 1) or per affine point
+template <class P>
+__global__ void k_g2_times_r(const P* __restrict__ pts, size_t n, int* flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G2J p;
+    if constexpr (sizeof(P) == sizeof(G2A)) { if (pts[i].is_inf()) return; p = G2J::from_affine(reinterpret_cast<const G2A*>(pts)[i]); }
+    else p = reinterpret_cast<const G2J*>(pts)[i];
+    uint32_t r[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) r[w] = FrParams::P[w];
+    if (!jac_mul_words(p, r).is_inf()) atomicOr(flag, 8);
+}
+static void g2_subgroup_check(zk_ctx* ctx, const G2A* d_pts, size_t n, int* d_flag) {
+    if (!n) return;
+    if (n <= 4096) {
+        hipLaunchKernelGGL(k_g2_times_r<G2A>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, d_pts, n, d_flag);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+    std::random_device rd;
+    MsmTable<Fq2> tab;
+    msm_build_table<Fq2>(ctx, d_pts, n, msm_auto_window_g2(n), tab);
+    DevBuf<Fr> rho(n);
+    DevBuf<G2J> sum(2);
+    MsmWorkspace ws;
+    for (int trial = 0; trial < 2; ++trial) {
+        const uint64_t seed = ((uint64_t)rd() << 32) | rd();
+        hipLaunchKernelGGL(k_random_scalars64, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, seed, rho.p, n);
+        msm_run<Fq2>(ctx, ws, ctx->stream, tab, rho.p, n, 0, 1, sum.p + trial);
+    }
+    hipLaunchKernelGGL(k_g2_times_r<G2J>, dim3(1), dim3(64), 0, ctx->stream, sum.p, (size_t)2, d_flag);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // the table and the workspace go out of scope
 }
 
 zk_crs* crs_upload(zk_ctx* ctx, const zk_crs_desc& d) {
@@ -42,6 +97,13 @@ zk_crs* crs_upload(zk_ctx* ctx, const zk_crs_desc& d) {
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     ZK_REQUIRE(!(h & 2), ZK_ERR_RANGE, "zk_crs_upload: coordinate >= q");
     ZK_REQUIRE(!(h & 4), ZK_ERR_RANGE, "zk_crs_upload: point not on the curve");
+    g2_subgroup_check(ctx, c->beta2.p, 1, flag.p);
+    g2_subgroup_check(ctx, c->gamma2.p, 1, flag.p);
+    g2_subgroup_check(ctx, c->delta2.p, 1, flag.p);
+    g2_subgroup_check(ctx, c->xi2.p, d.n, flag.p);
+    ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_REQUIRE(!(h & 8), ZK_ERR_RANGE, "zk_crs_upload: G2 point outside the subgroup of order r");
     return c.release();
 }
 
@@ -94,6 +156,10 @@ void crs_attach_lagrange(zk_ctx* ctx, zk_crs& c, const uint64_t* lag1, const uin
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     ZK_REQUIRE(!(h & 2), ZK_ERR_RANGE, "zk_crs_load: coordinate >= q");
     ZK_REQUIRE(!(h & 4), ZK_ERR_RANGE, "zk_crs_load: point not on the curve");
+    g2_subgroup_check(ctx, c.lag2.p, c.n, flag.p);
+    ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(hipStreamSynchronize(ctx->stream));
+    ZK_REQUIRE(!(h & 8), ZK_ERR_RANGE, "zk_crs_load: G2 point outside the subgroup of order r");
     c.ap = true;
 }
 

@@ -135,11 +135,14 @@ ZK_NI Aff<F> jac_to_affine(const Jac<F>& p) {
     return Aff<F>{p.X * zi2, p.Y * zi2 * zi};
 }
 
-// the same with the data-dependent inversion (ff.cuh inv_vartime): for single-lane callers
+// The same with the data-dependent inversion (ff.cuh inv_vartime), for single-lane callers.  Z depends on the witness (it is a
+// product of the differences met along the addition chain) and cannot be recovered from the affine point, so it is NOT public: what is
+// inverted is Z * lambda for a fresh uniformly random lambda != 0 the caller supplies, whose distribution -- and with it the trip
+// count of the Euclidean loop -- is independent of Z; 1 / Z = lambda / (Z lambda).
 template <class F>
-ZK_NI Aff<F> jac_to_affine_vartime(const Jac<F>& p) {
+ZK_NI Aff<F> jac_to_affine_vartime(const Jac<F>& p, const F& lambda) {
     if (p.is_inf()) return Aff<F>::infinity();
-    F zi = p.Z.inv_vartime();
+    F zi = (p.Z * lambda).inv_vartime() * lambda;
     F zi2 = zi.sqr();
     return Aff<F>{p.X * zi2, p.Y * zi2 * zi};
 }

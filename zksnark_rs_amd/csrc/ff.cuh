@@ -292,9 +292,10 @@ struct alignas(16) Fp {
     }
     // The same inverse by the binary extended Euclid for an odd modulus (Handbook of Applied Cryptography 14.61): about
     // 1.4 x 254 rounds of shifts and subtractions on eight words, ~25 k instructions where Fermat's 255 squarings + 127
-    // multiplications take ~130 k.  The trip count depends on the value (no secret here: the inverted Z coordinates are
-    // public once the proof is), so this is for single-lane uses -- the three inversions that close a proof -- and not for
-    // whole waves, whose lanes would all wait for the slowest one.
+    // multiplications take ~130 k.  The trip count depends on the VALUE, so a caller with a secret operand blinds it first
+    // (ec.cuh jac_to_affine_vartime: the Z coordinates that close a proof are multiplied by a fresh random factor), and this is
+    // for single-lane uses -- the three inversions that close a proof -- not for whole waves, whose lanes would all wait for the
+    // slowest one.
     ZK_HD Fp inv_vartime() const {
         if (is_zero()) return zero();
         uint32_t u[8], v[8], x1[8], x2[8];

@@ -100,7 +100,8 @@ void pts_from_mont(zk_ctx* ctx, const A* in, A* out, size_t n) {
 }
 // flag |= 4 when a finite point (Montgomery form) does not satisfy y^2 = x^3 + b.  b is passed in Montgomery form:
 // 3 for G1, 3 / (9 + i) for the twist (zk_crs_upload / zk_crs_load: a CRS is not trusted to be on the curve --
-// an off-curve base would leak witness scalars through the inner products, invalid-curve style).
+// an off-curve base would leak witness scalars through the inner products, invalid-curve style).  G1 has prime order; for the G2
+// arrays being on the twist is not enough (composite cofactor): crs.hip g2_subgroup_check multiplies them by r as well.
 template <class A, class F>
 __global__ void k_pts_on_curve(const A* __restrict__ pts, size_t n, F b, int* flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -542,4 +542,15 @@ int zk_qap_dims(const zk_qap* qap, size_t* n, size_t* m, size_t* input, int* den
     return ZK_OK;
 }
 
+int zk_qap_weighted_sum(zk_ctx* ctx, const zk_qap* qap, const uint64_t* weights, size_t m, int which, uint64_t* out) {
+    if (!ctx || !qap) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { qap_weighted_sum(ctx, *qap, weights, m, which, out); });
+}
+
+/* 0: sparse rows over the roots of unity w^j (n = 2^k), 1: dense coefficient matrices, 2: sparse rows over the integers 1..n */
+int zk_qap_kind(const zk_qap* qap) {
+    if (!qap) return ZK_ERR_ARG;
+    return qap->dense ? 1 : (qap->roots ? 2 : 0);
+}
+
 }  // extern "C"

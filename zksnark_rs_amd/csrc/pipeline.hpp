@@ -91,6 +91,7 @@ Fr ap_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
 void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can, size_t count = 1, size_t hb_stride = 0);
 zk_qap* qap_upload_dense(zk_ctx*, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t, size_t m, size_t n, size_t input);
 void qap_free(zk_qap*);
+void qap_weighted_sum(zk_ctx*, const zk_qap&, const uint64_t* weights, size_t m, int which, uint64_t* out);   // qap.hip
 void qap_save(zk_ctx*, const zk_qap&, const char* path);      // serialize.hip
 zk_qap* qap_load(zk_ctx*, const char* path);
 void proof_save(const uint8_t proof[ZK_PROOF_BYTES], const char* path);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <random>
 #include <vector>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
@@ -99,18 +100,22 @@ __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
         out[4 * i + 3] = (uint8_t)w;
     }
 }
-__device__ void encode_g1(const G1J& p, uint8_t* out) {
+// Blinding factors of the three inversions that close a proof (ec.cuh jac_to_affine_vartime): fresh per proof, drawn on the host by
+// the library itself -- they do not change the proof bytes, so the (r, s)-determinism of the ABI is untouched.
+struct AssembleBlind { Fq a; Fq2 b; Fq c; };
+
+__device__ void encode_g1(const G1J& p, const Fq& lambda, uint8_t* out) {
     for (int i = 0; i < 65; ++i) out[i] = 0;
     if (p.is_inf()) return;
-    G1A a = jac_to_affine_vartime(p);   // one lane per wave is active here
+    G1A a = jac_to_affine_vartime(p, lambda);   // one lane per wave is active here
     out[0] = 4;
     put_be32(a.x, out + 1);
     put_be32(a.y, out + 33);
 }
-__device__ void encode_g2(const G2J& p, uint8_t* out) {
+__device__ void encode_g2(const G2J& p, const Fq2& lambda, uint8_t* out) {
     for (int i = 0; i < 129; ++i) out[i] = 0;
     if (p.is_inf()) return;
-    G2A a = jac_to_affine_vartime(p);
+    G2A a = jac_to_affine_vartime(p, lambda);
     out[0] = 4;
     put_be32(a.x.c1, out + 1);
     put_be32(a.x.c0, out + 33);
@@ -124,24 +129,27 @@ __device__ void encode_g2(const G2J& p, uint8_t* out) {
 // where H + r B1 + s A comes out of ONE inner product: scalars h_i over xi_t and (r v_i + s u_i) over
 // xi.  No scalar multiplication with a run-time base is left.
 __device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const G1A* __restrict__ alpha1,
-                                              const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
+                                              const G2A* __restrict__ beta2, const AssembleBlind& bl, uint8_t* __restrict__ proof) {
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x & 63) return;
-    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), proof);
-    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), proof + 65);
-    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), proof + 65 + 129);
+    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), bl.a, proof);
+    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), bl.b, proof + 65);
+    if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), bl.c, proof + 65 + 129);
 }
 __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
-                                                  const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proof) {
+                                                  const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, AssembleBlind bl, uint8_t* __restrict__ proof) {
     ZK_LATENCY_KERNEL();
-    assemble_body(ms, pre, alpha1, beta2, proof);
+    assemble_body(ms, pre, alpha1, beta2, bl, proof);
 }
 
 // batch form: workgroup j assembles proof j from blob j of the partial sums
 __global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre,
-                                                        const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, uint8_t* __restrict__ proofs) {
+                                                        const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, AssembleBlind bl, uint8_t* __restrict__ proofs) {
     ZK_LATENCY_KERNEL();
-    assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, alpha1, beta2,
+    // one draw per batch, made different for every proof of it (bl . (j + 1): still uniform, still unknown)
+    const Fq j1 = Fq::from_u32(blockIdx.x + 1);
+    bl.a = bl.a * j1; bl.b = Fq2{bl.b.c0 * j1, bl.b.c1 * j1}; bl.c = bl.c * j1;
+    assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, alpha1, beta2, bl,
                   proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES);
 }
 
@@ -232,6 +240,19 @@ struct ProveSlot {
 };
 struct ProveState {
     static constexpr int SLOTS = ZK_MAX_IN_FLIGHT;
+    std::mt19937_64 rng{std::random_device{}()};   // blinding factors only (AssembleBlind); never anything that reaches the proof bytes
+    AssembleBlind draw_blind() {
+        auto fq = [&] {
+            Fq x;
+            for (int i = 0; i < 4; ++i) { const uint64_t w = rng(); x.l[2 * i] = (uint32_t)w; x.l[2 * i + 1] = (uint32_t)(w >> 32); }
+            x.l[7] &= 0x0fffffffu;   // < 2^252 < q: a valid residue whatever form it is read in
+            x.l[0] |= 1u;            // never zero
+            return x;
+        };
+        AssembleBlind b;
+        b.a = fq(); b.b = Fq2{fq(), fq()}; b.c = fq();
+        return b;
+    }
     ProveSlot slot[SLOTS];
     int next = 0;
     hipEvent_t last_acc = nullptr;   // end of the most recently enqueued accumulation chain
@@ -536,7 +557,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
         {
             ProfScope pscope(ctx, "assemble", 0, fin);
-            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, S.d_proof.p);
+            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), S.d_proof.p);
         }
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
@@ -751,7 +772,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
     {
         ProfScope pscope(ctx, "assemble", 0, fin);
-        hipLaunchKernelGGL(k_assemble_batch, dim3(count), dim3(192), 0, fin, S.b_partials.p, S.b_pre.p, crs.alpha1.p, crs.beta2.p, S.b_proofs.p);
+        hipLaunchKernelGGL(k_assemble_batch, dim3(count), dim3(192), 0, fin, S.b_partials.p, S.b_pre.p, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), S.b_proofs.p);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(S.h_b_proofs, S.b_proofs.p, (size_t)count * ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
@@ -849,7 +870,7 @@ void prove_combine_on(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, 
     ProveState& ps = prove_state(ctx);
     launch_pre(ctx, crs, st, rc, sc, ps.comb_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, ps.comb_ms.p);
-    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.comb_proof.p);
+    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), ps.comb_proof.p);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(h_proof_pinned, ps.comb_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
 }

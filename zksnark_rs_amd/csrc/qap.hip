@@ -328,4 +328,27 @@ void poly_divide_newton(zk_ctx* ctx, const zk_qap& q, const Fr* r, size_t len_r,
     reverse_prefix(ctx, work, K, K, out, K);
 }
 
+// sum_i a_i P_i for P = u / v / w (groth16/mod.rs:233-253: zip with the weights, Mul<T>, Sum): the first stage of prove on its own.
+// Dense form: the n coefficients (k_dense_matvec).  Sparse forms: the n values on the QAP's domain (k_spmv over the rows by gate;
+// u and v only -- W is never evaluated by the prover, see prove.hip).  Canonical output on the host.
+void qap_weighted_sum(zk_ctx* ctx, const zk_qap& q, const uint64_t* weights, size_t m_in, int which, uint64_t* out) {
+    ZK_REQUIRE(weights && out && which >= 0 && which <= 2, ZK_ERR_ARG, "zk_qap_weighted_sum: bad argument");
+    ZK_REQUIRE(q.dense || which < 2, ZK_ERR_UNSUPPORTED, "zk_qap_weighted_sum: a sparse QAP holds only u and v by gate");
+    const size_t a_len = std::min(m_in, q.m);   // zip truncates
+    DevBuf<Fr> a(std::max<size_t>(a_len, 1)), res(q.n);
+    DevBuf<int> flag(1);
+    hipStream_t st = ctx->stream;
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    if (a_len) ZK_HIP(hipMemcpyAsync(a.p, weights, a_len * sizeof(Fr), hipMemcpyHostToDevice, st));
+    fr_to_mont(ctx, a.p, a.p, a_len, flag.p);
+    if (q.dense) dense_matvec(ctx, which == 0 ? q.du.p : which == 1 ? q.dv.p : q.dw.p, a.p, a_len, q.n, res.p);
+    else spmv(ctx, which == 0 ? q.u_gate : q.v_gate, a.p, a_len, res.p);
+    fr_from_mont(ctx, res.p, res.p, q.n);
+    int h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(out, res.p, q.n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_qap_weighted_sum: weight >= r");
+}
+
 }  // namespace zk

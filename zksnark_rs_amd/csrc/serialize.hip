@@ -75,6 +75,16 @@ void crs_save(zk_ctx* ctx, const zk_crs& crs, const char* path) {
     ZK_REQUIRE(ok, ZK_ERR_IO, std::string("crs_save: short write to ") + path);
 }
 
+// bytes left in the file behind the current position (the loaders size their buffers from header fields: a 72-byte file must not
+// be able to ask for tens of GB)
+static uint64_t bytes_left(std::FILE* f) {
+    const long at = std::ftell(f);
+    if (at < 0 || std::fseek(f, 0, SEEK_END) != 0) return 0;
+    const long end = std::ftell(f);
+    (void)std::fseek(f, at, SEEK_SET);
+    return end > at ? (uint64_t)(end - at) : 0;
+}
+
 zk_crs* crs_load(zk_ctx* ctx, const char* path) {
     File f(std::fopen(path, "rb"));
     ZK_REQUIRE(f.f, ZK_ERR_IO, std::string("crs_load: cannot open ") + path);
@@ -84,7 +94,9 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
     const size_t n = head[1], m = head[2], input = head[3];
     ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << 26) && m >= input + 1 && m <= ((size_t)1 << 28), ZK_ERR_IO, "crs_load: implausible dimensions in the header");
     Layout lay(n, m, input);
-    std::vector<uint64_t> buf(lay.words() + (v2 ? 8 * n + 8 * (n - 1) + 16 * n : 0));
+    const size_t crs_words = lay.words() + (v2 ? 8 * n + 8 * (n - 1) + 16 * n : 0);
+    ZK_REQUIRE(bytes_left(f.f) >= (uint64_t)crs_words * 8, ZK_ERR_IO, "crs_load: file is truncated");
+    std::vector<uint64_t> buf(crs_words);
     ZK_REQUIRE(std::fread(buf.data(), 8, buf.size(), f.f) == buf.size(), ZK_ERR_IO, "crs_load: file is truncated");
     uint8_t extra;
     ZK_REQUIRE(std::fread(&extra, 1, 1, f.f) == 0, ZK_ERR_IO, "crs_load: trailing bytes after the payload");
@@ -181,6 +193,7 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
         ZK_REQUIRE(head[2] >= 1 && head[2] <= ((uint64_t)1 << 22) && m * head[2] <= ((uint64_t)1 << 33), ZK_ERR_IO, "qap_load: implausible header");
         words = (3 * m * head[2] + head[2] + 1) * 4;
     }
+    ZK_REQUIRE(bytes_left(f.f) >= (uint64_t)words * 8, ZK_ERR_IO, "qap_load: file is truncated");
     std::vector<uint64_t> buf(words);
     ZK_REQUIRE(std::fread(buf.data(), 8, words, f.f) == words, ZK_ERR_IO, "qap_load: file is truncated");
     uint8_t extra;
