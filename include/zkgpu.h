@@ -61,13 +61,15 @@ int zk_ctx_create(int device_ordinal, zk_ctx** out);
 void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
-/* Tunables: "msm_window_bits" (Pippenger c; 0 = auto), "msm_lane_entries" (additions per lane of the
- * bucket accumulation, a multiple of 4; default 32), "profile" (0/1: per-kernel
- * event timing, read back with zk_profile_*), "msm_shard_points" (zk_prove_partial: 0 = a rank owns
- * Pippenger windows, 1 = a rank owns a range of the points), "dense_long_division" (1: the dense form always divides
- * by t with the reference's long division; default 0 = power-series inverse above 512 quotient coefficients),
- * "serialize" (0/1: measurement mode, all kernels of a proof on
- * one stream so that event timings are stand-alone durations).  Unknown keys return ZK_ERR_UNSUPPORTED. */
+/* Options of the product build: "msm_window_bits" (Pippenger c of the fixed-base tables; 0 = automatic, c = the same for every table,
+ * 100 * big + small = `big` for tables of 2^21 points and more, + 10000 * g2 = its own window for the G2 table), "profile" (0 off,
+ * 1 event-time the bucket accumulations, 2 every launch group; read back with zk_profile_*), "msm_shard_points" (zk_prove_partial:
+ * 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points), "rank_tables" (multi-GPU exchange: 1 = window tables of
+ * the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the reference's long
+ * division; default 0 = power-series inverse above 512 quotient coefficients).  Each is exercised by a -m gpu test.
+ * A library built with -DZK_MEASURE (make -C zksnark_rs_amd/csrc measure; zk_get_option(ctx, "measure_build") == 1) also accepts the
+ * measurement switches of bench.py --opt / --serialize ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole",
+ * "msm_small_lanes", "msm_unchain_lanes", "chain_order"); the product build answers ZK_ERR_UNSUPPORTED to them and to unknown keys. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);
 
@@ -83,7 +85,9 @@ int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int cose
 
 /* sum_i scalars[i] * points[i]: the SigmaG1/SigmaG2 inner products of groth16::prove
  * (groth16/mod.rs:255-272,279-290), i.e. n x exp_encrypted_g1/g2 (fr.rs:114-119) folded with
- * Sum for G1Local/G2Local (fr.rs:191-198,217-223).  window_bits = 0 picks automatically. */
+ * Sum for G1Local/G2Local (fr.rs:191-198,217-223).  window_bits = 0 picks automatically.  zk_msm_g1 only: window_bits in
+ * [-9, -2] runs the Pippenger form BASELINE.json's north_star words with c = -window_bits -- one wavefront per (window, chunk),
+ * buckets in LDS, a wave-level fold of the partial sums (csrc/msm_lds.hpp) -- a measured comparator, never used by zk_prove. */
 /* Window size c (bits) the fixed-base tables of a product of `count` points are built with when the option msm_window_bits
  * is 0: the outcome of the sweeps in DESIGN.md 4c (G1: 17 from 2^17 points, 20 from 2^21; the G2 table: 20 from 2^20).  Host code, no
  * device needed.  (The reference has no such notion: fr.rs:114-119 is one double-and-add per term.) */

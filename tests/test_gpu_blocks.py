@@ -177,6 +177,26 @@ def test_msm_matches_reference_sum(ctx, orc, n, c):
     assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
 
 
+@pytest.mark.parametrize("n,c", [(1, 2), (17, 3), (300, 5), (1000, 8), (3000, 9), (70000, 9)])
+def test_msm_lds_bucket_form(ctx, orc, n, c):
+    """The Pippenger form BASELINE.json's north_star words (one wavefront per (window, chunk), buckets in LDS under per-bucket locks,
+    wave-level fold; csrc/msm_lds.hpp: zk_msm_g1 with window_bits = -c) gives the same point as the folded double-and-add --
+    zero / one / r-1 scalars, infinity, repeated points and P + (-P) in one bucket included.  It is a measured comparator only."""
+    rng = SplitMix64(900 + n)
+    p1, k = g1_points(orc, rng, n), rand_fr(rng, n)
+    if n >= 17:
+        k[0] = 0; k[1] = ints_to_limbs([1])[0]; k[2] = ints_to_limbs([R_MODULUS - 1])[0]
+        p1[3] = 0
+        p1[5] = p1[4]; k[5] = k[4]
+        p1[7] = p1[6]; k[7] = ints_to_limbs([(R_MODULUS - int(zk.limbs_to_int(k[6]))) % R_MODULUS])[0]
+    assert np.array_equal(ctx.msm_g1(p1, k, -c), orc.msm_g1(p1, k, 0))
+    if n == 17:
+        with pytest.raises(zk.ZkError):
+            ctx.msm_g1(p1, k, -10)        # the buckets of a wider window do not fit LDS
+        with pytest.raises(zk.ZkError):
+            ctx.msm_g2(g2_points(orc, rng, n), k, -5)   # G1 only
+
+
 @pytest.mark.parametrize("c", [0, 6, 13])
 def test_msm_skewed_scalars(ctx, orc, c):
     """Boolean-heavy witnesses: most scalars are 0, 1, 2 or r-1, so a few buckets hold almost every digit

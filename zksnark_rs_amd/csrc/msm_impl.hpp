@@ -993,6 +993,24 @@ void msm_init_attributes() {
 }
 #endif  // ZK_MSM_COMMON
 
+#ifdef ZK_MSM_COMMON
+#include "msm_lds.hpp"
+#endif
+// zk_msm_g1 with a negative window size: north_star's LDS-bucket form (msm_lds.hpp), G1 only
+template <class F>
+void msm_lds_dispatch(zk_ctx* ctx, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n, Jac<F>* d_out) {
+#ifdef ZK_MSM_COMMON
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        DevBuf<Jac<Fq>> parts;
+        if (!n) { ZK_HIP(hipMemsetAsync(d_out, 0, sizeof(Jac<Fq>), st)); return; }
+        msm_lds_run_g1(ctx, st, tab, d_scalars, n, parts, d_out);
+        ZK_HIP(hipStreamSynchronize(st));   // `parts` goes out of scope
+        return;
+    }
+#endif
+    throw StatusError{ZK_ERR_UNSUPPORTED, "zk_msm: the LDS-bucket form (negative window_bits) exists for G1 only"};
+}
+
 template <class F>
 __global__ void k_jac_to_affine_canonical(const Jac<F>* in, Aff<F>* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1016,10 +1034,12 @@ void msm_host(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
         fr_to_mont(ctx, ds.p, tmp.p, n, flag.p);   // range check of the scalars (digits use the canonical integers)
     }
     int c = window_bits > 0 ? window_bits : (ctx->opt_window_bits > 0 ? (int)ctx->opt_window_bits : (sizeof(F) > sizeof(Fq) ? msm_auto_window_g2(n) : msm_auto_window(n)));
+    if (window_bits < 0) c = -window_bits;   // the LDS-bucket comparator (msm_lds.hpp)
     MsmTable<F> tab;
     msm_build_table<F>(ctx, dp.p, n, c, tab);
     if (!ctx->msm_ws0) ctx->msm_ws0 = std::make_shared<MsmWorkspace>();
-    msm_run<F>(ctx, *ctx->msm_ws0, st, tab, ds.p, n, 0, 1, dres.p);
+    if (window_bits < 0) msm_lds_dispatch<F>(ctx, st, tab, ds.p, n, dres.p);
+    else msm_run<F>(ctx, *ctx->msm_ws0, st, tab, ds.p, n, 0, 1, dres.p);
     hipLaunchKernelGGL(k_jac_to_affine_canonical<F>, dim3(1), dim3(64), 0, st, dres.p, daff.p, 1);
     ZK_HIP(hipGetLastError());
     int hflag = 0;
