@@ -215,6 +215,52 @@ def test_gpu_chain_circuit_at_full_size(ctx, orc, n):
     assert not ctx.verify(crs, [x, limbs_to_int(weights[2])], got_bad)
 
 
+def ctx_bytes_of_crs(ctx, crs, tmp_path):
+    ctx.crs_save(crs, tmp_path / "ref.zkcrs")
+    return (tmp_path / "ref.zkcrs").read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", ["simple.zk", "deg_15.zk"])
+def test_gpu_uploaded_crs_serves_integer_roots_programs(ctx, prog):
+    """groth16::prove takes any (&SigmaG1, &SigmaG2) (mod.rs:213-217): the CRS of the fixture proofs, uploaded as the reference's arrays
+    alone (zk_crs_upload), with the program's rows over ASTParser's roots 1..n (zk_qap_upload_sparse_integers) gives the fixture bytes --
+    the Lagrange-basis points are derived from the powers (csrc/basis.hip)."""
+    c = case(prog)
+    circ = Circuit(open(os.path.join(GOLD, "zk", prog)).read())
+    weights = circ.weights(case_inputs(c))
+    td = ints_to_limbs([H(t) for t in c["trapdoor"]])
+    r, s = H(c["r"]), H(c["s"])
+    crs_dense = ctx.setup(circ.qap(ctx), td)                                   # the reference's arrays (power basis) ...
+    crs_up = ctx.crs_upload(circ.n, circ.m, circ.input, ctx.crs_download(crs_dense))   # ... and nothing else
+    assert ctx.prove(crs_up, circ.qap_sparse(ctx), weights, r, s).hex() == c["proof"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 65539])
+def test_gpu_uploaded_crs_change_of_basis_at_size(ctx, orc, tmp_path, n):
+    """The same at 4096 and 2^16 + 3 gates: zk_crs_upload + zk_qap_upload_sparse_integers + zk_prove == the zk_setup path == the closed
+    form, and the derived Lagrange-basis arrays equal the ones zk_setup wrote (the CRS containers are identical byte for byte)."""
+    rng = SplitMix64(8800 + n)
+    m, l, u, v, w = chain_rows_integers(n)
+    x = rng.fr()
+    weights = chain_weights_integers(n, x, [rng.fr() for _ in range(n)])
+    desc = ctx.sparse_desc(0, m, l, u, v, w)
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    good = ctx.prove(crs, qap, weights, r, s)
+    assert good == orc.trapdoor_proof_integers(desc, n, td, weights, r, s)
+    crs_up = ctx.crs_upload(n, m, l, ctx.crs_download(crs))
+    assert ctx.prove(crs_up, qap, weights, r, s) == good
+    # the derived Lagrange-basis arrays are the ones zk_setup wrote: the two CRS containers (ZKCRSv2) agree byte for byte
+    ctx.crs_save(crs, tmp_path / "setup.zkcrs")
+    ctx.crs_save(crs_up, tmp_path / "derived.zkcrs")
+    a, b = (tmp_path / "setup.zkcrs").read_bytes(), (tmp_path / "derived.zkcrs").read_bytes()
+    assert a[:8] == b"ZKCRSv2\0" and a == b
+
+
 @pytest.mark.gpu
 def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     n = 12
@@ -226,13 +272,16 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     crs = ctx.setup(qap, td)
     r, s = rng.fr(), rng.fr()
     good = ctx.prove(crs, qap, weights, r, s)
-    # a CRS that carries only the reference's arrays cannot serve this form
+    # a CRS that carries only the reference's arrays (zk_crs_upload): the plain container keeps the v1 format ...
     crs2 = ctx.crs_upload(circ.n, circ.m, circ.input, ctx.crs_download(crs))
-    with pytest.raises(zk.ZkError) as e:
-        ctx.prove(crs2, qap, weights, r, s)
-    assert e.value.status == -7 and "zk_setup" in str(e.value)
-    # ... but serves the dense form of the same circuit, with the same bytes
+    ctx.crs_save(crs2, tmp_path / "plain.zkcrs")
+    assert (tmp_path / "plain.zkcrs").read_bytes()[:8] == b"ZKCRSv1\0"
+    # ... serves the dense form of the same circuit, with the same bytes ...
     assert ctx.prove(crs2, circ.qap(ctx), weights, r, s) == good
+    # ... and this form after the change of basis of its points (csrc/basis.hip, once per CRS), which a saved copy then carries
+    assert ctx.prove(crs2, qap, weights, r, s) == good
+    ctx.crs_save(crs2, tmp_path / "based.zkcrs")
+    assert (tmp_path / "based.zkcrs").read_bytes() == ctx_bytes_of_crs(ctx, crs, tmp_path)
     # x among 1..2n-1: the Lagrange denominators vanish
     with pytest.raises(zk.ZkError) as e:
         ctx.setup(qap, ints_to_limbs([5, 6, 7, 8, 2 * n - 1]))
@@ -253,8 +302,6 @@ def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         ctx.crs_load(tmp_path / "bad.zkcrs")
     assert e.value.status == -8
-    ctx.crs_save(crs2, tmp_path / "plain.zkcrs")               # a CRS without them keeps the v1 container
-    assert (tmp_path / "plain.zkcrs").read_bytes()[:8] == b"ZKCRSv1\0"
     # container: kind 2 round trip
     ctx.qap_save(qap, tmp_path / "c.zkqap")
     q2 = ctx.qap_load(tmp_path / "c.zkqap")

@@ -366,6 +366,8 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
+    // an integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1): change of basis, once per CRS
+    if (!xout && !q.dense && q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
     if (xout) {}   // scalars only: no inner product, no table (the ranks of a scalar exchange build only their own slices)
     else if (q.dense) crs_ensure_tables(ctx, crs, false, 0);
     else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
@@ -587,6 +589,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     const ExchangeDims xd = exchange_dims(q, world);
     // world > 1: tables of this rank's point ranges only (option rank_tables; 0 = slices of the full tables, as a lone prover has them)
     const bool rt = world > 1 && ctx->opt_rank_tables;
+    if (q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
     if (rt) crs_ensure_rank_tables(ctx, crs, !q.roots, q.log_n, q.roots != 0, rank, world, xd.cl, xd.cn, xd.ch);
     else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
@@ -656,6 +659,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
+    if (q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
     if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true); else crs_ensure_tables(ctx, crs, true, q.log_n);
     crs_ensure_fixed_tables(ctx, crs);
     if (!S.h_b_proofs) {
