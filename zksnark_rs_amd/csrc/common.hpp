@@ -103,7 +103,7 @@ struct zk_ctx {
     long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
     long opt_ablate = 0;          // bit 0: reuse the previous sorted list of a workspace (repeated inputs only; prices the sort)
     long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take shorter runs (msm_impl.hpp)
-    long opt_unchain_lanes = 65536; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation
+    long opt_unchain_lanes = 140000; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation (2^16 gates: lone proof 2.83 -> 2.55 ms, two in flight level)
     long opt_chain_order = 0;     // order of the accumulation chain of a proof: 0 = L, B2, A, HB; 1 = L, A, B2, HB
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
