@@ -126,21 +126,28 @@ def cpu_baseline(zk, ctx, seed, main_inst, full=False):
 
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
-PMC_FILES = {20: "r2_pmc_traffic.json", 16: "r2_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
+PMC_FILES = {20: "r3_pmc_traffic.json", 16: "r3_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
+PMC_ACC_FILES = {20: "r3_pmc_acc.json", 16: "r3_pmc_acc_2p16.json"}
 
 # VALU issue ceiling of gfx950 for the two instruction classes of the multiplier, from tools/ubench_valu.hip (>= 5 ms kernels, in-kernel
 # shader / wall clocks, cross-checked with SQ_INSTS_VALU and GRBM_GUI_ACTIVE: profiles/r2_ubench_valu.txt, r2_ubench_valu_pmc.txt):
 #   64-bit / integer-multiply class (v_mad_u64_u32, v_mad_i64_i32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64, carry adds): 4 cycles
 #   per wave-instruction and SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614 G/s (measured 585 at 8 waves/SIMD, 546 at 3, clock 2.36-2.40 GHz);
 #   plain 32-bit class (v_and, v_add_u32, v_mov, shifts): 2 cycles -> 1229 G/s (measured 1062).
-# (Round 1's "5.09 cycles" was a 40-140 us kernel timed with events: launch overhead and the clock ramp inside the measurement.)
 VALU_PEAK_G = {"slow": 1024 * 2.4 / 4.0, "fast": 1024 * 2.4 / 2.0}
 VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
-# wave-instructions per lane-addition (SQ_INSTS_VALU / additions, profiles/r2_pmc_acc.txt) and the share in the 4-cycle class
-# (per mixed addition: 1467 multiply-adds + ~400 64-bit adds / shifts / mul_lo of the column bookkeeping; tools/instr_mix.py lists the loop)
-# G1: 2243 per addition at c = 17 (the n-point product), 2293 at c = 20 (more bucket boundaries per lane: the two 2n-point products);
-# the figure below is their mean weighted by additions at 2^20 gates
-ACC_INSTR = {"msm_accumulate_g1": (2282.0, 0.83), "msm_accumulate_g2": (7417.0, 0.80)}
+
+
+def pmc_acc(name, log_n=20):
+    """(wave-instructions per addition, share of the 4-cycle class, source) of an accumulation kernel, MEASURED: tools/profile_round.sh ->
+    tools/pmc_acc_summary.py -> profiles/r3_pmc_acc.json (SQ_INSTS_VALU per addition; the class share = SQ_INSTS_VALU_INT64 /
+    SQ_INSTS_VALU of the executed instructions).  None when the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_ACC_FILES[log_n])) as f:
+            k = json.load(f)["kernels"][name]
+        return float(k["wave_instr_per_addition"]), float(k["share_4_cycle_class"]), k
+    except Exception:
+        return None
 
 
 def msm_window(count, opt=0, g2=False):
@@ -551,11 +558,25 @@ def main():
             gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
             traffic = pmc_traffic(name, args.log_n) if (args.log_n in PMC_FILES and world == 1 and not args.window_bits and args.batch <= 1
                                                        and args.roots == "unity") else None
-            winst, slow = ACC_INSTR[name]
             adds = pairs * windows
-            g_inst = adds / (avg_ms * 1e-3) / 64.0 * winst / 1e9
-            peak_mix = 1.0 / (slow / VALU_PEAK_G["slow"] + (1.0 - slow) / VALU_PEAK_G["fast"])
-            meas_mix = 1.0 / (slow / VALU_MEASURED_G["slow"] + (1.0 - slow) / VALU_MEASURED_G["fast"])
+            measured = pmc_acc(name, args.log_n) if args.log_n in PMC_ACC_FILES else None
+            valu = None
+            if measured:
+                winst, slow, src = measured
+                g_inst = adds / (avg_ms * 1e-3) / 64.0 * winst / 1e9
+                peak_mix = 1.0 / (slow / VALU_PEAK_G["slow"] + (1.0 - slow) / VALU_PEAK_G["fast"])
+                meas_mix = 1.0 / (slow / VALU_MEASURED_G["slow"] + (1.0 - slow) / VALU_MEASURED_G["fast"])
+                valu = {"achieved": round(g_inst, 1), "unit": "G wave-instr/s", "peak": round(peak_mix, 1), "frac": round(g_inst / peak_mix, 3),
+                        "peak_measured_ubench": round(meas_mix, 1), "frac_of_measured_peak": round(g_inst / meas_mix, 3),
+                        "additions_per_launch": round(adds), "windows_per_product": wins, "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
+                        "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
+                        "int64_share": src.get("int64_share"), "int32_share": src.get("int32_share"),
+                        "sustained_clock_GHz_stand_alone": src.get("sustained_clock_GHz"),
+                        "source": "profiles/%s (SQ_INSTS_VALU / additions; SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU)" % PMC_ACC_FILES[args.log_n],
+                        "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
+                                "tools/ubench_valu.hip sustains (585 / 1062 G/s).  Under this kernel the chip clocks below 2.4 GHz "
+                                "(sustained_clock_GHz_stand_alone), i.e. at the sustained clock the issue fraction is frac x 2.4 / clock; other "
+                                "kernels of the pipeline share the SIMDs during this measurement"}
             roofline = {
                 # the roofline the metric names: SURVEY 8(d) algorithmic bytes of one launch / its event-timed duration against HBM
                 "bound": "valu", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -569,14 +590,7 @@ def main():
                         "HBM-bound: it is bound by VALU issue (`valu` below).  It gathers one table entry per Pippenger window and pair "
                         "(implementation_bytes = windows x (4 + 64|128) B x pairs + parked images), which is what `traffic` measures.",
                 # the bound that binds: wave-instructions issued per second against the issue ceiling of the instruction mix
-                "valu": {"achieved": round(g_inst, 1), "unit": "G wave-instr/s", "peak": round(peak_mix, 1), "frac": round(g_inst / peak_mix, 3),
-                         "peak_measured_ubench": round(meas_mix, 1), "frac_of_measured_peak": round(g_inst / meas_mix, 3),
-                         "additions_per_launch": round(adds), "windows_per_product": wins, "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
-                         "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
-                         "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
-                                 "tools/ubench_valu.hip sustains (585 / 1062 G/s).  Under this kernel the chip clocks at ~1.93 GHz "
-                                 "(GRBM_GUI_ACTIVE / duration, profiles/r2_pmc_acc.txt), i.e. at the sustained clock the issue fraction is "
-                                 "frac x 2.4 / 1.93; other kernels of the pipeline share the SIMDs during this measurement"},
+                "valu": valu,
                 "whole_proof": {"algorithmic_bytes": 1404.0 * n, "achieved_GBps": round(1404.0 * n * value / 1e9, 2),
                                 "frac": round(1404.0 * n * value / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
                                 "note": "SURVEY 8(d): 1404 n bytes per proof; per GPU"},

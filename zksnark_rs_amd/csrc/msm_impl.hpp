@@ -677,10 +677,18 @@ constexpr int TAIL_THREADS = 64;
 // Fq2 kernels take when left alone) therefore waits for TWO accumulation waves of one SIMD to retire together, which only happens when
 // an accumulation drains: the kernel trace showed the four-wave k_msm_sum_points<Fq2> taking 1.2 ms instead of 0.28 and the G2 tail
 // as a whole ending with the last accumulation of its proof.
-// (Compiling the Fq2 tail kernels for 128 registers -- 700..1350 B of scratch each -- measured level with leaving them at 246..256:
-// profiles/r3_experiments.txt.)
-template <class F> struct TailWaves { static constexpr int value = 3; };
-template <> struct TailWaves<Fq2> { static constexpr int value = 2; };
+// Same-box A/B at 2^20 gates with the G2 table at c = 20 (2^19 bucket images to fold): Fq2 tail kernels left at 246..256 registers
+// 91.1 proofs/s, compiled for three waves per SIMD (168 registers, 500..1100 B of scratch) 94.3, for four (128 registers) 91.9
+// (profiles/r3_experiments.txt): at 168 a tail wave fits into the 208 registers one retired G1 accumulation wave leaves, the G2
+// tail no longer ends with the last accumulation of its proof and the next proof's G2 sort, queued behind it, starts in time.
+#ifndef ZK_TAIL_G2_WAVES
+#define ZK_TAIL_G2_WAVES 3
+#endif
+#ifndef ZK_TAIL_G1_WAVES
+#define ZK_TAIL_G1_WAVES 3
+#endif
+template <class F> struct TailWaves { static constexpr int value = ZK_TAIL_G1_WAVES; };
+template <> struct TailWaves<Fq2> { static constexpr int value = ZK_TAIL_G2_WAVES; };
 
 template <class F>
 __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
