@@ -347,6 +347,25 @@ def test_scalar_exchange_full_size_2_20(ctx, orc):
         assert ctx.prove_combine(crs, gathered.data_ptr(), world, r, s) == want[j], j
 
 
+def test_prove_at_the_largest_size_2_23(ctx, orc):
+    """2^23 constraints over the roots of unity (16.8 M wires; every transform takes three passes over HBM, the window tables 56 GB):
+    proof == the oracle's closed form.  ~30 s, 72 GiB of HBM."""
+    log_n = 23
+    rng = SplitMix64(2300 + log_n)
+    n = 1 << log_n
+    m, l, u, v, w = chain_rows(log_n)
+    weights = chain_weights(log_n, rng.fr(), [rng.next() for _ in range(n)])
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    qap = ctx.qap_sparse(log_n, m, l, u, v, w)
+    crs = ctx.setup(qap, td)
+    p1 = ctx.prove(crs, qap, weights, r, s)
+    p2 = ctx.prove(crs, qap, weights, r, s)
+    want = orc.trapdoor_proof_sparse(ctx.sparse_desc(log_n, m, l, u, v, w), td, weights, r, s)
+    assert p1 == p2 == want
+    del crs, qap
+
+
 def test_window_sharded_full_size_2_20(ctx, orc):
     """BASELINE configs[4] as it is worded: the 2^20 proof with the Pippenger WINDOWS of every inner product sharded over the ranks
     (rank g accumulates the windows w = g mod world; msm_shard_points = 0), worlds 2 and 8 played on one device, the all-gather

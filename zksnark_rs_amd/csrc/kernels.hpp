@@ -27,9 +27,10 @@ constexpr unsigned NTT_MAX_LOG = 24;         // <= 22: at most two passes over H
 struct NttTables {
     unsigned log_n = 0;
     DevBuf<Fr> tw_fwd, tw_inv;       // w_2048^k and w_2048^-k, k < 1024 (local butterflies)
+    DevBuf<int32_t> tw29_fwd, tw29_inv;   // the same in the tiles' lazy radix, 12 words per twiddle (ntt.hip k_tw29)
     DevBuf<Fr> mid_fwd, mid_inv;     // inter-pass twiddles, n entries each (log_n > 11)
-    DevBuf<Fr> coset_fwd_brev;       // g^brev(pos)                     (prove pipeline, DIT input order)
-    DevBuf<Fr> coset_inv_brev_half;  // g^-brev(pos) / 2                (prove pipeline, h combine)
+    DevBuf<Fr> coset_fwd_brev;       // g^brev(pos) / n                 (prove pipeline, DIT input order; n: of the unscaled inverse transform before it)
+    DevBuf<Fr> coset_inv_brev_half;  // g^-brev(pos) / (2 n)            (prove pipeline, h combine)
     Fr n_inv;                        // 1/n
 };
 std::shared_ptr<NttTables> ntt_get_tables(zk_ctx*, unsigned log_n);

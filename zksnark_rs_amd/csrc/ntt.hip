@@ -84,6 +84,18 @@ static Fr host_inv_pow2(unsigned k) {  // 2^-k
     return host_fr_pow(two, k).inv();
 }
 
+// twiddle of the local butterflies in the tile's own radix: 9 x 29-bit limbs, 12 words apart (three 16-byte loads, no conversion)
+constexpr int TW29_STRIDE = 12;
+__global__ void k_tw29(const Fr* __restrict__ tw, int count, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const FpR<FrParams> v = FpR<FrParams>::load(tw[i]);
+#pragma unroll
+    for (int l = 0; l < 9; ++l) out[i * TW29_STRIDE + l] = v.v[l];
+#pragma unroll
+    for (int l = 9; l < TW29_STRIDE; ++l) out[i * TW29_STRIDE + l] = 0;
+}
+
 std::shared_ptr<NttTables> ntt_get_tables(zk_ctx* ctx, unsigned log_n) {
     auto it = ctx->ntt_tables.find(log_n);
     if (it != ctx->ntt_tables.end()) return it->second;
@@ -95,6 +107,11 @@ std::shared_ptr<NttTables> ntt_get_tables(zk_ctx* ctx, unsigned log_n) {
     t->tw_inv.alloc(1024);
     fr_powers(ctx, w2048, Fr::one(), t->tw_fwd.p, 1024);
     fr_powers(ctx, w2048.inv(), Fr::one(), t->tw_inv.p, 1024);
+    t->tw29_fwd.alloc(1024 * TW29_STRIDE);
+    t->tw29_inv.alloc(1024 * TW29_STRIDE);
+    hipLaunchKernelGGL(k_tw29, dim3(4), dim3(256), 0, ctx->stream, t->tw_fwd.p, 1024, t->tw29_fwd.p);
+    hipLaunchKernelGGL(k_tw29, dim3(4), dim3(256), 0, ctx->stream, t->tw_inv.p, 1024, t->tw29_inv.p);
+    ZK_HIP(hipGetLastError());
     if (log_n > NTT_MAX_LOCAL_LOG) {
         size_t n = (size_t)1 << log_n;
         // two passes: n = 2^a columns-transform x rows of 2^11; three passes (log_n > 22): 2^(log_n - 22) x blocks of 2^22
@@ -119,8 +136,9 @@ void ntt_ensure_coset_tables(zk_ctx* ctx, NttTables& t) {
     Fr g = host_root_of_unity(t.log_n + 1);
     t.coset_fwd_brev.alloc(n);
     t.coset_inv_brev_half.alloc(n);
-    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g, Fr::one(), t.coset_fwd_brev.p, t.log_n);
-    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g.inv(), host_inv_pow2(1), t.coset_inv_brev_half.p, t.log_n);
+    // both tables carry the 1 / n of the inverse transform in front of them (prove.hip runs those transforms unscaled)
+    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g, t.n_inv, t.coset_fwd_brev.p, t.log_n);
+    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g.inv(), host_inv_pow2(1) * t.n_inv, t.coset_inv_brev_half.p, t.log_n);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }
@@ -163,7 +181,7 @@ struct NttPass {
     unsigned log_tiles;   // tiles per transform; workgroup b * tiles + t is tile t of transform b (batches: data = [batch][n])
     size_t n;             // transform length
     size_t row_stride, tile_stride;
-    const Fr* tw;    // w_2048^(+-k), k < 1024
+    const int32_t* tw;   // w_2048^(+-k), k < 1024, in the lazy radix (k_tw29)
     const Fr* mid;   // applied on store (data layout) or nullptr
     const Fr* pre;   // applied on load (data layout) or nullptr
     Fr post;
@@ -224,8 +242,19 @@ __device__ __forceinline__ Fr fr_store_exact(const FrL& a) {
 }
 
 // K butterfly stages (stage numbers s .. s+K-1 of a 2^L-point transform) on the 2^K elements of one unit
+__device__ __forceinline__ FrL tw_get(const int32_t* __restrict__ tw, size_t idx) {
+    const int4* p = reinterpret_cast<const int4*>(tw + idx * TW29_STRIDE);
+    const int4 a = p[0], b = p[1], c = p[2];
+    FrL r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; r.v[8] = c.x;
+    return r;
+}
+
+// Butterflies whose twiddle is w^0 = 1 are not multiplied.  They sit where the stride is one: in the LAST round of a DIF tile
+// (qshift = 0, so j = 0 and pos = q & (half - 1)) and in the FIRST round of a DIT tile (s = 0) -- three of the four butterflies a
+// lane runs there, 1.5 of a tile's 9..11 stages; the test is uniform over the workgroup.
 template <bool DIT, int K>
-__device__ __forceinline__ void ntt_round(int32_t* lds, const Fr* __restrict__ tw, int col_base, unsigned L, unsigned s, int u, unsigned tw_shift) {
+__device__ __forceinline__ void ntt_round(int32_t* lds, const int32_t* __restrict__ tw, int col_base, unsigned L, unsigned s, int u, unsigned tw_shift) {
     constexpr int Q = 1 << K;
     FrL x[Q];
     int row0, qshift, j;
@@ -246,19 +275,20 @@ __device__ __forceinline__ void ntt_round(int32_t* lds, const Fr* __restrict__ t
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             if (q & half) continue;
+            const bool one = qshift == 0 && (q & (half - 1)) == 0;     // twiddle w^0 (qshift == 0 implies j == 0)
             if (!DIT) {
                 // decimation in frequency: (x, y) -> (x + y, (x - y) w),  w = w_{2^(L-s-t)}^pos
                 const int pos = ((q & (half - 1)) << qshift) | j;
-                const FrL w = FrL::load(tw[((size_t)pos << (s + t)) << tw_shift]);
                 FrL sum = x[q] + x[q + half];
                 if (t == 1) sum = sum.norm();
-                x[q + half] = (x[q] - x[q + half]) * w;
+                if (one) x[q + half] = (x[q] - x[q + half]).norm();
+                else x[q + half] = (x[q] - x[q + half]) * tw_get(tw, ((size_t)pos << (s + t)) << tw_shift);
                 x[q] = sum;
             } else {
                 // decimation in time: (x, y) -> (x + w y, x - w y),  w = w_{2^(s+t+1)}^pos
                 const int pos = ((q & (half - 1)) << qshift) | j;
-                const FrL w = FrL::load(tw[((size_t)pos << (L - 1 - s - t)) << tw_shift]);
-                const FrL y = (t == 2 ? x[q + half].norm() : x[q + half]) * w;
+                const FrL yin = t == 2 ? x[q + half].norm() : x[q + half];
+                const FrL y = one ? yin : yin * tw_get(tw, ((size_t)pos << (L - 1 - s - t)) << tw_shift);
                 x[q + half] = x[q] - y;
                 x[q] = x[q] + y;
             }
@@ -346,7 +376,7 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     }
     auto tabs = ntt_get_tables(ctx, log_n);
     size_t n = (size_t)1 << log_n;
-    const Fr* tw = inverse ? tabs->tw_inv.p : tabs->tw_fwd.p;
+    const int32_t* tw = inverse ? tabs->tw29_inv.p : tabs->tw29_fwd.p;
     double pass_bytes = 64.0 * n * batch;  // read + write of every element
     if (!batch) return;
     const Fr post_f = post ? *post : tabs->n_inv;

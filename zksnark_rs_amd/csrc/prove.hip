@@ -330,19 +330,22 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
     spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
     fr_pointwise_mul(ctx, ue, ve, x0, n);                             // U.V on <w>
-    ntt_dif(ctx, S.uv.p, q.log_n, true, true, 2);                     // V, U coefficients (bit-reversed order), one launch per pass
-    fr_from_mont(ctx, ve, vc_can, n);
+    // The inverse transforms run WITHOUT their 1 / n (a multiplication per element in the last pass): the factor rides in the
+    // kernels that consume their outputs anyway -- the conversions to canonical scalars, r v + s u, the coset table, the h combine.
+    const Fr n_inv = tabs->n_inv;
+    ntt_dif(ctx, S.uv.p, q.log_n, true, false, 2);                    // n V, n U coefficients (bit-reversed order), one launch per pass
+    fr_scale_to_canonical(ctx, ve, n_inv, vc_can, n);
     launch(0, 1, vc_can, n);
-    fr_from_mont(ctx, ue, uc_can, n);
+    fr_scale_to_canonical(ctx, ue, n_inv, uc_can, n);
     launch(2, 0, uc_can, n);
     // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-    fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + n, n);
+    fr_lincomb_to_canonical(ctx, ve, r_mont * n_inv, ue, s_mont * n_inv, hb_can + n, n);
     ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w>
+    ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w> (the table holds g^i / n)
     fr_pointwise_mul(ctx, ug, vg, y0, n);                             // U.V on g<w>
-    ntt_dif(ctx, S.xy.p, q.log_n, true, true, 2);                     // lo + hi | (lo - hi)_i * g^i
-    Fr half = host_fr_from_u64(2).inv();
-    h_combine(ctx, x0, y0, tabs->coset_inv_brev_half.p, half, hb_can, n);
+    ntt_dif(ctx, S.xy.p, q.log_n, true, false, 2);                    // n (lo + hi) | n (lo - hi)_i * g^i
+    Fr half = host_fr_from_u64(2).inv() * n_inv;
+    h_combine(ctx, x0, y0, tabs->coset_inv_brev_half.p, half, hb_can, n);        // the table holds g^-i / (2 n)
     // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
     launch(4, 2, hb_can, 2 * n);
 }
@@ -750,19 +753,20 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         spmv(ctx, q.v_gate, a_mont, a_len[j], ve + j * n);
     }
     fr_pointwise_mul(ctx, ue, ve, x0, n * cnt);                             // U.V on <w>
-    ntt_dif(ctx, S.uv.p, q.log_n, true, true, 2 * cnt);                     // V, U coefficients (bit-reversed order)
-    fr_from_mont(ctx, ve, S.bx_v.p, n * cnt);
+    const Fr n_inv = tabs->n_inv;                                           // the inverse transforms run without their 1 / n (see sparse_scalar_stage)
+    ntt_dif(ctx, S.uv.p, q.log_n, true, false, 2 * cnt);                    // n V, n U coefficients (bit-reversed order)
+    fr_scale_to_canonical(ctx, ve, n_inv, S.bx_v.p, n * cnt);
     launch(0, 1, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
-    fr_from_mont(ctx, ue, S.bx_u.p, n * cnt);
+    fr_scale_to_canonical(ctx, ue, n_inv, S.bx_u.p, n * cnt);
     launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
     for (size_t j = 0; j < cnt; ++j)
-        fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+        fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]) * n_inv, ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]) * n_inv,
                                 S.bx_h.p + j * 2 * n + n, n);
     ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2 * cnt);   // V, U on g<w>
     fr_pointwise_mul(ctx, ug, vg, y0, n * cnt);                             // U.V on g<w>
-    ntt_dif(ctx, S.xy.p, q.log_n, true, true, 2 * cnt);                     // lo + hi | (lo - hi)_i * g^i
-    const Fr half = host_fr_from_u64(2).inv();
+    ntt_dif(ctx, S.xy.p, q.log_n, true, false, 2 * cnt);                    // n (lo + hi) | n (lo - hi)_i * g^i
+    const Fr half = host_fr_from_u64(2).inv() * n_inv;
     for (size_t j = 0; j < cnt; ++j)
         h_combine(ctx, x0 + j * n, y0 + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
     launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n, &ms->hb);
