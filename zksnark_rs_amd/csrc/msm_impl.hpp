@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
 // bucket; buckets of more than MSM_HEAVY runs (skewed digit distributions) are queued for k_msm_merge_heavy instead.  Empty buckets
 // get the image of infinity here (no run wrote their slot).
 constexpr uint32_t MSM_HEAVY = 96;
+constexpr uint32_t MSM_HEAVY_CHUNK = 2048;   // images one workgroup of k_msm_merge_heavy sums (a bucket of 32768 runs as ONE workgroup's job took 3 ms)
 // Workgroup size of the reduction tail (merge / fold / weigh).  ONE wave: while an accumulation fills the chip, a 256-lane
 // workgroup of a 150..250-register kernel needs all four SIMDs of a CU to have room at the same moment, which only happens in
 // the accumulation's last round (the timeline showed the previous proof's G2 tail still running 8 ms after its accumulation
@@ -282,7 +283,7 @@ template <> struct TailWaves<Fq2> { static constexpr int value = ZK_TAIL_G2_WAVE
 
 template <class F>
 __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_merge(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
-                                                   AccSlot<F>* __restrict__ img, uint32_t* __restrict__ heavy) {
+                                                   AccSlot<F>* __restrict__ img, uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
     ZK_LATENCY_KERNEL();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= (uint32_t)buckets) return;
@@ -291,7 +292,12 @@ __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_merge
     if (!z) { acc_clear(acc); img[b].a = acc; return; }
     const uint32_t r = (z + T - 1) / T;
     if (r == 1) return;
-    if (r - 1 > MSM_HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = b; return; }
+    if (r - 1 > MSM_HEAVY) {   // queued in chunks of MSM_HEAVY_CHUNK images: (bucket, chunk) items behind heavy[2], multi-chunk buckets from the end
+        const uint32_t chunks = (r + MSM_HEAVY_CHUNK - 1) / MSM_HEAVY_CHUNK, at = atomicAdd(&heavy[0], chunks);
+        for (uint32_t w = 0; w < chunks; ++w) { heavy[2 + 2 * (at + w)] = b; heavy[3 + 2 * (at + w)] = w; }
+        if (chunks > 1) heavy[heavy_cap - 1 - atomicAdd(&heavy[1], 1u)] = b;
+        return;
+    }
     const AccSlot<F>* more = img + (size_t)buckets + xbase[b];
     acc = img[b].a;
     for (uint32_t j = 0; j + 1 < r; ++j) acc = acc_add(acc, more[j].a);
@@ -299,27 +305,30 @@ __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_merge
 }
 
 constexpr int MSM_HEAVY_THREADS = 128;
-// heavy buckets: one workgroup each, lanes stride over the images, tree over LDS
-template <class F>
+// heavy buckets.  Image j of bucket b: its own slot (j = 0) or slot j - 1 behind img[buckets + xbase[b]].
+// FINAL = false: one workgroup per queued (bucket, chunk) item sums the chunk's images (lanes stride over them, tree over LDS) into the
+// chunk's first image.  FINAL = true: one workgroup per multi-chunk bucket sums the chunks' first images into the bucket's slot.
+template <class F, bool FINAL>
 __global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
-                                                         AccSlot<F>* __restrict__ img, const uint32_t* __restrict__ heavy) {
+                                                         AccSlot<F>* __restrict__ img, const uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
     ZK_LATENCY_KERNEL();
     __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
-    const uint32_t count = heavy[0];
+    const uint32_t count = FINAL ? heavy[1] : heavy[0];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
-        const uint32_t b = heavy[1 + h];
+        const uint32_t b = FINAL ? heavy[heavy_cap - 1 - h] : heavy[2 + 2 * h], w = FINAL ? 0 : heavy[3 + 2 * h];
         const uint32_t z = start[b + 1] - start[b], r = (z + T - 1) / T;
-        const AccSlot<F>* more = img + (size_t)buckets + xbase[b];
+        AccSlot<F>* more = img + (size_t)buckets + xbase[b];
+        const uint32_t lo = FINAL ? 0 : w * MSM_HEAVY_CHUNK, hi = FINAL ? r : min(lo + MSM_HEAVY_CHUNK, r), step = FINAL ? MSM_HEAVY_CHUNK : 1;
         typename AccOf<F>::type acc;
-        if (threadIdx.x == 0) acc = img[b].a; else acc_clear(acc);
-        for (uint32_t j = threadIdx.x; j + 1 < r; j += MSM_HEAVY_THREADS) acc = acc_add(acc, more[j].a);
+        acc_clear(acc);
+        for (uint32_t j = lo + threadIdx.x * step; j < hi; j += MSM_HEAVY_THREADS * step) acc = acc_add(acc, j == 0 ? img[b].a : more[j - 1].a);
         sh[threadIdx.x].a = acc;
         __syncthreads();
         for (int d = MSM_HEAVY_THREADS / 2; d >= 1; d >>= 1) {
             if ((int)threadIdx.x < d) sh[threadIdx.x].a = acc_add(sh[threadIdx.x].a, sh[threadIdx.x + d].a);
             __syncthreads();
         }
-        if (threadIdx.x == 0) img[b].a = sh[0].a;
+        if (threadIdx.x == 0) { if (lo == 0) img[b].a = sh[0].a; else more[lo - 1].a = sh[0].a; }
         __syncthreads();
     }
 }
@@ -467,7 +476,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t half = ((size_t)buckets + 1) / 2, quarter = ((size_t)buckets + 3) / 4;
     ws.fold.ensure((2 * (half + quarter) + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // per chain: passes 1, 3, .. | passes 2, 4, ..; then C | R
     ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * sizeof(Jac<F>));   // terms | partial sums
-    ws.heavy.ensure((size_t)buckets + 1);
+    const size_t heavy_cap = 2 + 2 * ((size_t)buckets + max_extra / MSM_HEAVY_CHUNK + 1) + (size_t)buckets;   // count, count | (bucket, chunk) items | multi-chunk buckets, from the end
+    ws.heavy.ensure(heavy_cap);
     AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
     AccSlot<F>* const fold_base = reinterpret_cast<AccSlot<F>*>(ws.fold.p);
     AccSlot<F>* d_tmp[4] = {fold_base, fold_base + half, fold_base + half + quarter, fold_base + 2 * half + quarter};
@@ -536,13 +546,14 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     }
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (max_extra + 5.0 * buckets), st);
-        ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p);
+        ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, 2 * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
         // heavy buckets are outliers when the average bucket is a few runs (a small grid that mostly finds nothing to do -- surplus
         // workgroups read the count and leave; a narrow top window makes 2^(top bits) buckets heavy at once); with few buckets and many
         // entries (small windows) nearly every bucket is heavy
         const unsigned heavy_grid = entries / T / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
-        hipLaunchKernelGGL(k_msm_merge_heavy<F>, dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p);
+        hipLaunchKernelGGL((k_msm_merge_heavy<F, false>), dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
+        hipLaunchKernelGGL((k_msm_merge_heavy<F, true>), dim3(64), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
         // column sums C[g][lo] (fold the row index, FOLD images per lane and pass), then row sums R[g][hi] (fold the column index)
         uint32_t FOLD = 2;   // images per lane and pass (msm_fold option), a power of two
         while (FOLD * 2 <= (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64))) FOLD *= 2;

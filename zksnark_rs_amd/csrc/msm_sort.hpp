@@ -391,14 +391,34 @@ __global__ __launch_bounds__(256) void k_msm_runs_emit(const uint32_t* __restric
     const uint32_t xb = wg_xbase[blockIdx.x] + scratch[threadIdx.x] - x;
     for (int i = threadIdx.x; i <= RUN_MAX; i += 256) gb[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0;
     __syncthreads();
-    if (!r) return;
-    xbase[b] = xb;
-    const uint32_t pos = gb[len] + rank;
-    uint32_t k0 = s;
-    for (uint32_t j = 0; j < r; ++j) {
-        const uint32_t k1 = s + (uint32_t)((uint64_t)z * (j + 1) / r);
-        runs[pos + j] = MsmRun{k0, k1 - k0, j == 0 ? b : (uint32_t)buckets + xb + j - 1, k1};
-        k0 = k1;
+    // A bucket of many runs (a heavy bucket: evaluation-basis scalars of a structured circuit repeat one value over every gate, a
+    // boolean witness fills one bucket) is written by the whole workgroup -- one lane looping over 32768 descriptors took 9 ms.
+    __shared__ uint32_t big[256][6];
+    __shared__ uint32_t nbig;
+    if (threadIdx.x == 0) nbig = 0;
+    __syncthreads();
+    if (r) {
+        xbase[b] = xb;
+        const uint32_t pos = gb[len] + rank;
+        if (r > 32) {
+            const uint32_t slot = atomicAdd(&nbig, 1u);
+            big[slot][0] = b; big[slot][1] = s; big[slot][2] = z; big[slot][3] = r; big[slot][4] = pos; big[slot][5] = xb;
+        } else {
+            uint32_t k0 = s;
+            for (uint32_t j = 0; j < r; ++j) {
+                const uint32_t k1 = s + (uint32_t)((uint64_t)z * (j + 1) / r);
+                runs[pos + j] = MsmRun{k0, k1 - k0, j == 0 ? b : (uint32_t)buckets + xb + j - 1, k1};
+                k0 = k1;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < nbig; ++i) {
+        const uint32_t bb = big[i][0], bs = big[i][1], bz = big[i][2], br = big[i][3], bpos = big[i][4], bxb = big[i][5];
+        for (uint32_t j = threadIdx.x; j < br; j += 256) {
+            const uint32_t k0 = bs + (uint32_t)((uint64_t)bz * j / br), k1 = bs + (uint32_t)((uint64_t)bz * (j + 1) / br);
+            runs[bpos + j] = MsmRun{k0, k1 - k0, j == 0 ? bb : (uint32_t)buckets + bxb + j - 1, k1};
+        }
     }
 }
 
