@@ -415,7 +415,7 @@ impl GpuProver {
             p = p * w;
         }
         assert_eq!(index.len(), n, "the number of gates must be 2^log_n");
-        Self::from_rows(rr, &index, n, Some(log_n))
+        Self::from_rows(rr, &index, n, Some(log_n), None)
     }
 
     /// The circuits the reference itself produces: a RootRepresentation over the roots 1, 2, .., n (ASTParser, circuit/mod.rs:517),
@@ -434,10 +434,27 @@ impl GpuProver {
             k = k + FrLocal::from(1usize);
             n += 1;
         }
-        Self::from_rows(rr, &index, n, None)
+        Self::from_rows(rr, &index, n, None, None)
     }
 
-    fn from_rows<R: RootRepresentation<FrLocal>>(rr: &R, index: &HashMap<[u64; 4], u32>, n: usize, log_n: Option<u32>)
+    /// The same circuits with a CRS the reference's own `setup` made (groth16::prove takes any (&SigmaG1, &SigmaG2), mod.rs:213-217):
+    /// the library derives the Lagrange-basis points it multiplies with from [x^i]_1, [x^i]_2, [x^i t(x)/delta]_1 at the first proof
+    /// (public linear combinations; once per CRS, O(n^2): n <= 2^16 + 2^10 gates).
+    pub fn with_sigma_integers<R: RootRepresentation<FrLocal>>(rr: &R, sigma: (&SigmaG1<G1Local>, &SigmaG2<G2Local>)) -> Self {
+        let mut index: HashMap<[u64; 4], u32> = HashMap::new();
+        let mut k = FrLocal::from(1usize);
+        let mut n = 0usize;
+        for root in rr.roots() {
+            assert!(root == k, "zk_qap_upload_sparse_integers needs the roots 1, 2, 3, ...");
+            index.insert(fr_to_words(&root), n as u32);
+            k = k + FrLocal::from(1usize);
+            n += 1;
+        }
+        Self::from_rows(rr, &index, n, None, Some(sigma)).0
+    }
+
+    fn from_rows<R: RootRepresentation<FrLocal>>(rr: &R, index: &HashMap<[u64; 4], u32>, n: usize, log_n: Option<u32>,
+                                                 given: Option<(&SigmaG1<G1Local>, &SigmaG2<G2Local>)>)
         -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {
         struct Rows { ptr: Vec<u64>, gate: Vec<u32>, val: Vec<u64> }
         let collect = |rows: R::Row| -> Rows {
@@ -464,7 +481,14 @@ impl GpuProver {
                 Some(_) => check(ctx.0, zk_qap_upload_sparse(ctx.0, &desc, &mut q)),
                 None => check(ctx.0, zk_qap_upload_sparse_integers(ctx.0, &desc, n, &mut q)),
             }
-            check(ctx.0, zk_setup(ctx.0, q, td.as_ptr(), &mut crs));
+            match given {
+                Some((s1, s2)) => {
+                    let (c, cn, cm, cl) = upload_crs(&ctx, s1, s2);
+                    assert!(cn == n && cm == m && cl == rr.input(), "CRS and circuit dimensions differ");
+                    crs = c;
+                }
+                None => check(ctx.0, zk_setup(ctx.0, q, td.as_ptr(), &mut crs)),
+            }
         }
         let sigma = download_crs(&ctx, crs, n, m, rr.input());
         (GpuProver { ctx, qap: q, crs, n, m, input: rr.input() }, sigma)

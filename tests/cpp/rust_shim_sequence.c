@@ -190,6 +190,14 @@ int main(int argc, char** argv) {
         uint8_t ps[ZK_PROOF_BYTES];
         ZK(zk_prove(ctx, cs, qs, weights, m, r, s, ps));
         CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
+        zk_crs_free(cs);
+        /* ---- GpuProver::with_sigma_integers: the same rows with the HOST CRS of gpu::setup above (the reference's arrays only:
+         *      zk_crs_upload; the library derives the Lagrange-basis points from [x^i] at the first proof) ---- */
+        ZK(zk_crs_upload(ctx, &desc, &cs));
+        memset(ps, 0, sizeof ps);
+        ZK(zk_prove(ctx, cs, qs, weights, m, r, s, ps));
+        CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
+        CHECK(zk_qap_kind(qs) == 2);
         zk_crs_free(cs); zk_qap_free(qs);
         for (int k = 0; k < 3; ++k) { free(ptr[k]); free(gate[k]); free(val[k]); }
         printf("ok from_root_rep_integers\n");
