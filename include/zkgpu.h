@@ -66,7 +66,9 @@ const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last fai
  * 1 event-time the bucket accumulations, 2 every launch group; read back with zk_profile_*), "msm_shard_points" (zk_prove_partial:
  * 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points), "rank_tables" (multi-GPU exchange: 1 = window tables of
  * the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the reference's long
- * division; default 0 = power-series inverse above 512 quotient coefficients).  Each is exercised by a -m gpu test.
+ * division; default 0 = power-series inverse above 512 quotient coefficients), "msm_quad_buckets" (inner products of at most this
+ * many buckets run their reduction tail with four lanes per point addition: shorter dependency chains for small circuits; default
+ * 65536, 0 = never).  Each is exercised by a -m gpu test.
  * A library built with -DZK_MEASURE (make -C zksnark_rs_amd/csrc measure; zk_get_option(ctx, "measure_build") == 1) also accepts the
  * measurement switches of bench.py --opt / --serialize ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole",
  * "msm_small_lanes", "msm_unchain_lanes", "chain_order"); the product build answers ZK_ERR_UNSUPPORTED to them and to unknown keys. */

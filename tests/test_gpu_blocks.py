@@ -242,6 +242,32 @@ def test_msm_one_heavy_bucket(ctx, orc):
     assert np.array_equal(ctx.msm_g2(p2, k, 0), orc.msm_g2(p2, k, 10))
 
 
+@pytest.mark.parametrize("c", [0, 5, 12, 16, 18])
+def test_msm_tail_forms_agree(ctx, orc, c):
+    """The reduction tail (merge, row / column folds, weighted sum) exists in two forms -- one lane per point addition, and four lanes
+    sharing each addition (csrc/quad29.cuh, inner products of at most `msm_quad_buckets` buckets).  Both against the folded
+    double-and-add on the same input: repeated points (doublings inside the tail), P + (-P), infinity, buckets of many runs."""
+    n = 3000
+    rng = SplitMix64(5150 + c)
+    p1, p2, k = g1_points(orc, rng, n), g2_points(orc, rng, n), rand_fr(rng, n)
+    k[0] = 0; k[1] = ints_to_limbs([1])[0]; k[2] = ints_to_limbs([R_MODULUS - 1])[0]
+    p1[3] = 0; p2[3] = 0
+    for i in range(8, n - 40, 40):     # equal points with equal scalars; equal points with opposite scalars
+        p1[i + 1] = p1[i]; p2[i + 1] = p2[i]; k[i + 1] = k[i]
+        p1[i + 3] = p1[i + 2]; p2[i + 3] = p2[i + 2]
+        k[i + 3] = ints_to_limbs([(R_MODULUS - int(zk.limbs_to_int(k[i + 2]))) % R_MODULUS])[0]
+    k[1000:1400] = ints_to_limbs([5])[0]                      # one bucket of 400 entries per window 0
+    want1, want2 = orc.msm_g1(p1, k, 0), orc.msm_g2(p2, k, 0)
+    try:
+        for quad_buckets in (0, 1 << 22):
+            ctx.set_option("msm_quad_buckets", quad_buckets)
+            assert np.array_equal(ctx.msm_g1(p1, k, c), want1), (c, quad_buckets)
+            assert np.array_equal(ctx.msm_g2(p2, k, c), want2), (c, quad_buckets)
+    finally:
+        ctx.set_option("msm_quad_buckets", 65536)
+    assert ctx.get_option("msm_quad_buckets") == 65536
+
+
 def test_msm_linearity_large(ctx, orc):
     """Size-independent property at 2^18 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b)."""
     rng = SplitMix64(78)

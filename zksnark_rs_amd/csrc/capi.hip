@@ -96,6 +96,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "rank_tables")) return &ctx->opt_rank_tables;
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
+    if (!std::strcmp(key, "msm_quad_buckets")) return &ctx->opt_quad_buckets;
 #ifdef ZK_MEASURE
     // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;

@@ -108,6 +108,7 @@ struct zk_ctx {
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
     long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
+    long opt_quad_buckets = 65536; // inner products of at most this many buckets run their reduction tail with four lanes per addition (msm_quad.hpp)
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;

@@ -31,6 +31,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "lazy29.cuh"
+#include "quad29.cuh"
 
 namespace zk {
 
@@ -401,6 +402,8 @@ __global__ __launch_bounds__(256, TailWaves<F>::value) void k_msm_sum_points(con
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
+#include "msm_quad.hpp"   // the same tail with four lanes per addition, for products of few buckets
+
 template <class F>
 hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
                     int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp) {
@@ -453,6 +456,9 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
     const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
     const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
+    // Few buckets: the tail is a chain of dependent additions on lanes that have nothing else to do, so four lanes share each
+    // addition (msm_quad.hpp: ~3x shorter chains).  Many buckets (the products of 2^20 points and more, batches): one lane per addition.
+    const bool quad = (size_t)buckets <= (size_t)std::max<long>(ctx->opt_quad_buckets, 0);
     const int run_wgs = (int)ceil_div(buckets, 256);
 
     ws.hist.ensure((size_t)chunks * bins);
@@ -475,7 +481,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.bucket_sums.ensure(((size_t)buckets + max_extra) * sizeof(AccSlot<F>));              // S_b as accumulator images | extra runs
     const size_t half = ((size_t)buckets + 1) / 2, quarter = ((size_t)buckets + 3) / 4;
     ws.fold.ensure((2 * (half + quarter) + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // per chain: passes 1, 3, .. | passes 2, 4, ..; then C | R
-    ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * sizeof(Jac<F>));   // terms | partial sums
+    ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * std::max(sizeof(Jac<F>), sizeof(AccSlot<F>)));   // terms | partial sums
     const size_t heavy_cap = 2 + 2 * ((size_t)buckets + max_extra / MSM_HEAVY_CHUNK + 1) + (size_t)buckets;   // count, count | (bucket, chunk) items | multi-chunk buckets, from the end
     ws.heavy.ensure(heavy_cap);
     AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
@@ -547,7 +553,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (max_extra + 5.0 * buckets), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
+        if (quad) hipLaunchKernelGGL(k_msm_merge_q<F>, dim3(ceil_div(buckets, QUAD_JOBS)), dim3(QUAD_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
+        else hipLaunchKernelGGL(k_msm_merge<F>, dim3(ceil_div(buckets, TAIL_THREADS)), dim3(TAIL_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
         // heavy buckets are outliers when the average bucket is a few runs (a small grid that mostly finds nothing to do -- surplus
         // workgroups read the count and leave; a narrow top window makes 2^(top bits) buckets heavy at once); with few buckets and many
         // entries (small windows) nearly every bucket is heavy
@@ -569,11 +576,19 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                 const uint32_t f = std::min(h.count, FOLD);
                 AccSlot<F>* out = h.count == f ? h.fin : h.tmp[h.tog];
                 const uint32_t A = h.outer * (h.count / f);
-                job[q] = FoldJob{h.in, out, A, f, h.B, (uint32_t)ceil_div((size_t)A * h.B, TAIL_THREADS)};
+                job[q] = FoldJob{h.in, out, A, f, h.B, (uint32_t)ceil_div((size_t)A * h.B, quad ? QUAD_JOBS : TAIL_THREADS)};
                 if (h.count == f) h.done = true;
                 h.count /= f; h.in = out; h.tog ^= 1;
             }
-            hipLaunchKernelGGL(k_msm_fold<F>, dim3(job[0].blocks + job[1].blocks), dim3(TAIL_THREADS), 0, st, job[0], job[1]);
+            if (quad) hipLaunchKernelGGL(k_msm_fold_q<F>, dim3(job[0].blocks + job[1].blocks), dim3(QUAD_THREADS), 0, st, job[0], job[1]);
+            else hipLaunchKernelGGL(k_msm_fold<F>, dim3(job[0].blocks + job[1].blocks), dim3(TAIL_THREADS), 0, st, job[0], job[1]);
+        }
+        if (quad) {
+            AccSlot<F>* d_term = reinterpret_cast<AccSlot<F>*>(ws.seg_sums.p);
+            hipLaunchKernelGGL(k_msm_weigh_q<F>, dim3(ceil_div(K + rows, QUAD_JOBS), groups), dim3(QUAD_THREADS), 0, st, d_C, d_R, kbits, rows, d_term);
+            hipLaunchKernelGGL(k_msm_sum_q<F>, dim3(groups), dim3(QUAD_SUM_THREADS), 0, st, d_term, K + rows, d_out, grp.out_stride);
+            ZK_HIP(hipGetLastError());
+            return st;
         }
         hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(TAIL_THREADS), 0, st, d_C, d_R, kbits, rows, d_seg);
         // K + rows terms per group: one workgroup while each lane has at most 4 of them, otherwise two levels
