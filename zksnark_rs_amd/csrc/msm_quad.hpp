@@ -6,9 +6,17 @@
 // (inside namespace zk; quad29.cuh is included at the top of msm_impl.hpp)
 constexpr int QUAD_THREADS = 64;                  // one wave = 16 jobs: fits wherever an accumulation wave retires (see TAIL_THREADS)
 constexpr int QUAD_JOBS = QUAD_THREADS / 4;
+// Registers: the Fq2 kernels are left all 256 + AGPRs (one wave per SIMD).  They serve products of few buckets, i.e. small circuits, where no
+// chip-filling accumulation competes for the register files (that argument, TailWaves, is for 2^20 gates: there the G2 product has
+// 2^19 buckets and takes the one-lane tail); capped at 168 they carried ~450 B of spills through every addition.
+#ifndef ZK_QUAD_G2_WAVES
+#define ZK_QUAD_G2_WAVES 1
+#endif
+template <class F> struct QuadWaves { static constexpr int value = TailWaves<F>::value; };
+template <> struct QuadWaves<Fq2> { static constexpr int value = ZK_QUAD_G2_WAVES; };
 
 template <class F>
-__global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_merge_q(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
+__global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_merge_q(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
                                                      AccSlot<F>* __restrict__ img, uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
     ZK_LATENCY_KERNEL();
     const uint32_t b = blockIdx.x * QUAD_JOBS + (threadIdx.x >> 2);
@@ -34,7 +42,7 @@ __global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_merge
 }
 
 template <class F>
-__global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_fold_q(FoldJob j0, FoldJob j1) {
+__global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_fold_q(FoldJob j0, FoldJob j1) {
     ZK_LATENCY_KERNEL();
     const bool second = blockIdx.x >= j0.blocks;
     const AccSlot<F>* in = reinterpret_cast<const AccSlot<F>*>(second ? j1.in : j0.in);
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_fold_
 
 // term[group][j] as in k_msm_weigh, kept as accumulator images
 template <class F>
-__global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_weigh_q(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
+__global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_weigh_q(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
                                                      AccSlot<F>* __restrict__ term) {
     ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(QUAD_THREADS, TailWaves<F>::value) void k_msm_weigh
 // one workgroup per group (blockIdx.x): its 64 quads add the `count` terms (each quad its share, then a tree over LDS) -> out
 constexpr int QUAD_SUM_THREADS = 256;
 template <class F>
-__global__ __launch_bounds__(QUAD_SUM_THREADS, TailWaves<F>::value) void k_msm_sum_q(const AccSlot<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
+__global__ __launch_bounds__(QUAD_SUM_THREADS, QuadWaves<F>::value) void k_msm_sum_q(const AccSlot<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
     ZK_LATENCY_KERNEL();
     __shared__ AccSlot<F> sh[QUAD_SUM_THREADS / 4];
     constexpr int Q = QUAD_SUM_THREADS / 4;

@@ -37,9 +37,9 @@ static_assert(sizeof(MsmResults) == 4 * 96 + 192, "partial layout");
 static_assert(sizeof(MsmResults) <= ZK_PARTIAL_BYTES, "ZK_PARTIAL_BYTES too small");
 
 struct AssemblePre {
-    G1J r_delta;      // r * delta1
+    G1J r_delta;      // alpha1 + r * delta1
     G1J fixed_c;      // s * alpha1 + r * beta1 + (r s) * delta1
-    G2J s_delta2;     // s * delta2
+    G2J s_delta2;     // beta2 + s * delta2
 };
 
 __device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >> 3] >> ((w & 7) * 4)) & 15u; }
@@ -51,7 +51,8 @@ __device__ __forceinline__ uint32_t nibble(const Fr& k, int w) { return (k.l[w >
 // (s delta2).  All waves run the SAME loop with workgroup barriers at uniform places -- the G1 / G2 difference is inside
 // barrier-free regions -- so no barrier sits in divergent control flow.
 __device__ __forceinline__ void assemble_pre_body(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1, const G1A* __restrict__ ft_delta1,
-                                                  const G2A* __restrict__ ft_delta2, const Fr& r, const Fr& s, AssemblePre* __restrict__ out) {
+                                                  const G2A* __restrict__ ft_delta2, const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2,
+                                                  const Fr& r, const Fr& s, AssemblePre* __restrict__ out) {
     __shared__ G1J sh1[4][64];
     __shared__ G2J sh2[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -70,23 +71,24 @@ __device__ __forceinline__ void assemble_pre_body(const G1A* __restrict__ ft_alp
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out->r_delta = sh1[0][0];
         out->fixed_c = jac_add_ni(jac_add_ni(sh1[1][0], sh1[2][0]), sh1[3][0]);
     }
-    if (threadIdx.x == 256) out->s_delta2 = sh2[0];
+    // the constant terms of a and b join here, off the critical path: k_assemble is left with ONE addition per proof element
+    if (threadIdx.x == 64) out->r_delta = jac_madd_ni(sh1[0][0], *alpha1);
+    if (threadIdx.x == 256) out->s_delta2 = jac_madd_ni(sh2[0], *beta2);
 }
 __global__ __launch_bounds__(320) void k_assemble_pre(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
                                                       const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
-                                                      Fr r, Fr s, AssemblePre* __restrict__ out) {
+                                                      const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, Fr r, Fr s, AssemblePre* __restrict__ out) {
     ZK_LATENCY_KERNEL();
-    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, r, s, out);
+    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, alpha1, beta2, r, s, out);
 }
 // batch form (zk_prove_batch_*): workgroup j serves proof j; (r, s) pairs in device memory
 __global__ __launch_bounds__(320) void k_assemble_pre_batch(const G1A* __restrict__ ft_alpha1, const G1A* __restrict__ ft_beta1,
                                                             const G1A* __restrict__ ft_delta1, const G2A* __restrict__ ft_delta2,
-                                                            const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
+                                                            const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, const Fr* __restrict__ rs, AssemblePre* __restrict__ out) {
     ZK_LATENCY_KERNEL();
-    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, rs[2 * blockIdx.x], rs[2 * blockIdx.x + 1], out + blockIdx.x);
+    assemble_pre_body(ft_alpha1, ft_beta1, ft_delta1, ft_delta2, alpha1, beta2, rs[2 * blockIdx.x], rs[2 * blockIdx.x + 1], out + blockIdx.x);
 }
 
 __device__ __forceinline__ void put_be32(const Fq& x_mont, uint8_t* out) {
@@ -123,33 +125,30 @@ __device__ void encode_g2(const G2J& p, const Fq2& lambda, uint8_t* out) {
     put_be32(a.y.c0, out + 97);
 }
 
-// (mod.rs:274-293)  a = A + alpha + r delta ;  b = B2 + beta2 + s delta2 ;
+// (mod.rs:274-293)  a = A + [alpha + r delta] ;  b = B2 + [beta2 + s delta2] ;   (brackets: k_assemble_pre)
 // c = H + L + s a + r (beta + B1 + s delta) - (r s) delta
 //   = [H + r B1 + s A] + L + [s alpha + r beta + (r s) delta]
 // where H + r B1 + s A comes out of ONE inner product: scalars h_i over xi_t and (r v_i + s u_i) over
 // xi.  No scalar multiplication with a run-time base is left.
-__device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const G1A* __restrict__ alpha1,
-                                              const G2A* __restrict__ beta2, const AssembleBlind& bl, uint8_t* __restrict__ proof) {
+__device__ __forceinline__ void assemble_body(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const AssembleBlind& bl, uint8_t* __restrict__ proof) {
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x & 63) return;
-    if (wave == 0) encode_g1(jac_add_ni(jac_madd_ni(ms->a, *alpha1), pre->r_delta), bl.a, proof);
-    if (wave == 1) encode_g2(jac_add_ni(jac_madd_ni(ms->b2, *beta2), pre->s_delta2), bl.b, proof + 65);
+    if (wave == 0) encode_g1(jac_add_ni(ms->a, pre->r_delta), bl.a, proof);
+    if (wave == 1) encode_g2(jac_add_ni(ms->b2, pre->s_delta2), bl.b, proof + 65);
     if (wave == 2) encode_g1(jac_add_ni(jac_add_ni(ms->hb, ms->l), pre->fixed_c), bl.c, proof + 65 + 129);
 }
-__global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre,
-                                                  const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, AssembleBlind bl, uint8_t* __restrict__ proof) {
+__global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, AssembleBlind bl, uint8_t* __restrict__ proof) {
     ZK_LATENCY_KERNEL();
-    assemble_body(ms, pre, alpha1, beta2, bl, proof);
+    assemble_body(ms, pre, bl, proof);
 }
 
 // batch form: workgroup j assembles proof j from blob j of the partial sums
-__global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre,
-                                                        const G1A* __restrict__ alpha1, const G2A* __restrict__ beta2, AssembleBlind bl, uint8_t* __restrict__ proofs) {
+__global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre, AssembleBlind bl, uint8_t* __restrict__ proofs) {
     ZK_LATENCY_KERNEL();
     // one draw per batch, made different for every proof of it (bl . (j + 1): still uniform, still unknown)
     const Fq j1 = Fq::from_u32(blockIdx.x + 1);
     bl.a = bl.a * j1; bl.b = Fq2{bl.b.c0 * j1, bl.b.c1 * j1}; bl.c = bl.c * j1;
-    assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, alpha1, beta2, bl,
+    assemble_body(reinterpret_cast<const MsmResults*>(blobs + (size_t)blockIdx.x * ZK_PARTIAL_BYTES), pre + blockIdx.x, bl,
                   proofs + (size_t)blockIdx.x * ZK_PROOF_BYTES);
 }
 
@@ -310,7 +309,7 @@ void prove_exchange_elems(const zk_qap& q, int world, size_t out[4]) {
 }
 
 static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr& rc, const Fr& sc, AssembleScratch* d_as) {
-    hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, rc, sc, &d_as->pre);
+    hipLaunchKernelGGL(k_assemble_pre, dim3(1), dim3(320), 0, st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p, crs.alpha1.p, crs.beta2.p, rc, sc, &d_as->pre);
     ZK_HIP(hipGetLastError());
 }
 
@@ -562,7 +561,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
         {
             ProfScope pscope(ctx, "assemble", 0, fin);
-            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), S.d_proof.p);
+            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, ps.draw_blind(), S.d_proof.p);
         }
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
@@ -690,7 +689,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         hipStream_t pre_st = ctx->opt_serialize ? st : ctx->side;
         ZK_HIP(hipMemcpyAsync(S.b_rs.p, S.h_b_rs, (size_t)count * 2 * sizeof(Fr), hipMemcpyHostToDevice, pre_st));
         hipLaunchKernelGGL(k_assemble_pre_batch, dim3(count), dim3(320), 0, pre_st, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p,
-                           S.b_rs.p, S.b_pre.p);
+                           crs.alpha1.p, crs.beta2.p, S.b_rs.p, S.b_pre.p);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
     }
@@ -780,7 +779,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
     {
         ProfScope pscope(ctx, "assemble", 0, fin);
-        hipLaunchKernelGGL(k_assemble_batch, dim3(count), dim3(192), 0, fin, S.b_partials.p, S.b_pre.p, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), S.b_proofs.p);
+        hipLaunchKernelGGL(k_assemble_batch, dim3(count), dim3(192), 0, fin, S.b_partials.p, S.b_pre.p, ps.draw_blind(), S.b_proofs.p);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(S.h_b_proofs, S.b_proofs.p, (size_t)count * ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
@@ -878,7 +877,7 @@ void prove_combine_on(zk_ctx* ctx, const zk_crs& crs_c, const void* d_partials, 
     ProveState& ps = prove_state(ctx);
     launch_pre(ctx, crs, st, rc, sc, ps.comb_as.p);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(320), 0, st, (const uint8_t*)d_partials, world, ps.comb_ms.p);
-    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, crs.alpha1.p, crs.beta2.p, ps.draw_blind(), ps.comb_proof.p);
+    hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, st, ps.comb_ms.p, &ps.comb_as.p->pre, ps.draw_blind(), ps.comb_proof.p);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(h_proof_pinned, ps.comb_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, st));
 }
