@@ -100,7 +100,7 @@ int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
 
 /* Element-wise field / group kernels (diagnostic entry points used by the parity tests).
  * op: 0 add, 1 sub, 2 mul, 3 inverse of a (b ignored; ZK_ERR_DIV_BY_ZERO if any a == 0), 4 the same inverse by the
- * binary extended Euclid that closes a proof (ff.cuh inv_vartime)
+ * binary extended Euclid (ff.cuh inv_euclid), 5 by division steps in batches of 30 (inv_divsteps: what closes a proof)
  * FrLocal Add/Sub/Mul/Div: fr.rs:18-71 */
 int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

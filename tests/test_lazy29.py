@@ -146,3 +146,21 @@ def test_lazy29_argument_errors(ctx):
     assert ctx.lib.zk_lazy29_batch(ctx.ptr, 1, FR_REDUCE, ap, None, None, None, 1, op, None) == -1   # Fr-only op
     assert ctx.lib.zk_lazy29_batch(ctx.ptr, 0, MONT, ap, None, None, None, 1, op, None) == -1        # missing operand
     assert ctx.lib.zk_lazy29_batch(ctx.ptr, 0, 9, ap, None, None, None, 1, op, None) == -1
+
+
+def test_three_inversions_agree_on_the_host(tmp_path):
+    """ff.cuh is __host__ __device__: Fermat's ladder, the binary extended Euclid and the division steps in batches of 30 that close
+    every proof (inv_divsteps) on small values, powers of two and 20000 random values per field, plus x * x^-1 == 1 -- compiled with
+    hipcc and run on the CPU (tests/cpp/inverse_check.hip).  The GPU side of the same code: test_field_ops[inv_divsteps]."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "inverse_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "zksnark_rs_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "inverse_check.hip"), "-o", exe], check=True, capture_output=True, text=True, timeout=600)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "Fr: 20850 cases, 0 bad" in res.stdout and "Fq: 20850 cases, 0 bad" in res.stdout, res.stdout + res.stderr

@@ -214,10 +214,10 @@ class Context:
         return out
 
     def fr_batch(self, op, a, b=None):
-        return self._batch(self.lib.zk_fr_batch, {"add": 0, "sub": 1, "mul": 2, "inv": 3, "inv_euclid": 4}[op], a, b)
+        return self._batch(self.lib.zk_fr_batch, {"add": 0, "sub": 1, "mul": 2, "inv": 3, "inv_euclid": 4, "inv_divsteps": 5}[op], a, b)
 
     def fq_batch(self, op, a, b=None):
-        return self._batch(self.lib.zk_fq_batch, {"add": 0, "sub": 1, "mul": 2, "inv": 3, "inv_euclid": 4}[op], a, b)
+        return self._batch(self.lib.zk_fq_batch, {"add": 0, "sub": 1, "mul": 2, "inv": 3, "inv_euclid": 4, "inv_divsteps": 5}[op], a, b)
 
     def _pt2(self, fn, words, a, b, bwords):
         a, ap = _u64(np.asarray(a).reshape(-1, words))

@@ -135,10 +135,10 @@ ZK_NI Aff<F> jac_to_affine(const Jac<F>& p) {
     return Aff<F>{p.X * zi2, p.Y * zi2 * zi};
 }
 
-// The same with the data-dependent inversion (ff.cuh inv_vartime), for single-lane callers.  Z depends on the witness (it is a
+// The same with the data-dependent inversion (ff.cuh inv_vartime = division steps in batches of 30), for single-lane callers.  Z depends on the witness (it is a
 // product of the differences met along the addition chain) and cannot be recovered from the affine point, so it is NOT public: what is
 // inverted is Z * lambda for a fresh uniformly random lambda != 0 the caller supplies, whose distribution -- and with it the trip
-// count of the Euclidean loop -- is independent of Z; 1 / Z = lambda / (Z lambda).
+// count of the loop -- is independent of Z; 1 / Z = lambda / (Z lambda).
 template <class F>
 ZK_NI Aff<F> jac_to_affine_vartime(const Jac<F>& p, const F& lambda) {
     if (p.is_inf()) return Aff<F>::infinity();

@@ -15,9 +15,9 @@ __global__ void k_field_batch(int op, const F* __restrict__ a, const F* __restri
     if (!x.raw_in_range()) { atomicOr(flag, 2); return; }
     x = F::from_canonical(x);
     F r;
-    if (op == 3 || op == 4) {
+    if (op >= 3) {
         if (x.is_zero()) { atomicOr(flag, 1); return; }
-        r = op == 3 ? x.inv() : x.inv_vartime();
+        r = op == 3 ? x.inv() : op == 4 ? x.inv_euclid() : x.inv_divsteps();
     } else {
         F y = b[i];
         if (!y.raw_in_range()) { atomicOr(flag, 2); return; }
@@ -29,7 +29,7 @@ __global__ void k_field_batch(int op, const F* __restrict__ a, const F* __restri
 
 template <class F>
 void field_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    ZK_REQUIRE(a && out && (op >= 3 || b) && op >= 0 && op <= 4, ZK_ERR_ARG, "zk_f*_batch: bad argument");
+    ZK_REQUIRE(a && out && (op >= 3 || b) && op >= 0 && op <= 5, ZK_ERR_ARG, "zk_f*_batch: bad argument");
     if (n == 0) return;
     DevBuf<F> da(n), db(op >= 3 ? 0 : n), dout(n);
     DevBuf<int> flag(1);

@@ -436,8 +436,8 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         deferred.emplace_back(k, [&, k, tab, scalars, count, out, ms_st](int after) { launch_now(k, after, *tab, scalars, count, out, ms_st); });
     };
     auto run_deferred = [&] {
-        static const int orders[2][4] = {{1, 0, 2, 4}, {1, 2, 0, 4}};   // MSM slots: 1 = L, 0 = B in G2, 2 = A, 4 = H + r B1 + s A
-        const int* order = orders[ctx->opt_chain_order == 1 ? 1 : 0];
+        static const int orders[3][4] = {{1, 0, 2, 4}, {1, 2, 0, 4}, {0, 1, 4, 2}};   // MSM slots: 1 = L, 0 = B in G2, 2 = A, 4 = H + r B1 + s A
+        const int* order = orders[ctx->opt_chain_order == 1 ? 1 : ctx->opt_chain_order == 2 ? 2 : 0];
         int prev = -1;
         for (int pos = 0; pos < 4; ++pos)
             for (auto& d : deferred)
