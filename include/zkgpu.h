@@ -84,6 +84,12 @@ long zk_get_option(const zk_ctx* ctx, const char* key);
  * with w = 5^((r-1)/2^log_n).  coset=1 evaluates on / interpolates from the coset g*<w> with
  * g = 5^((r-1)/2^(log_n+1)) (forward: in[j] *= g^j first; inverse: out[j] *= g^-j last).  log_n <= 24 (23 with coset). */
 int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset);
+/* Interpolation through ARBITRARY distinct nodes: coeffs[0..n) = the coefficients of the polynomial of degree < n with
+ * p(roots[k]) = values[k] -- what QAP::from does per wire polynomial with Lagrange sums (fr.rs:140-173, coefficient_poly.rs:159-200;
+ * O(n^2) each) and the prover of an arbitrary-roots QAP (zk_qap_upload_sparse_roots) does per proof for U, V and the interpolant of the
+ * products, by a sub-product tree over batched NTTs in O(n log^2 n) (csrc/interp.hip).  1 <= n <= 2^23; ZK_ERR_ARG when two roots
+ * coincide.  (The per-root-set tables cost O(n^2) field multiplications once.) */
+int zk_interpolate_fr(zk_ctx* ctx, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs);
 
 /* sum_i scalars[i] * points[i]: the SigmaG1/SigmaG2 inner products of groth16::prove
  * (groth16/mod.rs:255-272,279-290), i.e. n x exp_encrypted_g1/g2 (fr.rs:114-119) folded with

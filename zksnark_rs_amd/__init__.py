@@ -188,6 +188,16 @@ class Context:
         self._check(self.lib.zk_ntt_fr(self.ptr, a.ctypes.data_as(_lib.u64p), log_n, int(inverse), int(coset)))
         return a
 
+    def interpolate_fr(self, roots, values):
+        """coefficients of the polynomial of degree < n through (roots[k], values[k]) -- zk_interpolate_fr"""
+        r = np.ascontiguousarray(np.asarray(roots, dtype=np.uint64).reshape(-1, 4))
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.uint64).reshape(-1, 4))
+        if r.shape != v.shape:
+            raise ValueError("roots and values differ in length")
+        out = np.zeros_like(r)
+        self._check(self.lib.zk_interpolate_fr(self.ptr, r.ctypes.data_as(_lib.u64p), v.ctypes.data_as(_lib.u64p), r.shape[0], out.ctypes.data_as(_lib.u64p)))
+        return out
+
     def _msm(self, fn, words, points, scalars, window_bits):
         p, pp = _u64(np.asarray(points).reshape(-1, words))
         s, sp = _u64(np.asarray(scalars).reshape(-1, 4))

@@ -79,6 +79,7 @@ SIGNATURES = {
     "zk_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "zk_get_option": (C.c_long, [C.c_void_p, C.c_char_p]),
     "zk_ntt_fr": (C.c_int, [C.c_void_p, u64p, C.c_uint, C.c_int, C.c_int]),
+    "zk_interpolate_fr": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, u64p]),
     "zk_msm_g1": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
     "zk_msm_g2": (C.c_int, [C.c_void_p, u64p, u64p, C.c_size_t, C.c_int, u64p]),
     "zk_lazy29_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, i32p, i32p, i32p, i32p, C.c_size_t, u64p, i32p]),

@@ -5,6 +5,7 @@
 #include <vector>
 #include "kernels.hpp"
 #include "pipeline.hpp"
+#include "interp.hpp"
 
 using namespace zk;
 
@@ -133,6 +134,10 @@ long zk_get_option(const zk_ctx* ctx, const char* key) {
 int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset) {
     if (!ctx) return ZK_ERR_ARG;
     return guarded(ctx, [&] { ntt_host(ctx, data, log_n, inverse, coset); ctx->resolve_profile(); });
+}
+int zk_interpolate_fr(zk_ctx* ctx, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs) {
+    if (!ctx) return ZK_ERR_ARG;
+    return guarded(ctx, [&] { interp_host(ctx, roots, values, n, coeffs); ctx->resolve_profile(); });
 }
 int zk_msm_g1(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t out[ZK_G1_WORDS]) {
     if (!ctx) return ZK_ERR_ARG;

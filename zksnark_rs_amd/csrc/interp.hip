@@ -1,0 +1,246 @@
+// interp.hip -- interpolation through ARBITRARY distinct nodes in O(n log^2 n): the coefficients of the polynomial of degree < n
+// that takes given values on caller-supplied roots r_0 .. r_{n-1}.
+//
+// QAP::from (/root/reference/src/groth16/fr.rs:140-173) interpolates every wire polynomial through the roots of the
+// RootRepresentation (circuit/mod.rs:201-214: `roots()` is caller data) with Lagrange sums (coefficient_poly.rs:159-200, O(n^2) per
+// polynomial).  The prover only ever needs the three combinations U = sum a_i u_i, V, and the interpolant E of the products U_k V_k
+// (aproots.hip: W + rem = E), so it interpolates THOSE, per proof, from their values on the roots (the SpMV output):
+//     F(x) = sum_k a_k N(x) / (x - r_k),   a_k = F_k / N'(r_k),   N(x) = prod_k (x - r_k)
+// by the sub-product tree: a node that covers the leaves [lo, hi) holds N_node = prod (x - r_k) and P_node = sum a_k N_node / (x - r_k);
+//     P_parent = P_left N_right + P_right N_left,   N_parent = N_left N_right.
+// Layout for the GPU:
+//   * the bottom of the tree is flat: blocks of 64 leaves with a per-QAP 64 x 64 matrix q[i][k] = coefficient i of N_block / (x - r_k)
+//     divided by N'(r_k), so a block's P is one small matrix-vector product per proof (no tree below 64 leaves, no tiny transforms);
+//   * above, one level = batched transforms (ntt.hip, one launch per pass for ALL nodes of the level and all vectors): children padded
+//     to twice their size, forward DIF, P_l N_r + P_r N_l point-wise against the stored images of the children's N, inverse DIT;
+//   * leaves beyond n are empty (N = 1, P = 0), so n is arbitrary; a node's N has degree = its number of real leaves.
+// Per-QAP precompute: N'(r_k) = prod_{j != k} (r_k - r_j) directly (O(n^2) field multiplications, 0.6 s at 2^18, once per circuit),
+// the block matrices, the images of every node's N (2 npad elements per level), t = N_root.
+#include <vector>
+#include "pipeline.hpp"
+#include "interp.hpp"
+
+namespace zk {
+
+constexpr int IB = INTERP_BLOCK;   // leaves per bottom block
+
+// ---- per-QAP tables ---------------------------------------------------------------------------------------------------------
+// d[k] = prod_{j != k} (r_k - r_j); flag |= 16 when two roots coincide
+__global__ void k_interp_nprime(const Fr* __restrict__ r, size_t n, Fr* __restrict__ out, int* __restrict__ flag) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Fr rk = r[k];
+    Fr acc = Fr::one();
+    for (size_t j = 0; j < n; ++j) {
+        const Fr d = rk - r[j];
+        acc = acc * (j == k ? Fr::one() : d);
+    }
+    if (acc.is_zero()) { atomicOr(flag, 16); out[k] = Fr::zero(); return; }
+    out[k] = acc.inv();
+}
+
+// One workgroup (IB lanes) per block of IB leaves.  Lane k: Q_k = prod_{j in block, j != k} (x - r_j) (IB coefficients, degree = real
+// leaves - 1), q[block][i][k] = w_k Q_k[i].  Lane 0 also writes the block's N = Q_0 (x - r_0) as a full coefficient list (degree
+// d = real leaves of the block) into node[block * 2 IB ..] (zero padded to 2 IB: the layout of level 0).
+__global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __restrict__ r, const Fr* __restrict__ w, size_t n, Fr* __restrict__ qmat, Fr* __restrict__ node) {
+    __shared__ Fr rs[IB];
+    const size_t blk = blockIdx.x, base = blk * IB;
+    const int k = threadIdx.x;
+    const int real = (int)(base >= n ? 0 : (n - base < (size_t)IB ? n - base : IB));
+    rs[k] = k < real ? r[base + k] : Fr::zero();
+    __syncthreads();
+    Fr c[IB + 1];
+#pragma unroll 1
+    for (int i = 0; i <= IB; ++i) c[i] = Fr::zero();
+    c[0] = Fr::one();
+    int deg = 0;
+    for (int j = 0; j < real; ++j) {
+        if (j == k) continue;
+        const Fr rj = rs[j];
+        // c <- c (x - r_j)
+        for (int i = deg + 1; i >= 1; --i) c[i] = c[i - 1] - rj * c[i];
+        c[0] = Fr::zero() - rj * c[0];
+        ++deg;
+    }
+    const Fr wk = k < real ? w[base + k] : Fr::zero();
+    Fr* q = qmat + blk * (size_t)IB * IB;
+    for (int i = 0; i < IB; ++i) q[(size_t)i * IB + k] = (k < real && i <= deg) ? wk * c[i] : Fr::zero();
+    if (k == 0) {
+        Fr* out = node + blk * (size_t)(2 * IB);
+        if (real == 0) {
+            out[0] = Fr::one();
+            for (int i = 1; i < 2 * IB; ++i) out[i] = Fr::zero();
+        } else {
+            // N_block = Q_0 (x - r_0)
+            const Fr r0 = rs[0];
+            Fr prev = Fr::zero();
+            for (int i = 0; i <= deg + 1; ++i) {
+                const Fr ci = i <= deg ? c[i] : Fr::zero();
+                out[i] = prev - r0 * ci;
+                prev = ci;
+            }
+            for (int i = deg + 2; i < 2 * IB; ++i) out[i] = Fr::zero();
+        }
+    }
+}
+
+// number of real leaves under node `idx` of a level whose nodes cover `size` leaves each
+__device__ __host__ inline size_t interp_degree(size_t idx, size_t size, size_t n) {
+    const size_t lo = idx * size;
+    return lo >= n ? 0 : (n - lo < size ? n - lo : size);
+}
+
+// parents of a level from the cyclic products of their children (prod: parents x 2s, the product of two polynomials of degree <= s
+// modulo x^(2s) - 1): the full coefficient list of degree d = d_l + d_r, zero padded to 4s -- the children layout of the next level.
+// When d = 2s the leading 1 wrapped onto coefficient 0.
+__global__ void k_interp_place(const Fr* __restrict__ prod, size_t parents, size_t s2, size_t n, Fr* __restrict__ next) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= parents * 2 * s2) return;
+    const size_t p = g / (2 * s2), j = g - p * 2 * s2;
+    const size_t d = interp_degree(p, s2, n);
+    Fr v = Fr::zero();
+    if (j < s2) {
+        v = prod[p * s2 + j];
+        if (j == 0 && d == s2) v = v - Fr::one();
+    } else if (j == s2 && d == s2) {
+        v = Fr::one();
+    }
+    next[g] = v;
+}
+__global__ void k_interp_root(const Fr* __restrict__ prod, size_t npad, size_t n, Fr* __restrict__ t) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    Fr v = j < npad ? prod[j] : Fr::zero();
+    if (n == npad) { if (j == 0) v = v - Fr::one(); if (j == n) v = Fr::one(); }
+    t[j] = v;
+}
+
+// out[p][j] = node[2p][j] node[2p + 1][j], j < 2s
+__global__ void k_interp_mul_pairs(const Fr* __restrict__ node, size_t s2, size_t parents, Fr* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= parents * s2) return;
+    const size_t p = g / s2, j = g - p * s2;
+    out[g] = node[(2 * p) * s2 + j] * node[(2 * p + 1) * s2 + j];
+}
+
+// ---- per proof --------------------------------------------------------------------------------------------------------------
+// P of the bottom blocks: out[v][blk IB + i] = sum_k values[v][blk IB + k] q[blk][i][k]   (values beyond n are not read)
+__global__ void k_interp_bottom(const Fr* __restrict__ values, size_t vstride, const Fr* __restrict__ qmat, size_t n, size_t npad, Fr* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= npad) return;
+    const size_t blk = g / IB, base = blk * IB;
+    const Fr* f = values + (size_t)blockIdx.y * vstride + base;
+    const Fr* q = qmat + g * IB;
+    const int real = (int)(base >= n ? 0 : (n - base < (size_t)IB ? n - base : IB));
+    Fr acc = Fr::zero();
+    for (int k = 0; k < real; ++k) acc = acc + f[k] * q[k];
+    out[(size_t)blockIdx.y * npad + g] = acc;
+}
+// children (size s, contiguous) -> zero padded to 2s
+__global__ void k_interp_pad(const Fr* __restrict__ cur, size_t s, size_t total2, Fr* __restrict__ tmp) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total2) return;
+    const size_t c = g / (2 * s), j = g - c * 2 * s;
+    tmp[g] = j < s ? cur[c * s + j] : Fr::zero();
+}
+// out[v][p][j] = P_l[j] N_r[j] + P_r[j] N_l[j], j < 2s; nev: the images of the level's children N (same order), shared by the vectors
+__global__ void k_interp_combine(const Fr* __restrict__ tmp, const Fr* __restrict__ nev, size_t s2, size_t parents, Fr* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= parents * s2) return;
+    const size_t p = g / s2, j = g - p * s2;
+    const Fr* t = tmp + (size_t)blockIdx.y * parents * 2 * s2;
+    const size_t l = (2 * p) * s2 + j, r = (2 * p + 1) * s2 + j;
+    out[(size_t)blockIdx.y * parents * s2 + g] = t[l] * nev[r] + t[r] * nev[l];
+}
+
+std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, size_t n, int* d_flag) {
+    ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << (NTT_MAX_LOG - 1)), ZK_ERR_SIZE, "interpolation: n must be in [1, 2^23]");
+    auto t = std::make_shared<InterpTree>();
+    hipStream_t st = ctx->stream;
+    t->n = n;
+    unsigned L = 0;
+    while (((size_t)1 << L) < std::max<size_t>(n, IB)) ++L;
+    t->log_npad = L;
+    const size_t npad = (size_t)1 << L;
+    t->roots.alloc(n);
+    ZK_HIP(hipMemcpyAsync(t->roots.p, d_roots_mont, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    t->w.alloc(n);
+    hipLaunchKernelGGL(k_interp_nprime, dim3(ceil_div(n, 128)), dim3(128), 0, st, t->roots.p, n, t->w.p, d_flag);
+    const size_t blocks = npad / IB;
+    t->qmat.alloc(npad * IB);
+    DevBuf<Fr> node(2 * npad), prod(npad);
+    hipLaunchKernelGGL(k_interp_blocks, dim3(blocks), dim3(IB), 0, st, t->roots.p, t->w.p, n, t->qmat.p, node.p);
+    ZK_HIP(hipGetLastError());
+    // levels: children of s = IB << l leaves, images at size 2s
+    unsigned lg = 0;
+    while ((1u << lg) < (unsigned)IB) ++lg;
+    for (unsigned l = 0; lg + l < L; ++l) {
+        const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
+        ntt_dif(ctx, node.p, lg + l + 1, false, false, children);
+        t->nev.emplace_back();
+        t->nev.back().alloc(2 * npad);
+        ZK_HIP(hipMemcpyAsync(t->nev.back().p, node.p, 2 * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        // N_parent = N_l N_r (cyclic, size 2s)
+        hipLaunchKernelGGL(k_interp_mul_pairs, dim3(ceil_div(parents * s2, 256)), dim3(256), 0, st, node.p, s2, parents, prod.p);
+        ntt_dit(ctx, prod.p, lg + l + 1, true, true, nullptr, parents);
+        if (parents > 1) hipLaunchKernelGGL(k_interp_place, dim3(ceil_div(parents * 2 * s2, 256)), dim3(256), 0, st, prod.p, parents, s2, n, node.p);
+        ZK_HIP(hipGetLastError());
+    }
+    t->t.alloc(n + 1);
+    if (L == lg) {   // a single block: its N sits in node[0 .. n]
+        ZK_HIP(hipMemcpyAsync(t->t.p, node.p, (n + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_interp_root, dim3(ceil_div(n + 1, 256)), dim3(256), 0, st, prod.p, npad, n, t->t.p);
+        ZK_HIP(hipGetLastError());
+    }
+    ZK_HIP(hipStreamSynchronize(st));   // node / prod go out of scope
+    return t;
+}
+
+void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vstride, size_t count, Fr* d_work, Fr* d_out) {
+    const size_t n = t.n, npad = (size_t)1 << t.log_npad;
+    hipStream_t st = ctx->stream;
+    Fr* cur = d_out;                      // count x npad
+    Fr* tmp = d_work;                     // count x 2 npad
+    Fr* alt = d_work + 2 * count * npad;  // count x npad
+    hipLaunchKernelGGL(k_interp_bottom, dim3(ceil_div(npad, 256), count), dim3(256), 0, st, d_values, vstride, t.qmat.p, n, npad, cur);
+    unsigned lg = 0;
+    while ((1u << lg) < (unsigned)IB) ++lg;
+    for (unsigned l = 0; lg + l < t.log_npad; ++l) {
+        const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
+        hipLaunchKernelGGL(k_interp_pad, dim3(ceil_div(2 * npad * count, 256)), dim3(256), 0, st, cur, s, 2 * npad * count, tmp);
+        ntt_dif(ctx, tmp, lg + l + 1, false, false, children * count);
+        Fr* nxt = cur == d_out ? alt : d_out;
+        hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, nxt);
+        ntt_dit(ctx, nxt, lg + l + 1, true, true, nullptr, parents * count);
+        cur = nxt;
+    }
+    if (cur != d_out) ZK_HIP(hipMemcpyAsync(d_out, cur, count * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipGetLastError());
+}
+
+// zk_interpolate_fr: host arrays in, n coefficients out (diagnostic entry point of the parity tests)
+void interp_host(zk_ctx* ctx, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs) {
+    ZK_REQUIRE(roots && values && coeffs && n >= 1, ZK_ERR_ARG, "zk_interpolate_fr: null pointer or n = 0");
+    hipStream_t st = ctx->stream;
+    DevBuf<Fr> r(n), v(n);
+    DevBuf<int> flag(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    ZK_HIP(hipMemcpyAsync(r.p, roots, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipMemcpyAsync(v.p, values, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    fr_to_mont(ctx, r.p, r.p, n, flag.p);
+    fr_to_mont(ctx, v.p, v.p, n, flag.p);
+    auto t = interp_build(ctx, r.p, n, flag.p);
+    const size_t npad = (size_t)1 << t->log_npad;
+    DevBuf<Fr> work(3 * npad), out(npad);
+    interp_run(ctx, *t, v.p, n, 1, work.p, out.p);
+    fr_from_mont(ctx, out.p, out.p, n);
+    int hflag = 0;
+    ZK_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(coeffs, out.p, n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    ZK_REQUIRE(!(hflag & 3), ZK_ERR_RANGE, "zk_interpolate_fr: element >= modulus");
+    ZK_REQUIRE(!(hflag & 16), ZK_ERR_ARG, "zk_interpolate_fr: the roots are not distinct");
+}
+
+}  // namespace zk

@@ -1,0 +1,27 @@
+// interp.hpp -- interpolation through arbitrary nodes by a sub-product tree (interp.hip)
+#pragma once
+#include <memory>
+#include <vector>
+#include "kernels.hpp"
+
+namespace zk {
+
+constexpr int INTERP_BLOCK = 64;   // leaves per flat bottom block
+
+struct InterpTree {
+    size_t n = 0;
+    unsigned log_npad = 0;            // npad = 2^log_npad >= max(n, INTERP_BLOCK)
+    DevBuf<Fr> roots, w;              // the nodes and 1 / N'(r_k), Montgomery
+    DevBuf<Fr> qmat;                  // bottom blocks: [block][i][k] = coefficient i of N_block / (x - r_k), times w_k
+    std::vector<DevBuf<Fr>> nev;      // level l: DIF images of the children's N (children of 64 << l leaves, padded to twice that): 2 npad each
+    DevBuf<Fr> t;                     // N_root = prod (x - r_k): n + 1 coefficients
+};
+
+// d_flag |= 16 when two roots coincide
+std::shared_ptr<InterpTree> interp_build(zk_ctx*, const Fr* d_roots_mont, size_t n, int* d_flag);
+// `count` vectors of values on the roots (vector v at d_values + v vstride, Montgomery) -> their interpolants' coefficients, vector v at
+// d_out + v npad (npad entries, zero behind n); d_work: 3 count npad elements.  Everything on ctx->stream.
+void interp_run(zk_ctx*, const InterpTree&, const Fr* d_values, size_t vstride, size_t count, Fr* d_work, Fr* d_out);
+void interp_host(zk_ctx*, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs);
+
+}  // namespace zk
