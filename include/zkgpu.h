@@ -163,6 +163,15 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
  * ZK_ERR_UNSUPPORTED at prove);
  * Batches and the multi-GPU entry points take both sparse forms. */
 int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, size_t n, zk_qap** out);
+/* The same rows over ANY distinct roots r_0 .. r_{n-1} the caller supplies (RootRepresentation::roots() is caller data,
+ * circuit/mod.rs:201-214, dummy_rep.rs:47): gate j = root roots[j] (4 words each, canonical), 1 <= n <= 2^22.  Equivalent to
+ * QAP::from(root_rep) (fr.rs:140-173) followed by the reference's coefficient-form prove -- byte-identical proofs -- but the 3 m wire
+ * polynomials are never interpolated: the prover interpolates U = sum a_i u_i, V and the interpolant of the products U_k V_k per proof
+ * from their values on the roots by a sub-product tree (csrc/interp.hip, O(n log^2 n)) and takes its inner products with the
+ * reference's own [x^i] arrays, so ANY CRS for the circuit serves (zk_setup, zk_crs_upload, a file).  Once per root set: O(n^2) field
+ * multiplications (0.6 s at 2^18 gates).  ZK_ERR_ARG when two roots coincide.  One proof at a time or pipelined on one GPU, or
+ * window-sharded (zk_prove_partial); batches and the scalar exchange take the two forms above (ZK_ERR_UNSUPPORTED). */
+int zk_qap_upload_sparse_roots(zk_ctx* ctx, const zk_qap_sparse_desc* desc, const uint64_t* roots, size_t n, zk_qap** out);
 
 /* Dense coefficient form, exactly the fields of QAP<CoefficientPoly<FrLocal>>: u, v, w are
  * m x n row-major (coefficient k of wire i at [i*n + k], zero padded), t has n+1 coefficients
@@ -177,7 +186,7 @@ int zk_qap_dims(const zk_qap* qap, size_t* n, size_t* m, size_t* input, int* den
 /* Which device form a QAP handle holds (a container read by zk_qap_load does not say otherwise): 0 = sparse rows over the roots of
  * unity w^j, n = 2^k (zk_qap_upload_sparse); 1 = the dense m x n coefficient matrices of QAP<CoefficientPoly<FrLocal>>
  * (groth16/mod.rs:60-67; zk_qap_upload_dense, zk_circuit_qap); 2 = sparse rows over the integers 1..n, the roots ASTParser emits
- * (circuit/mod.rs:517; zk_qap_upload_sparse_integers). */
+ * (circuit/mod.rs:517; zk_qap_upload_sparse_integers); 3 = sparse rows over the caller's roots (zk_qap_upload_sparse_roots). */
 int zk_qap_kind(const zk_qap* qap);
 /* The first stage of groth16::prove on its own (diagnostic entry point of the parity tests): u_sum = sum_i qap.u[i] * weights[i]
  * (groth16/mod.rs:233-253 -- zip with the weights, CoefficientPoly: Mul<T> coefficient_poly.rs:132-146, Sum :75-91); which = 0 / 1 / 2

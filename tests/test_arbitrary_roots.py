@@ -10,11 +10,6 @@ R = zk.R_MODULUS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    return zk.Context(0)
-
-
 def lagrange_coeffs(roots, values):
     """the reference's way (coefficient_poly.rs:159-200 restated with Python integers): sum_k v_k prod_{j != k} (x - r_j) / (r_k - r_j)"""
     n = len(roots)
@@ -95,3 +90,170 @@ def test_interpolation_refuses_repeated_roots(ctx):
     with pytest.raises(zk.ZkError) as e:
         ctx.interpolate_fr(roots, roots)
     assert e.value.status == zk._lib.ZK_ERR_ARG
+
+
+# ---- the sparse QAP form over the caller's roots (zk_qap_upload_sparse_roots, csrc/arbroots.hip) ---------------------------------
+from test_integer_roots import random_rows, chain_rows_integers, chain_weights_integers   # noqa: E402
+
+
+def distinct_roots(rng, n):
+    seen, out = set(), []
+    while len(out) < n:
+        r = rng.fr()
+        if r not in seen:
+            seen.add(r); out.append(r)
+    return out
+
+
+def dense_from_rows(roots, rows, m):
+    """QAP::from(root_rep) restated (fr.rs:140-173): every wire polynomial by the Lagrange sums above -> (m, n, 4) coefficient limbs"""
+    n = len(roots)
+    ptr, gate, val = rows
+    out = np.zeros((m, n, 4), np.uint64)
+    for i in range(m):
+        vals = [0] * n
+        for e in range(int(ptr[i]), int(ptr[i + 1])):
+            vals[int(gate[e])] = limbs_to_int(val[e])
+        if any(vals):
+            out[i] = ints_to_limbs(lagrange_coeffs(roots, vals)).reshape(n, 4)
+    return out
+
+
+def root_poly(roots):
+    full = [1]
+    for r in roots:
+        nxt = [0] * (len(full) + 1)
+        for i, c in enumerate(full):
+            nxt[i + 1] = (nxt[i + 1] + c) % R
+            nxt[i] = (nxt[i] - r * c) % R
+        full = nxt
+    return ints_to_limbs(full).reshape(len(roots) + 1, 4)
+
+
+@pytest.mark.parametrize("n,m,l", [(1, 4, 1), (2, 5, 0), (5, 12, 2), (17, 30, 3), (40, 70, 1)])
+def test_arbitrary_roots_match_the_faithful_oracle_and_the_dense_form(ctx, orc, n, m, l):
+    """random distinct roots, random rows: CRS arrays and proof bytes of the sparse arbitrary-roots form == the oracle's faithful
+    restatement of setup / prove over the dense QAP that QAP::from builds from the same root representation == the dense device form;
+    satisfying-or-not witnesses of three lengths; a CRS uploaded from the reference's arrays serves the form as it is."""
+    rng = SplitMix64(7700 + n)
+    roots = distinct_roots(rng, n)
+    if n >= 5:
+        roots[0], roots[1] = 0, 1
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    du, dv, dw, dt = dense_from_rows(roots, u, m), dense_from_rows(roots, v, m), dense_from_rows(roots, w, m), root_poly(roots)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    qs = ctx.qap_sparse_roots(ints_to_limbs(roots).reshape(n, 4), m, l, u, v, w)
+    qd = ctx.qap_dense(du, dv, dw, dt, l)
+    cs, cd = ctx.setup(qs, td), ctx.setup(qd, td)
+    a_s, a_d, a_o = ctx.crs_download(cs), ctx.crs_download(cd), orc.setup_dense(du, dv, dw, dt, l, td)
+    for k in a_o:
+        assert np.array_equal(a_s[k], a_o[k]), k
+        assert np.array_equal(a_d[k], a_o[k]), k
+    up = ctx.crs_upload(n, m, l, a_o)
+    crs_desc = ctx.crs_desc(n, m, l, a_o)
+    r, s = rng.fr(), rng.fr()
+    for count in (m, max(l + 1, m - 2), m + 2):
+        wts = ints_to_limbs([1] + [rng.fr() for _ in range(count - 1)])
+        want = orc.prove_dense(du, dv, dw, dt, l, crs_desc, wts, r, s)
+        assert ctx.prove(cs, qs, wts, r, s) == want, count
+        assert ctx.prove(cd, qd, wts, r, s) == want, count
+        assert ctx.prove(up, qs, wts, r, s) == want, count
+
+
+@pytest.mark.parametrize("n", [3, 64, 65, 600, 4099])
+def test_the_integers_as_arbitrary_roots(ctx, n):
+    """roots 1..n handed over as caller data: the CRS and the bytes of the integer-roots form (which the suite pins to the faithful
+    oracle, the dense form and the closed form)"""
+    rng = SplitMix64(7800 + n)
+    m, l = 2 * n + 7, 2
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    qi = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    qa = ctx.qap_sparse_roots(ints_to_limbs(list(range(1, n + 1))).reshape(n, 4), m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    ci, ca = ctx.setup(qi, td), ctx.setup(qa, td)
+    ai, aa = ctx.crs_download(ci), ctx.crs_download(ca)
+    for k in ai:
+        assert np.array_equal(ai[k], aa[k]), k
+    r, s = rng.fr(), rng.fr()
+    for count in (m, m - 3):
+        wts = ints_to_limbs([1] + [rng.fr() for _ in range(count - 1)])
+        assert ctx.prove(ca, qa, wts, r, s) == ctx.prove(ci, qi, wts, r, s)
+
+
+@pytest.mark.parametrize("n", [1000, (1 << 16) + 3, 1 << 18])
+def test_affine_images_of_the_integers_match_the_closed_form(ctx, orc, n):
+    """Size-independent property.  Over the roots r_k = a k + b the wire polynomials are u_i((x - b) / a), so a proof with trapdoor x'
+    is the integer-roots proof with trapdoor x = (x' - b) / a (A, B and every term of C are values of the same polynomials) -- which
+    the oracle's closed form gives at any size.  The device treats the roots as arbitrary field elements (dense form at 2^18 gates:
+    3 m n x 32 B = 13 TB).  Valid and invalid witness; zk_verify accepts / rejects; pipelined submissions."""
+    m, l, u, v, w = chain_rows_integers(n)
+    rng = SplitMix64(7900 + (n & 0xFFFF))
+    x, avals = rng.fr(), [rng.fr() for _ in range(n)]
+    weights = chain_weights_integers(n, x, avals)
+    a, b = rng.fr() | 1, rng.fr()
+    k = np.arange(1, n + 1, dtype=object)
+    roots = ints_to_limbs([int(v_) for v_ in (a * k + b) % R]).reshape(n, 4)
+    desc = ctx.sparse_desc(0, m, l, u, v, w)
+    qap = ctx.qap_sparse_roots(roots, m, l, u, v, w)
+    td_ints = [rng.fr() for _ in range(5)]
+    td = ints_to_limbs(td_ints)
+    td_int = ints_to_limbs(td_ints[:4] + [(td_ints[4] - b) * pow(a, -1, R) % R])
+    crs = ctx.setup(qap, td)
+    r, s = rng.fr(), rng.fr()
+    good = ctx.prove(crs, qap, weights, r, s)
+    assert good == orc.trapdoor_proof_integers(desc, n, td_int, weights, r, s)
+    assert ctx.verify(crs, [x, limbs_to_int(weights[2])], good)
+    bad = weights.copy(); bad[n // 2, 0] ^= np.uint64(1)
+    got_bad = ctx.prove(crs, qap, bad, r, s)
+    assert got_bad == orc.trapdoor_proof_integers(desc, n, td_int, bad, r, s)
+    assert not ctx.verify(crs, [x, limbs_to_int(weights[2])], got_bad)
+    hosts = [np.ascontiguousarray(w_) for w_ in (weights, bad, weights)]
+    t = [ctx.prove_submit_host(crs, qap, w_.ctypes.data, w_.shape[0], r, s) for w_ in hosts]
+    got = [ctx.prove_wait(x_) for x_ in t]
+    assert got == [good, got_bad, good]
+
+
+def test_arbitrary_roots_container_limits_and_errors(ctx, tmp_path):
+    rng = SplitMix64(8100)
+    n, m, l = 150, 333, 2
+    roots = ints_to_limbs(distinct_roots(rng, n)).reshape(n, 4)
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    qap = ctx.qap_sparse_roots(roots, m, l, u, v, w)
+    assert ctx.lib.zk_qap_kind(qap.ptr) == 3
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    wts = ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)])
+    r, s = rng.fr(), rng.fr()
+    want = ctx.prove(crs, qap, wts, r, s)
+    path = tmp_path / "arb.zkqap"
+    ctx.qap_save(qap, path)
+    back = ctx.qap_load(path)
+    assert ctx.lib.zk_qap_kind(back.ptr) == 3 and (back.n, back.m, back.input) == (n, m, l)
+    assert ctx.prove(crs, back, wts, r, s) == want
+    raw = bytearray(open(path, "rb").read())
+    raw[-5] ^= 1                                      # a root altered: the checksum catches it
+    open(tmp_path / "bad.zkqap", "wb").write(raw)
+    with pytest.raises(zk.ZkError) as e:
+        ctx.qap_load(tmp_path / "bad.zkqap")
+    assert e.value.status == zk._lib.ZK_ERR_IO
+    open(tmp_path / "short.zkqap", "wb").write(raw[:-40])
+    with pytest.raises(zk.ZkError):
+        ctx.qap_load(tmp_path / "short.zkqap")
+    dup = roots.copy(); dup[17] = dup[3]
+    with pytest.raises(zk.ZkError) as e:
+        ctx.qap_sparse_roots(dup, m, l, u, v, w)
+    assert e.value.status == zk._lib.ZK_ERR_ARG
+    big = roots.copy(); big[5] = ints_to_limbs([R])[0]
+    with pytest.raises(zk.ZkError) as e:
+        ctx.qap_sparse_roots(big, m, l, u, v, w)
+    assert e.value.status == zk._lib.ZK_ERR_RANGE
+    # the trapdoor's x on a root: refused like the reference's division by zero would be
+    td_bad = td.copy(); td_bad[4] = roots[9]
+    with pytest.raises(zk.ZkError):
+        ctx.setup(qap, td_bad)
+    # batches take the other two sparse forms
+    import torch
+    d = torch.from_numpy(wts.view(np.int64)).cuda()
+    with pytest.raises(zk.ZkError) as e:
+        ctx.prove_batch_submit(crs, qap, [d.data_ptr()], [m], [r], [s])
+    assert e.value.status == zk._lib.ZK_ERR_UNSUPPORTED

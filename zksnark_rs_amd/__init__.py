@@ -283,6 +283,17 @@ class Context:
         q.n, q.m, q.input, q.dense, q.roots = n, m, input, False, "integers"
         return q
 
+    def qap_sparse_roots(self, roots, m, input, u, v, w):
+        """Rows as in qap_sparse over ANY distinct roots (RootRepresentation::roots(), circuit/mod.rs:201-214): gate j = roots[j] ((n, 4) limbs)."""
+        r = np.ascontiguousarray(np.asarray(roots, dtype=np.uint64).reshape(-1, 4))
+        n = r.shape[0]
+        d = self.sparse_desc(0, m, input, u, v, w)
+        p = C.c_void_p()
+        self._check(self.lib.zk_qap_upload_sparse_roots(self.ptr, C.byref(d), r.ctypes.data_as(_lib.u64p), n, C.byref(p)))
+        q = Qap(self, p, self.lib.zk_qap_free)
+        q.n, q.m, q.input, q.dense, q.roots = n, m, input, False, "arbitrary"
+        return q
+
     def qap_dense(self, u, v, w, t, input):
         """u, v, w: (m, n, 4) coefficient matrices, t: (n+1, 4)."""
         u, up = _u64(u); v, vp = _u64(v); w, wp = _u64(w); t, tp = _u64(t)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "zk_g2_add_batch": (C.c_int, [C.c_void_p, u64p, u64p, u64p, C.c_size_t]),
     "zk_qap_upload_sparse": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.POINTER(C.c_void_p)]),
     "zk_qap_upload_sparse_integers": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zk_qap_upload_sparse_roots": (C.c_int, [C.c_void_p, C.POINTER(QapSparseDesc), u64p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_upload_dense": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
     "zk_qap_free": (None, [C.c_void_p]),
     "zk_qap_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

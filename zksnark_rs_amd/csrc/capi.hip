@@ -190,6 +190,11 @@ int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, s
     *out = nullptr;
     return guarded(ctx, [&] { *out = qap_upload_sparse_integers(ctx, *desc, n); });
 }
+int zk_qap_upload_sparse_roots(zk_ctx* ctx, const zk_qap_sparse_desc* desc, const uint64_t* roots, size_t n, zk_qap** out) {
+    if (!ctx || !desc || !out) return ZK_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] { *out = qap_upload_sparse_roots(ctx, *desc, roots, n); });
+}
 int zk_qap_upload_dense(zk_ctx* ctx, const uint64_t* u, const uint64_t* v, const uint64_t* w, const uint64_t* t,
                         size_t m, size_t n, size_t input, zk_qap** out) {
     if (!ctx || !out) return ZK_ERR_ARG;

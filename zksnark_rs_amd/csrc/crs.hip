@@ -503,9 +503,9 @@ zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
         ZK_HIP(hipStreamSynchronize(st));
         ZK_REQUIRE(!h, ZK_ERR_RANGE, "zk_setup: trapdoor element >= r");
     }
-    const bool ap = !q.dense && q.roots == 1;
-    hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, st, td.p, G2GEN, ap ? 2 : (q.dense ? 1 : 0), n, q.log_n, q.dt.p,
-                       ap ? ap_t_at_x(q, trapdoor) : Fr::zero(), cs.p);
+    const bool ap = !q.dense && q.roots == 1, arb = !q.dense && q.roots == 2;
+    hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, st, td.p, G2GEN, (ap || arb) ? 2 : (q.dense ? 1 : 0), n, q.log_n, q.dt.p,
+                       ap ? ap_t_at_x(q, trapdoor) : arb ? arb_t_at_x(q, trapdoor) : Fr::zero(), cs.p);
     ZK_HIP(hipGetLastError());
     DevBuf<Fr> apL(ap ? n : 0), apLS(ap ? std::max<size_t>(n - 1, 1) : 0);
 
@@ -523,6 +523,17 @@ zk_crs* crs_setup(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20]) {
         ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         ZK_REQUIRE(!(h & 8), ZK_ERR_UNSUPPORTED, "zk_setup: the trapdoor's x is one of the integers 1..2n-1 (draw another)");
+    } else if (arb) {
+        DevBuf<Fr> L(n);
+        arb_setup_lagrange(ctx, q, trapdoor, L.p, flag.p);
+        hipLaunchKernelGGL(k_setup_comb_sparse, dim3(ceil_div(m * 64, 256)), dim3(256), 0, st, cs.p, L.p,
+                           q.u_wire.ptr.p, q.u_wire.idx.p, q.u_wire.val.p, q.v_wire.ptr.p, q.v_wire.idx.p, q.v_wire.val.p,
+                           q.w_wire.ptr.p, q.w_wire.idx.p, q.w_wire.val.p, m, l, comb.p);
+        ZK_HIP(hipGetLastError());
+        int h = 0;
+        ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_REQUIRE(!(h & 8), ZK_ERR_UNSUPPORTED, "zk_setup: the trapdoor's x is one of the QAP's roots (draw another)");
     } else {
         DevBuf<Fr> L(n);
         hipLaunchKernelGGL(k_lagrange_at, dim3(ceil_div(n, 256)), dim3(256), 0, st, cs.p, host_root_of_unity(q.log_n), L.p, n);

@@ -547,10 +547,10 @@ int zk_qap_weighted_sum(zk_ctx* ctx, const zk_qap* qap, const uint64_t* weights,
     return guarded(ctx, [&] { qap_weighted_sum(ctx, *qap, weights, m, which, out); });
 }
 
-/* 0: sparse rows over the roots of unity w^j (n = 2^k), 1: dense coefficient matrices, 2: sparse rows over the integers 1..n */
+/* 0: sparse rows over the roots of unity w^j (n = 2^k), 1: dense coefficient matrices, 2: sparse rows over the integers 1..n, 3: over the caller's roots */
 int zk_qap_kind(const zk_qap* qap) {
     if (!qap) return ZK_ERR_ARG;
-    return qap->dense ? 1 : (qap->roots ? 2 : 0);
+    return qap->dense ? 1 : (qap->roots == 2 ? 3 : qap->roots ? 2 : 0);
 }
 
 }  // extern "C"

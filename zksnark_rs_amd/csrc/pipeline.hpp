@@ -1,6 +1,7 @@
 // pipeline.hpp -- device-resident QAP / CRS handles and the prove / setup pipelines.
 #pragma once
 #include "kernels.hpp"
+#include "interp.hpp"
 
 namespace zk {
 
@@ -20,13 +21,23 @@ struct ApTables {
     DevBuf<Fr> fact, ifact, w, ws, ntab, bhat;
 };
 
+// tables of the arbitrary-roots form (arbroots.hip): the sub-product tree of the roots, the evaluation coset g <w_M> (M = 2^log_m >= n):
+// g^j, g^-j, 1 / t on the coset (transform order)
+struct ArbTables {
+    std::shared_ptr<InterpTree> tree;
+    unsigned log_m = 0;
+    DevBuf<Fr> gpow, ginv_pow, tinv;
+    std::vector<Fr> host_roots;    // Montgomery; t(x) of a trapdoor is a host product
+};
+
 }  // namespace zk
 
 struct zk_qap {
     zk_ctx* ctx = nullptr;
     bool dense = false;
-    int roots = 0;            // sparse form: 0 = roots of unity w^j (n = 2^log_n), 1 = the integers 1..n (any n; aproots.hip)
+    int roots = 0;            // sparse form: 0 = roots of unity w^j (n = 2^log_n), 1 = the integers 1..n (any n; aproots.hip), 2 = caller's roots (arbroots.hip)
     std::shared_ptr<zk::ApTables> ap;
+    std::shared_ptr<zk::ArbTables> arb;
     size_t n = 0, m = 0, input = 0;
     unsigned log_n = 0;
     // sparse form (roots w^j): by gate (prove: evaluation vectors) and by wire (setup: u_i(x))
@@ -86,6 +97,12 @@ namespace zk {
 zk_qap* qap_upload_sparse(zk_ctx*, const zk_qap_sparse_desc&);
 zk_qap* qap_upload_rows(zk_ctx*, const zk_qap_sparse_desc&, size_t n);                  // rows over n gates, domain not set
 zk_qap* qap_upload_sparse_integers(zk_ctx*, const zk_qap_sparse_desc&, size_t n);       // aproots.hip
+zk_qap* qap_upload_sparse_roots(zk_ctx*, const zk_qap_sparse_desc&, const uint64_t* roots, size_t n);   // arbroots.hip
+void arb_download_roots(zk_ctx*, const zk_qap&, uint64_t* out);
+void arb_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, int* d_flag);
+Fr arb_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
+size_t arb_work_elems(const zk_qap&);
+void arb_scalars(zk_ctx*, const zk_qap&, Fr* vals, Fr* work, const Fr& r_mont, const Fr& s_mont, Fr* vc_can, Fr* uc_can, Fr* hb_can);
 void ap_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, Fr* d_LS, int* d_flag);
 Fr ap_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
 void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can, size_t count = 1, size_t hb_stride = 0);

@@ -371,9 +371,10 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
     // an integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1): change of basis, once per CRS
-    if (!xout && !q.dense && q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
+    ZK_REQUIRE(!(q.roots == 2 && xout), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange takes the roots-of-unity and integer-roots forms (an arbitrary-roots QAP proves on one GPU, or window-sharded)");
+    if (!xout && !q.dense && q.roots == 1 && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
     if (xout) {}   // scalars only: no inner product, no table (the ranks of a scalar exchange build only their own slices)
-    else if (q.dense) crs_ensure_tables(ctx, crs, false, 0);
+    else if (q.dense || q.roots == 2) crs_ensure_tables(ctx, crs, false, 0);   // coefficient forms: the reference's [x^i], natural order
     else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
     if (q.dense && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
@@ -445,7 +446,19 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             for (auto& d : deferred)
                 if (d.first == order[pos]) { d.second(prev); prev = d.first; }
     };
-    if (!q.dense && q.roots) {
+    if (!q.dense && q.roots == 2) {
+        // caller's roots (arbroots.hip): U, V and the interpolant of U_k V_k are interpolated per proof by the sub-product tree; bases = [x^i]
+        S.uv.ensure(3 * n); S.xy.ensure(arb_work_elems(q));
+        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+        Fr *ue = S.uv.p, *ve = S.uv.p + n;
+        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
+        spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
+        arb_scalars(ctx, q, S.uv.p, S.xy.p, r_mont, s_mont, S.vc_can.p, S.uc_can.p, S.hb_can.p);
+        launch(2, 1, crs.t_xi1, S.uc_can.p, n, &ms->a);
+        launch(0, 2, crs.t_xi2, S.vc_can.p, n, &ms->b2);
+        launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
+    } else if (!q.dense && q.roots) {
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
         const size_t M = (size_t)1 << q.ap->log_m;
         S.uv.ensure(2 * n); S.xy.ensure(3 * M);
@@ -585,7 +598,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs a sparse QAP form");
+    ZK_REQUIRE(!q.dense && q.roots != 2, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange takes the roots-of-unity and integer-roots forms");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
@@ -657,7 +670,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
                        const uint64_t* r, const uint64_t* s) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: batches need a sparse QAP form");
+    ZK_REQUIRE(!q.dense && q.roots != 2, ZK_ERR_UNSUPPORTED, "prove: batches take the roots-of-unity and integer-roots forms");
     ZK_REQUIRE(count >= 1 && count <= ZK_MAX_BATCH, ZK_ERR_ARG, "prove: batch size out of range");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;

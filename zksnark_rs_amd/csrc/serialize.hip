@@ -114,10 +114,10 @@ zk_crs* crs_load(zk_ctx* ctx, const char* path) {
 // holds what zk_qap_upload_sparse / zk_qap_upload_dense take, as canonical little-endian integers:
 //   offset 0   "ZKQAPv1\0"
 //          8   kind (0 = sparse rows over the roots w^j, 1 = dense coefficient matrices, 2 = sparse rows over the
-//              integer roots 1..n), n_or_log_n (log_n for kind 0, n otherwise), m, input                           4 x u64
+//              integer roots 1..n, 3 = sparse rows over the caller's roots), n_or_log_n (log_n for kind 0, n otherwise), m, input   4 x u64
 //         40   nnz(u), nnz(v), nnz(w)  (0 for the dense kind)                                                    3 x u64
 //         64   FNV-1a 64 of the payload
-//         72   payload  sparse: for u, v, w: ptr[m+1] (u64) | gate[nnz] (u32, padded to 8 bytes) | val[nnz] (32 B)
+//         72   payload  sparse: for u, v, w: ptr[m+1] (u64) | gate[nnz] (u32, padded to 8 bytes) | val[nnz] (32 B); kind 3: then the n roots (32 B)
 //                       dense : u, v, w (m n x 32 B each), t ((n+1) x 32 B)
 // Loading goes through the upload entry points, so every value is range-checked on the GPU.
 namespace {
@@ -144,7 +144,7 @@ void qap_save(zk_ctx* ctx, const zk_qap& q, const char* path) {
     std::vector<uint64_t> payload;
     uint64_t head[9] = {0};
     std::memcpy(head, QMAGIC, 8);
-    head[1] = q.dense ? 1 : (q.roots ? 2 : 0); head[2] = (q.dense || q.roots) ? q.n : q.log_n; head[3] = q.m; head[4] = q.input;
+    head[1] = q.dense ? 1 : (q.roots == 2 ? 3 : q.roots ? 2 : 0); head[2] = (q.dense || q.roots) ? q.n : q.log_n; head[3] = q.m; head[4] = q.input;
     if (!q.dense) {
         const DevCsr* rows[3] = {&q.u_wire, &q.v_wire, &q.w_wire};
         for (int k = 0; k < 3; ++k) {
@@ -157,6 +157,11 @@ void qap_save(zk_ctx* ctx, const zk_qap& q, const char* path) {
             payload.resize(at + gate.size() / 2);
             std::memcpy(payload.data() + at, gate.data(), gate.size() * 4);
             payload.insert(payload.end(), val.begin(), val.end());
+        }
+        if (q.roots == 2) {
+            const size_t at = payload.size();
+            payload.resize(at + 4 * q.n);
+            arb_download_roots(ctx, q, payload.data() + at);
         }
     } else {
         const size_t mn = q.m * q.n;
@@ -183,12 +188,13 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
     uint64_t head[9];
     ZK_REQUIRE(std::fread(head, 8, 9, f.f) == 9 && !std::memcmp(head, QMAGIC, 8), ZK_ERR_IO, "qap_load: not a ZKQAPv1 file");
     const uint64_t kind = head[1], m = head[3], input = head[4];
-    ZK_REQUIRE(kind <= 2 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
+    ZK_REQUIRE(kind <= 3 && m >= 1 && m <= ((uint64_t)1 << 31) && input < m, ZK_ERR_IO, "qap_load: implausible header");
     size_t words;
     if (kind != 1) {
         ZK_REQUIRE(head[2] <= (kind == 0 ? 26 : ((uint64_t)1 << 23)) && head[5] <= ((uint64_t)1 << 32) && head[6] <= ((uint64_t)1 << 32) && head[7] <= ((uint64_t)1 << 32), ZK_ERR_IO, "qap_load: implausible header");
         words = 0;
         for (int k = 0; k < 3; ++k) words += (m + 1) + (head[5 + k] + 1) / 2 + head[5 + k] * 4;
+        if (kind == 3) words += 4 * head[2];
     } else {
         ZK_REQUIRE(head[2] >= 1 && head[2] <= ((uint64_t)1 << 22) && m * head[2] <= ((uint64_t)1 << 33), ZK_ERR_IO, "qap_load: implausible header");
         words = (3 * m * head[2] + head[2] + 1) * 4;
@@ -214,6 +220,7 @@ zk_qap* qap_load(zk_ctx* ctx, const char* path) {
         rows[k]->gate = reinterpret_cast<const uint32_t*>(at); at += (nnz + 1) / 2;
         rows[k]->val = at; at += nnz * 4;
     }
+    if (kind == 3) return qap_upload_sparse_roots(ctx, d, at, head[2]);
     return kind == 2 ? qap_upload_sparse_integers(ctx, d, head[2]) : qap_upload_sparse(ctx, d);
 }
 
