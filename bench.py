@@ -47,7 +47,13 @@ def build_instance(zk, ctx, log_n, seed, witness="uniform", roots="unity"):
     td = zk.ints_to_limbs([rng.fr() for _ in range(5)])
     r, s = rng.fr(), rng.fr()
     # the same rows over the roots w^j (the metric's workload) or over ASTParser's roots 1..n
-    qap = ctx.qap_sparse(log_n, m, l, u, v, w) if roots == "unity" else ctx.qap_sparse_integers(n, m, l, u, v, w)
+    if roots == "arbitrary":    # affine images a k + b of the integers, handed over as caller data: treated as arbitrary field elements
+        import numpy as np
+        a, b = rng.fr() | 1, rng.fr()
+        k = np.arange(1, n + 1, dtype=object)
+        qap = ctx.qap_sparse_roots(zk.ints_to_limbs([int(v_) for v_ in (a * k + b) % zk.R_MODULUS]).reshape(n, 4), m, l, u, v, w)
+    else:
+        qap = ctx.qap_sparse(log_n, m, l, u, v, w) if roots == "unity" else ctx.qap_sparse_integers(n, m, l, u, v, w)
     crs = ctx.setup(qap, td)      # groth16::setup on the GPU, outside the timed region
     return dict(n=n, m=m, l=l, rows=(u, v, w), qap=qap, crs=crs, weights=weights, td=td, r=r, s=s, log_n=log_n)
 
@@ -217,9 +223,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="N = 1: proofs per zk_prove_batch_submit (grouped inner products; for circuits of 2^16 gates and fewer, where "
                          "a lone proof is bound by launch latency).  The metric's 2^20 workload is quoted with --batch 1")
-    ap.add_argument("--roots", choices=["unity", "integers"], default="unity",
+    ap.add_argument("--roots", choices=["unity", "integers", "arbitrary"], default="unity",
                     help="QAP domain: unity = w^j (the metric's workload); integers = 1..n, what ASTParser gives the same circuit "
-                         "(zk_qap_upload_sparse_integers; N = 1, no batches; secondary measurement, no CPU baseline)")
+                         "(zk_qap_upload_sparse_integers); arbitrary = caller-supplied field elements (zk_qap_upload_sparse_roots: the prover "
+                         "interpolates per proof by a sub-product tree).  N = 1, no batches; secondary measurements, no CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true",
                     help="event-time every launch group of a proof, not only the bucket accumulations (kernel_ms_per_proof then lists them "
@@ -237,7 +244,7 @@ def main():
     args = ap.parse_args()
     if args.latency:
         args.depth, args.no_cpu_baseline = 1, True
-    if args.roots == "integers":
+    if args.roots != "unity":
         args.no_cpu_baseline = True
 
     import torch
@@ -602,7 +609,7 @@ def main():
             "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
             "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d)" % (args.witness, args.seed),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM%s"
-                                   % (args.log_n, m, "" if args.roots == "unity" else "; QAP over the integer roots 1..n"),
+                                   % (args.log_n, m, "" if args.roots == "unity" else "; QAP over the integer roots 1..n" if args.roots == "integers" else "; QAP over caller-supplied (arbitrary) roots"),
                        "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("point-range" if args.shard == "points" else "window", world)) if shard
                                       else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums (%s); "
                                             "a step = one round of %d proofs" % (world, "zk_comm / zk_mgpu inside libzkgpu.so" if use_zk else "torch.distributed", world)) if exchange

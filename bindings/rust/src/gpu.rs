@@ -61,6 +61,7 @@ extern "C" {
     fn zk_crs_download(ctx: *mut ZkCtx, crs: *const ZkCrs, out: *const ZkCrsOut) -> c_int;
     fn zk_crs_free(c: *mut ZkCrs);
     fn zk_qap_upload_sparse_integers(ctx: *mut ZkCtx, desc: *const ZkQapSparseDesc, n: usize, out: *mut *mut ZkQap) -> c_int;
+    fn zk_qap_upload_sparse_roots(ctx: *mut ZkCtx, desc: *const ZkQapSparseDesc, roots: *const u64, n: usize, out: *mut *mut ZkQap) -> c_int;
     fn zk_setup(ctx: *mut ZkCtx, qap: *const ZkQap, trapdoor: *const u64, out: *mut *mut ZkCrs) -> c_int;
     fn zk_prove(ctx: *mut ZkCtx, crs: *const ZkCrs, qap: *const ZkQap, weights: *const u64, m: usize,
                 r: *const u64, s: *const u64, proof_out: *mut u8) -> c_int;
@@ -415,7 +416,7 @@ impl GpuProver {
             p = p * w;
         }
         assert_eq!(index.len(), n, "the number of gates must be 2^log_n");
-        Self::from_rows(rr, &index, n, Some(log_n), None)
+        Self::from_rows(rr, &index, n, Some(log_n), None, None)
     }
 
     /// The circuits the reference itself produces: a RootRepresentation over the roots 1, 2, .., n (ASTParser, circuit/mod.rs:517),
@@ -434,7 +435,24 @@ impl GpuProver {
             k = k + FrLocal::from(1usize);
             n += 1;
         }
-        Self::from_rows(rr, &index, n, None, None)
+        Self::from_rows(rr, &index, n, None, None, None)
+    }
+
+    /// ANY RootRepresentation (circuit/mod.rs:201-214: `roots()` is caller data, e.g. DummyRep's, dummy_rep.rs:47): the rows over the
+    /// caller's distinct roots, at any size up to 2^22 gates, with the reference's proof bytes (zk_qap_upload_sparse_roots: the prover
+    /// interpolates U, V and the interpolant of U_k V_k per proof by a sub-product tree, nothing is interpolated per wire).  `sigma`: a CRS
+    /// the reference's own `setup` made for the circuit, or None to make one on the GPU.
+    pub fn from_root_rep_any<R: RootRepresentation<FrLocal>>(rr: &R, sigma: Option<(&SigmaG1<G1Local>, &SigmaG2<G2Local>)>)
+        -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {
+        let mut index: HashMap<[u64; 4], u32> = HashMap::new();
+        let mut roots: Vec<u64> = Vec::new();
+        for (j, root) in rr.roots().enumerate() {
+            let w = fr_to_words(&root);
+            assert!(index.insert(w, j as u32).is_none(), "the roots of a RootRepresentation must be distinct");
+            roots.extend_from_slice(&w);
+        }
+        let n = index.len();
+        Self::from_rows(rr, &index, n, None, sigma, Some(&roots))
     }
 
     /// The same circuits with a CRS the reference's own `setup` made (groth16::prove takes any (&SigmaG1, &SigmaG2), mod.rs:213-217):
@@ -450,11 +468,11 @@ impl GpuProver {
             k = k + FrLocal::from(1usize);
             n += 1;
         }
-        Self::from_rows(rr, &index, n, None, Some(sigma)).0
+        Self::from_rows(rr, &index, n, None, Some(sigma), None).0
     }
 
     fn from_rows<R: RootRepresentation<FrLocal>>(rr: &R, index: &HashMap<[u64; 4], u32>, n: usize, log_n: Option<u32>,
-                                                 given: Option<(&SigmaG1<G1Local>, &SigmaG2<G2Local>)>)
+                                                 given: Option<(&SigmaG1<G1Local>, &SigmaG2<G2Local>)>, roots: Option<&Vec<u64>>)
         -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {
         struct Rows { ptr: Vec<u64>, gate: Vec<u32>, val: Vec<u64> }
         let collect = |rows: R::Row| -> Rows {
@@ -477,9 +495,10 @@ impl GpuProver {
         let (mut q, mut crs) = (std::ptr::null_mut(), std::ptr::null_mut());
         let td: Vec<u64> = (0..5).flat_map(|_| fr_to_words(&FrLocal::random_elem()).to_vec()).collect();   // alpha, beta, gamma, delta, x (mod.rs:139-145)
         unsafe {
-            match log_n {
-                Some(_) => check(ctx.0, zk_qap_upload_sparse(ctx.0, &desc, &mut q)),
-                None => check(ctx.0, zk_qap_upload_sparse_integers(ctx.0, &desc, n, &mut q)),
+            match (log_n, roots) {
+                (Some(_), _) => check(ctx.0, zk_qap_upload_sparse(ctx.0, &desc, &mut q)),
+                (None, Some(r)) => check(ctx.0, zk_qap_upload_sparse_roots(ctx.0, &desc, r.as_ptr(), n, &mut q)),
+                (None, None) => check(ctx.0, zk_qap_upload_sparse_integers(ctx.0, &desc, n, &mut q)),
             }
             match given {
                 Some((s1, s2)) => {

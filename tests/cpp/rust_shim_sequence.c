@@ -199,6 +199,25 @@ int main(int argc, char** argv) {
         CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
         CHECK(zk_qap_kind(qs) == 2);
         zk_crs_free(cs); zk_qap_free(qs);
+        /* ---- GpuProver::from_root_rep_any: the same rows with the roots handed over as caller data (here 1, 2: the bytes above must
+         *      come out again), zk_qap_upload_sparse_roots + the uploaded host CRS, and + zk_setup ---- */
+        {
+            uint64_t rts[8] = {1, 0, 0, 0, 2, 0, 0, 0};
+            zk_qap* qa = NULL;
+            ZK(zk_qap_upload_sparse_roots(ctx, &sd1, rts, n, &qa));
+            CHECK(zk_qap_kind(qa) == 3);
+            ZK(zk_crs_upload(ctx, &desc, &cs));
+            memset(ps, 0, sizeof ps);
+            ZK(zk_prove(ctx, cs, qa, weights, m, r, s, ps));
+            CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
+            zk_crs_free(cs);
+            ZK(zk_setup(ctx, qa, td, &cs));
+            memset(ps, 0, sizeof ps);
+            ZK(zk_prove(ctx, cs, qa, weights, m, r, s, ps));
+            CHECK(memcmp(ps, proof, ZK_PROOF_BYTES) == 0);
+            zk_crs_free(cs); zk_qap_free(qa);
+            printf("ok from_root_rep_any\n");
+        }
         for (int k = 0; k < 3; ++k) { free(ptr[k]); free(gate[k]); free(val[k]); }
         printf("ok from_root_rep_integers\n");
     }

@@ -86,7 +86,7 @@ def test_rust_shim_sequence_on_the_gpu(tmp_path):
     exe = build_shim(tmp_path)
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zk", "simple.zk")] + g2_generator_packed(), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
-    for name in ("byte_conversions", "setup", "prove", "verify", "prove_stream", "from_root_rep", "from_root_rep_integers", "multi_gpu_world_1"):
+    for name in ("byte_conversions", "setup", "prove", "verify", "prove_stream", "from_root_rep", "from_root_rep_integers", "from_root_rep_any", "multi_gpu_world_1"):
         assert "ok " + name in res.stdout, res.stdout + res.stderr
 
 
