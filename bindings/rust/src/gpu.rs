@@ -440,7 +440,7 @@ impl GpuProver {
 
     /// ANY RootRepresentation (circuit/mod.rs:201-214: `roots()` is caller data, e.g. DummyRep's, dummy_rep.rs:47): the rows over the
     /// caller's distinct roots, at any size up to 2^22 gates, with the reference's proof bytes (zk_qap_upload_sparse_roots: the prover
-    /// interpolates U, V and the interpolant of U_k V_k per proof by a sub-product tree, nothing is interpolated per wire).  `sigma`: a CRS
+    /// interpolates U and V per proof by a sub-product tree, nothing is interpolated per wire).  `sigma`: a CRS
     /// the reference's own `setup` made for the circuit, or None to make one on the GPU.
     pub fn from_root_rep_any<R: RootRepresentation<FrLocal>>(rr: &R, sigma: Option<(&SigmaG1<G1Local>, &SigmaG2<G2Local>)>)
         -> (Self, (SigmaG1<G1Local>, SigmaG2<G2Local>)) {

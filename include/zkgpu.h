@@ -86,8 +86,8 @@ long zk_get_option(const zk_ctx* ctx, const char* key);
 int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int coset);
 /* Interpolation through ARBITRARY distinct nodes: coeffs[0..n) = the coefficients of the polynomial of degree < n with
  * p(roots[k]) = values[k] -- what QAP::from does per wire polynomial with Lagrange sums (fr.rs:140-173, coefficient_poly.rs:159-200;
- * O(n^2) each) and the prover of an arbitrary-roots QAP (zk_qap_upload_sparse_roots) does per proof for U, V and the interpolant of the
- * products, by a sub-product tree over batched NTTs in O(n log^2 n) (csrc/interp.hip).  1 <= n <= 2^23; ZK_ERR_ARG when two roots
+ * O(n^2) each) and the prover of an arbitrary-roots QAP (zk_qap_upload_sparse_roots) does per proof for U and V,
+ * by a sub-product tree over batched NTTs in O(n log^2 n) (csrc/interp.hip).  1 <= n <= 2^23; ZK_ERR_ARG when two roots
  * coincide.  (The per-root-set tables cost O(n^2) field multiplications once.) */
 int zk_interpolate_fr(zk_ctx* ctx, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs);
 
@@ -166,10 +166,10 @@ int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, s
 /* The same rows over ANY distinct roots r_0 .. r_{n-1} the caller supplies (RootRepresentation::roots() is caller data,
  * circuit/mod.rs:201-214, dummy_rep.rs:47): gate j = root roots[j] (4 words each, canonical), 1 <= n <= 2^22.  Equivalent to
  * QAP::from(root_rep) (fr.rs:140-173) followed by the reference's coefficient-form prove -- byte-identical proofs -- but the 3 m wire
- * polynomials are never interpolated: the prover interpolates U = sum a_i u_i, V and the interpolant of the products U_k V_k per proof
- * from their values on the roots by a sub-product tree (csrc/interp.hip, O(n log^2 n)) and takes its inner products with the
+ * polynomials are never interpolated: the prover interpolates U = sum a_i u_i and V per proof from their values on the roots by a
+ * sub-product tree (csrc/interp.hip, O(n log^2 n)), divides U V by t (the remainder is dropped) and takes its inner products with the
  * reference's own [x^i] arrays, so ANY CRS for the circuit serves (zk_setup, zk_crs_upload, a file).  Once per root set: O(n^2) field
- * multiplications (0.6 s at 2^18 gates).  ZK_ERR_ARG when two roots coincide.  One proof at a time or pipelined on one GPU, or
+ * multiplications (0.7 s at 2^18 gates, 11 s at 2^20).  ZK_ERR_ARG when two roots coincide.  One proof at a time or pipelined on one GPU, or
  * window-sharded (zk_prove_partial); batches and the scalar exchange take the two forms above (ZK_ERR_UNSUPPORTED). */
 int zk_qap_upload_sparse_roots(zk_ctx* ctx, const zk_qap_sparse_desc* desc, const uint64_t* roots, size_t n, zk_qap** out);
 

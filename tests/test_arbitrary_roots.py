@@ -257,3 +257,30 @@ def test_arbitrary_roots_container_limits_and_errors(ctx, tmp_path):
     with pytest.raises(zk.ZkError) as e:
         ctx.prove_batch_submit(crs, qap, [d.data_ptr()], [m], [r], [s])
     assert e.value.status == zk._lib.ZK_ERR_UNSUPPORTED
+
+
+def test_arbitrary_roots_window_and_point_sharded(ctx):
+    """zk_prove_partial for every rank of worlds 1, 2, 3, 8 (partial sums by Pippenger windows and by point ranges) + zk_prove_combine ==
+    zk_prove: the latency form of the multi-GPU prover takes this QAP form as it is (the scalar exchange does not)."""
+    import torch
+    rng = SplitMix64(8200)
+    n, m, l = 700, 1500, 2
+    roots = ints_to_limbs(distinct_roots(rng, n)).reshape(n, 4)
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    qap = ctx.qap_sparse_roots(roots, m, l, u, v, w)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    wts = ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)])
+    r, s = rng.fr(), rng.fr()
+    want = ctx.prove(crs, qap, wts, r, s)
+    dw = torch.from_numpy(wts.view(np.int64)).cuda()
+    try:
+        for by_points in (0, 1):
+            ctx.set_option("msm_shard_points", by_points)
+            for world in (1, 2, 3, 8):
+                buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+                for rank in range(world):
+                    ctx.prove_partial(crs, qap, dw.data_ptr(), m, r, s, rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+                torch.cuda.synchronize()
+                assert ctx.prove_combine(crs, buf.data_ptr(), world, r, s) == want, (by_points, world)
+    finally:
+        ctx.set_option("msm_shard_points", 0)

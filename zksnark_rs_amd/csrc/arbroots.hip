@@ -3,17 +3,17 @@
 //
 // The reference interpolates all 3 m wire polynomials through the roots (QAP::from, fr.rs:140-173; Lagrange sums
 // coefficient_poly.rs:159-200: O(nnz n^2)) and then proves in coefficient form.  The dense device form does the same and stops at
-// 16384 gates (3 m n field elements).  Here the rows stay as they are and the PROVER interpolates, per proof, the three polynomials
-// it needs -- U = sum a_i u_i, V, and E = the interpolant of the products U_k V_k -- from their values on the roots (the SpMV output)
-// by the sub-product tree of interp.hip, O(n log^2 n):
+// 16384 gates (3 m n field elements).  Here the rows stay as they are and the PROVER interpolates, per proof, the two polynomials
+// it needs -- U = sum a_i u_i and V -- from their values on the roots (the SpMV output) by the sub-product tree of interp.hip,
+// O(n log^2 n):
 //   * A, B, r B1 + s A:  inner products of the coefficients of U, V with the reference's own [x^i]_1, [x^i]_2 -- ANY CRS serves (zk_setup,
 //     zk_crs_upload, a file), nothing is held in a Lagrange basis;
-//   * h = (U V - W) div t:  U V - W = h t + rem with rem = E - W (both W and E have degree < n and E interpolates U_k V_k = (U V)(r_k)),
-//     so h = (U V - E) / t exactly, for EVERY witness (aproots.hip has the same argument).  U, V, E are evaluated on a coset g <w> of
-//     2^k >= n points that misses every root, h's values are (U V - E) / t there, one inverse transform gives its n - 1 coefficients.
-//     W is never evaluated.
+//   * h = (U V - W) div t:  U V - W = h t + rem with rem = E - W, where E is the interpolant of the products U_k V_k = (U V)(r_k): both
+//     W and E have degree < n, so U V = h t + E and the quotient of U V ALONE by t is h, for EVERY witness (aproots.hip has the same
+//     argument).  W is never evaluated; the product and the division by t (monic, degree n; Newton's iteration on rev(t) once per QAP,
+//     long division below 512 quotient coefficients) are the coefficient-form tail the dense form already has (prove.hip, qap.hip).
 // Same group elements as the reference's proof, hence the same 259 bytes.  Per root set, once: the tree (interp.hip, O(n^2) multiplications
-// for N'(r_k)), t = prod (x - r_k), 1 / t on the coset.
+// for N'(r_k)), t = prod (x - r_k) and the power-series inverse of rev(t).
 #include <algorithm>
 #include <vector>
 #include "pipeline.hpp"
@@ -22,60 +22,25 @@
 namespace zk {
 
 // ---- per-QAP tables -------------------------------------------------------------------------------------------------------
-// buf[j] = t_j g^j (j < M; t_j = 0 beyond the degree; the leading 1 of a degree-M t is added after the transform)
-__global__ void k_arb_t_scaled(const Fr* __restrict__ t, size_t n, size_t M, const Fr* __restrict__ gpow, Fr* __restrict__ buf) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    buf[j] = j <= n ? t[j] * gpow[j] : Fr::zero();
-}
-// buf[j] <- 1 / (buf[j] + top); flag |= 32 when t vanishes on the coset
-__global__ void k_arb_t_invert(Fr* __restrict__ buf, size_t M, Fr top, int* __restrict__ flag) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    const Fr v = buf[j] + top;
-    if (v.is_zero()) { atomicOr(flag, 32); return; }
-    buf[j] = v.inv();
-}
-
 static void arb_build_tables(zk_ctx* ctx, zk_qap& q, const Fr* d_roots_mont, int* d_flag) {
     const size_t n = q.n;
     hipStream_t st = ctx->stream;
     auto a = std::make_shared<ArbTables>();
     a->tree = interp_build(ctx, d_roots_mont, n, d_flag);
-    {
-        int h = 0;
-        ZK_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_REQUIRE(!(h & 16), ZK_ERR_ARG, "arbitrary-roots QAP: the roots are not distinct");
-    }
-    a->log_m = a->tree->log_npad;
-    const size_t M = (size_t)1 << a->log_m;
+    int h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     a->host_roots.resize(n);
     ZK_HIP(hipMemcpyAsync(a->host_roots.data(), a->tree->roots.p, n * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    a->gpow.alloc(M); a->ginv_pow.alloc(M); a->tinv.alloc(M);
-    // the coset g <w_M>, g = 5^e for the first odd e whose coset misses every root (5 generates Fr*: 5^e with e odd is outside <w_M>)
-    const Fr five = host_fr_from_u64(5);
-    bool found = false;
-    for (uint64_t e = 1; e <= 15 && !found; e += 2) {
-        const Fr g = host_fr_pow(five, e);
-        fr_powers(ctx, g, Fr::one(), a->gpow.p, M);
-        hipLaunchKernelGGL(k_arb_t_scaled, dim3(ceil_div(M, 256)), dim3(256), 0, st, a->tree->t.p, n, M, a->gpow.p, a->tinv.p);
-        ntt_dif(ctx, a->tinv.p, a->log_m, false, false);
-        // n == M: t has M + 1 coefficients; x^M is the constant g^M on the coset
-        const Fr top = n == M ? host_fr_pow(g, M) : Fr::zero();
-        ZK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_arb_t_invert, dim3(ceil_div(M, 256)), dim3(256), 0, st, a->tinv.p, M, top, d_flag);
-        ZK_HIP(hipGetLastError());
-        int h = 0;
-        ZK_HIP(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipStreamSynchronize(st));
-        if (!(h & 32)) {
-            found = true;
-            fr_powers(ctx, g.inv(), Fr::one(), a->ginv_pow.p, M);
-        }
-    }
-    ZK_REQUIRE(found, ZK_ERR_UNSUPPORTED, "arbitrary-roots QAP: every candidate evaluation coset contains a root");
+    // t = prod (x - r_k): monic of degree n -- the divisor of the coefficient-form tail the dense form shares (prove.hip)
+    q.dt.alloc(n + 1);
+    ZK_HIP(hipMemcpyAsync(q.dt.p, a->tree->t.p, (n + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    q.t_degree = n;
+    q.t_is_zero = false;
+    q.t_cinv.alloc(1);
+    const Fr one = Fr::one();
+    ZK_HIP(hipMemcpyAsync(q.t_cinv.p, &one, sizeof(Fr), hipMemcpyHostToDevice, st));
     ZK_HIP(hipStreamSynchronize(st));
+    ZK_REQUIRE(!(h & 16), ZK_ERR_ARG, "arbitrary-roots QAP: the roots are not distinct");
     q.arb = a;
 }
 
@@ -135,57 +100,19 @@ void arb_setup_lagrange(zk_ctx* ctx, const zk_qap& q, const uint64_t trapdoor[20
     ZK_HIP(hipGetLastError());
 }
 
-// ---- prove: the scalars of A, B, H + r B1 + s A ------------------------------------------------------------------------------
-__global__ void k_arb_products(const Fr* __restrict__ ue, const Fr* __restrict__ ve, size_t n, Fr* __restrict__ ee) {
-    ZK_LATENCY_KERNEL();
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) ee[j] = ue[j] * ve[j];
-}
-// three coefficient vectors (M apart) -> scaled by g^j for the coset transform
-__global__ void k_arb_scale3(Fr* __restrict__ c, const Fr* __restrict__ gpow, size_t M) {
-    ZK_LATENCY_KERNEL();
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 3 * M) return;
-    c[j] = c[j] * gpow[j & (M - 1)];
-}
-// h on the coset: (U V - E) / t, into the first vector
-__global__ void k_arb_h(Fr* __restrict__ c, const Fr* __restrict__ tinv, size_t M) {
-    ZK_LATENCY_KERNEL();
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    c[j] = (c[j] * c[M + j] - c[2 * M + j]) * tinv[j];
-}
-// coefficients of h: the inverse transform's output times g^-j -> canonical
-__global__ void k_arb_h_out(const Fr* __restrict__ c, const Fr* __restrict__ ginv_pow, size_t count, Fr* __restrict__ out) {
-    ZK_LATENCY_KERNEL();
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < count) out[j] = (c[j] * ginv_pow[j]).to_canonical();
-}
+// ---- prove: the coefficients of U and V ----------------------------------------------------------------------------------------
+size_t arb_work_elems(const zk_qap& q) { return (size_t)8 << q.arb->tree->log_npad; }
 
-size_t arb_work_elems(const zk_qap& q) { return (size_t)12 << q.arb->log_m; }
-
-// ue, ve: the SpMV outputs (values of U, V on the roots, Montgomery; 3 n elements available at ue: ue | ve | products).  Writes the
-// canonical coefficients of V to vc_can (n), of U to uc_can (n), r V + s U to hb_can + (n - 1) (n) and h to hb_can (n - 1).
-// work: arb_work_elems(q) elements.
-void arb_scalars(zk_ctx* ctx, const zk_qap& q, Fr* vals, Fr* work, const Fr& r_mont, const Fr& s_mont, Fr* vc_can, Fr* uc_can, Fr* hb_can) {
-    const ArbTables& a = *q.arb;
-    const size_t n = q.n, M = (size_t)1 << a.log_m;
+// vals: the SpMV outputs U_k | V_k (values on the roots, Montgomery, n each) -> uc, vc: the n coefficients of the interpolants
+// (Montgomery).  work: arb_work_elems(q) elements.
+void arb_coefficients(zk_ctx* ctx, const zk_qap& q, const Fr* vals, Fr* work, Fr* uc, Fr* vc) {
+    const InterpTree& t = *q.arb->tree;
+    const size_t n = q.n, npad = (size_t)1 << t.log_npad;
     hipStream_t st = ctx->stream;
-    Fr *ue = vals, *ve = vals + n, *ee = vals + 2 * n;
-    hipLaunchKernelGGL(k_arb_products, dim3(ceil_div(n, 256)), dim3(256), 0, st, ue, ve, n, ee);
-    Fr* coef = work;                   // 3 M: U | V | E
-    interp_run(ctx, *a.tree, vals, n, 3, work + 3 * M, coef);
-    fr_from_mont(ctx, coef, uc_can, n);
-    fr_from_mont(ctx, coef + M, vc_can, n);
-    fr_lincomb_to_canonical(ctx, coef + M, r_mont, coef, s_mont, hb_can + (n - 1), n);
-    if (n >= 2) {
-        hipLaunchKernelGGL(k_arb_scale3, dim3(ceil_div(3 * M, 256)), dim3(256), 0, st, coef, a.gpow.p, M);
-        ntt_dif(ctx, coef, a.log_m, false, false, 3);
-        hipLaunchKernelGGL(k_arb_h, dim3(ceil_div(M, 256)), dim3(256), 0, st, coef, a.tinv.p, M);
-        ntt_dit(ctx, coef, a.log_m, true, true, nullptr, 1);
-        hipLaunchKernelGGL(k_arb_h_out, dim3(ceil_div(n - 1, 256)), dim3(256), 0, st, coef, a.ginv_pow.p, n - 1, hb_can);
-    }
-    ZK_HIP(hipGetLastError());
+    Fr* coef = work;                   // 2 npad: U | V
+    interp_run(ctx, t, vals, n, 2, work + 2 * npad, coef);
+    ZK_HIP(hipMemcpyAsync(uc, coef, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipMemcpyAsync(vc, coef + npad, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
 }
 
 }  // namespace zk

@@ -186,6 +186,7 @@ struct NttPass {
     const Fr* pre;   // applied on load (data layout) or nullptr
     Fr post;
     int has_post;
+    int contig;      // a tile = 2^log_cols WHOLE transforms of 2^log_rows contiguous elements each (batches of small transforms): element idx of the tile at base + idx
 };
 
 __device__ __forceinline__ FrL lds_get(const int32_t* lds, int e) {
@@ -319,9 +320,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
         int row = idx >> log_cols, col = idx & (cols - 1);
         size_t g = (size_t)row * p.row_stride + col;
+        int at = (col << log_rows) + row;
+        if (p.contig) { g = idx; at = idx; }
         FrL v = FrL::load(base[g]);
         if (pre) v = v * FrL::load(pre[g]);
-        lds_put(lds, (col << log_rows) + row, v);
+        lds_put(lds, at, v);
     }
     __syncthreads();
 
@@ -345,7 +348,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
         int row = idx >> log_cols, col = idx & (cols - 1);
         size_t g = (size_t)row * p.row_stride + col;
-        FrL v = lds_get(lds, (col << log_rows) + row);
+        int at = (col << log_rows) + row;
+        if (p.contig) { g = idx; at = idx; }
+        FrL v = lds_get(lds, at);
         if (mid) v = v * FrL::load(mid[g]);
         if (p.has_post) v = v * post;
         base[g] = fr_store_exact(v);
@@ -386,7 +391,7 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
         // contiguous blocks of 2^22 as a batch of two-pass transforms.  Same orders as below: DIF natural -> bit-reversed, DIT back.
         const unsigned a1 = log_n - 2 * NTT_MAX_LOCAL_LOG, log_c = NTT_MAX_LOCAL_LOG - a1, log_blk = 2 * NTT_MAX_LOCAL_LOG;
         const Fr* mid = inverse ? tabs->mid_inv.p : tabs->mid_fwd.p;
-        NttPass col{a1, log_c, log_blk - log_c, n, (size_t)1 << log_blk, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0};
+        NttPass col{a1, log_c, log_blk - log_c, n, (size_t)1 << log_blk, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0, 0};
         const size_t col_tiles = ((size_t)1 << (log_blk - log_c)) * batch;
         if (!dit) {
             col.mid = mid;
@@ -405,7 +410,15 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
         return;
     }
     if (log_n <= NTT_MAX_LOCAL_LOG) {
-        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, post_f, scale ? 1 : 0};
+        // batches of small transforms (the levels of interp.hip's tree): a tile takes as many whole transforms as fit its 2048 elements
+        unsigned pack = 0;
+        while (!d_pre && log_n + pack < NTT_MAX_LOCAL_LOG && (batch >> (pack + 1)) << (pack + 1) == batch && (batch >> (pack + 1)) >= 256) ++pack;
+        if (pack) {
+            NttPass p{log_n, pack, 0, n << pack, 1, n << pack, tw, nullptr, nullptr, post_f, scale ? 1 : 0, 1};
+            launch_pass(ctx, dit, d, p, batch >> pack, "ntt_tile", pass_bytes);
+            return;
+        }
+        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, post_f, scale ? 1 : 0, 0};
         launch_pass(ctx, dit, d, p, batch, "ntt_tile", pass_bytes);
         return;
     }
@@ -413,8 +426,8 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     unsigned log_c = NTT_MAX_LOCAL_LOG > a ? NTT_MAX_LOCAL_LOG - a : 0;  // columns per tile
     size_t r2 = (size_t)1 << NTT_MAX_LOCAL_LOG;
     const Fr* mid = inverse ? tabs->mid_inv.p : tabs->mid_fwd.p;
-    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0};
-    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, post_f, 0};
+    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, nullptr, nullptr, post_f, 0, 0};
+    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, post_f, 0, 0};
     size_t col_tiles = (r2 >> log_c) * batch, row_tiles = ((size_t)1 << a) * batch;
     if (!dit) {
         col.mid = mid;

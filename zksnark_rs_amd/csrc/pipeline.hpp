@@ -21,12 +21,9 @@ struct ApTables {
     DevBuf<Fr> fact, ifact, w, ws, ntab, bhat;
 };
 
-// tables of the arbitrary-roots form (arbroots.hip): the sub-product tree of the roots, the evaluation coset g <w_M> (M = 2^log_m >= n):
-// g^j, g^-j, 1 / t on the coset (transform order)
+// tables of the arbitrary-roots form (arbroots.hip): the sub-product tree of the roots (t = its root node sits in zk_qap::dt)
 struct ArbTables {
     std::shared_ptr<InterpTree> tree;
-    unsigned log_m = 0;
-    DevBuf<Fr> gpow, ginv_pow, tinv;
     std::vector<Fr> host_roots;    // Montgomery; t(x) of a trapdoor is a host product
 };
 
@@ -43,7 +40,7 @@ struct zk_qap {
     // sparse form (roots w^j): by gate (prove: evaluation vectors) and by wire (setup: u_i(x))
     zk::DevCsr u_gate, v_gate;
     zk::DevCsr u_wire, v_wire, w_wire;
-    // dense form: m x n coefficient matrices and t (n+1), Montgomery
+    // dense form: m x n coefficient matrices and t (n+1), Montgomery (arbitrary-roots form: t only)
     zk::DevBuf<zk::Fr> du, dv, dw, dt;
     size_t t_degree = 0;      // actual degree of t (dense)
     zk::DevBuf<zk::Fr> t_cinv; // 1 / leading coefficient of t (dense)
@@ -102,7 +99,7 @@ void arb_download_roots(zk_ctx*, const zk_qap&, uint64_t* out);
 void arb_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, int* d_flag);
 Fr arb_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
 size_t arb_work_elems(const zk_qap&);
-void arb_scalars(zk_ctx*, const zk_qap&, Fr* vals, Fr* work, const Fr& r_mont, const Fr& s_mont, Fr* vc_can, Fr* uc_can, Fr* hb_can);
+void arb_coefficients(zk_ctx*, const zk_qap&, const Fr* vals, Fr* work, Fr* uc, Fr* vc);
 void ap_setup_lagrange(zk_ctx*, const zk_qap&, const uint64_t trapdoor[20], Fr* d_L, Fr* d_LS, int* d_flag);
 Fr ap_t_at_x(const zk_qap&, const uint64_t trapdoor[20]);
 void ap_quotient_values(zk_ctx*, const zk_qap&, const Fr* ue, const Fr* ve, Fr* work, Fr* hb_can, size_t count = 1, size_t hb_stride = 0);

@@ -377,7 +377,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     else if (q.dense || q.roots == 2) crs_ensure_tables(ctx, crs, false, 0);   // coefficient forms: the reference's [x^i], natural order
     else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
-    if (q.dense && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
+    if ((q.dense || q.roots == 2) && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
         unsigned lc0 = 1;
         while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
         qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
@@ -446,19 +446,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             for (auto& d : deferred)
                 if (d.first == order[pos]) { d.second(prev); prev = d.first; }
     };
-    if (!q.dense && q.roots == 2) {
-        // caller's roots (arbroots.hip): U, V and the interpolant of U_k V_k are interpolated per proof by the sub-product tree; bases = [x^i]
-        S.uv.ensure(3 * n); S.xy.ensure(arb_work_elems(q));
-        S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
-        Fr *ue = S.uv.p, *ve = S.uv.p + n;
-        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
-        spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
-        arb_scalars(ctx, q, S.uv.p, S.xy.p, r_mont, s_mont, S.vc_can.p, S.uc_can.p, S.hb_can.p);
-        launch(2, 1, crs.t_xi1, S.uc_can.p, n, &ms->a);
-        launch(0, 2, crs.t_xi2, S.vc_can.p, n, &ms->b2);
-        launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
-    } else if (!q.dense && q.roots) {
+    if (!q.dense && q.roots == 1) {
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
         const size_t M = (size_t)1 << q.ap->log_m;
         S.uv.ensure(2 * n); S.xy.ensure(3 * M);
@@ -489,7 +477,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
         ap_quotient_values(ctx, q, ue, ve, S.xy.p, hb_can);              // h on S = {n+1 .. 2n-1}
         launch(4, 2, crs.t_hb1, hb_can, 2 * n - 1, &ms->hb);
-    } else if (!q.dense) {
+    } else if (!q.dense && q.roots == 0) {
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         S.uv.ensure(2 * n); S.uvg.ensure(2 * n); S.xy.ensure(2 * n);
@@ -523,9 +511,18 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         S.ue.ensure(n); S.ve.ensure(n); S.wc.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
         S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
-        dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
-        dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
+        if (q.dense) {
+            dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
+            dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
+            dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
+        } else {
+            // sparse rows over the caller's roots (arbroots.hip): the values of U, V on the roots, interpolated by the sub-product tree.
+            // W is not needed: U V = h t + E with E = the interpolant of U_k V_k (degree < n), so the quotient of U V alone is h.
+            S.uv.ensure(2 * n); S.xy.ensure(arb_work_elems(q));
+            spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.uv.p);
+            spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.uv.p + n);
+            arb_coefficients(ctx, q, S.uv.p, S.xy.p, S.ue.p, S.ve.p);
+        }
         fr_from_mont(ctx, S.ue.p, S.uc_can.p, n);
         fr_from_mont(ctx, S.ve.p, S.vc_can.p, n);
         launch(2, 1, crs.t_xi1, S.uc_can.p, n, &ms->a);
@@ -539,7 +536,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ntt_dif(ctx, S.prod_b.p, lc, false, false);
         fr_pointwise_mul(ctx, S.prod_a.p, S.prod_b.p, S.prod_a.p, nc);
         ntt_dit(ctx, S.prod_a.p, lc, true, true, nullptr);                // U*V coefficients, natural order
-        fr_sub_inplace(ctx, S.prod_a.p, S.wc.p, n);                       // - W
+        if (q.dense) fr_sub_inplace(ctx, S.prod_a.p, S.wc.p, n);          // - W
         // quotient by t (degree d); remainder dropped (coefficient_poly.rs:148-157)
         ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
