@@ -17,6 +17,8 @@ python bench.py --steps 100 --warmup 5 > $OUT/bench_100steps.json 2>> $OUT/bench
   python bench.py --log-n 4 --latency --steps 40 --warmup 8
   python bench.py --log-n 4 --roots integers --steps 640 --warmup 64 --batch 32
   python bench.py --roots integers --steps 60 --warmup 5
+  python bench.py --roots arbitrary --steps 30 --warmup 4
+  python bench.py --roots arbitrary --log-n 16 --steps 100 --warmup 8
   python bench.py --latency --steps 20 --warmup 4
   python bench.py --log-n 21 --steps 30 --warmup 4 --no-cpu-baseline
   python bench.py --log-n 22 --steps 20 --warmup 4 --no-cpu-baseline
