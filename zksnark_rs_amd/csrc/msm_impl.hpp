@@ -459,6 +459,11 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // Few buckets: the tail is a chain of dependent additions on lanes that have nothing else to do, so four lanes share each
     // addition (msm_quad.hpp: ~3x shorter chains).  Many buckets (the products of 2^20 points and more, batches): one lane per addition.
     const bool quad = (size_t)buckets <= (size_t)std::max<long>(ctx->opt_quad_buckets, 0);
+    // Whatever the size of the product, the END of its tail is a few thousand lanes in long dependency chains (the last fold passes,
+    // the weighted terms, their sum): those take the quad form too.  Stand-alone at 2^20 gates the weights of the G2 product took 0.81 ms
+    // and its final sum 0.39 with one lane per addition.
+    const bool quad_end = ctx->opt_quad_buckets > 0;
+    constexpr size_t QUAD_FOLD_JOBS = 16384;   // fold passes of at most this many output images
     const int run_wgs = (int)ceil_div(buckets, 256);
 
     ws.hist.ensure((size_t)chunks * bins);
@@ -481,7 +486,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.bucket_sums.ensure(((size_t)buckets + max_extra) * sizeof(AccSlot<F>));              // S_b as accumulator images | extra runs
     const size_t half = ((size_t)buckets + 1) / 2, quarter = ((size_t)buckets + 3) / 4;
     ws.fold.ensure((2 * (half + quarter) + (size_t)groups * (K + rows)) * sizeof(AccSlot<F>));   // per chain: passes 1, 3, .. | passes 2, 4, ..; then C | R
-    ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w) * std::max(sizeof(Jac<F>), sizeof(AccSlot<F>)));   // terms | partial sums
+    ws.seg_sums.ensure((size_t)groups * (K + rows + wgs_w + (K + rows) / QUAD_SUM_THREADS + 2) * std::max(sizeof(Jac<F>), sizeof(AccSlot<F>)));   // terms | partial sums
     const size_t heavy_cap = 2 + 2 * ((size_t)buckets + max_extra / MSM_HEAVY_CHUNK + 1) + (size_t)buckets;   // count, count | (bucket, chunk) items | multi-chunk buckets, from the end
     ws.heavy.ensure(heavy_cap);
     AccSlot<F>* d_img = reinterpret_cast<AccSlot<F>*>(ws.bucket_sums.p);
@@ -576,17 +581,31 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                 const uint32_t f = std::min(h.count, FOLD);
                 AccSlot<F>* out = h.count == f ? h.fin : h.tmp[h.tog];
                 const uint32_t A = h.outer * (h.count / f);
-                job[q] = FoldJob{h.in, out, A, f, h.B, (uint32_t)ceil_div((size_t)A * h.B, quad ? QUAD_JOBS : TAIL_THREADS)};
+                job[q] = FoldJob{h.in, out, A, f, h.B, 0};
                 if (h.count == f) h.done = true;
                 h.count /= f; h.in = out; h.tog ^= 1;
             }
-            if (quad) hipLaunchKernelGGL(k_msm_fold_q<F>, dim3(job[0].blocks + job[1].blocks), dim3(QUAD_THREADS), 0, st, job[0], job[1]);
+            const bool qf = quad || (quad_end && (size_t)job[0].A * job[0].B + (size_t)job[1].A * job[1].B <= QUAD_FOLD_JOBS);
+            for (int q = 0; q < 2; ++q) job[q].blocks = job[q].in ? (uint32_t)ceil_div((size_t)job[q].A * job[q].B, qf ? QUAD_JOBS : TAIL_THREADS) : 0;
+            if (qf && quad) hipLaunchKernelGGL((k_msm_fold_q<F, false>), dim3(job[0].blocks + job[1].blocks), dim3(QUAD_THREADS), 0, st, job[0], job[1]);
+            else if (qf) hipLaunchKernelGGL((k_msm_fold_q<F, true>), dim3(job[0].blocks + job[1].blocks), dim3(QUAD_THREADS), 0, st, job[0], job[1]);
             else hipLaunchKernelGGL(k_msm_fold<F>, dim3(job[0].blocks + job[1].blocks), dim3(TAIL_THREADS), 0, st, job[0], job[1]);
         }
-        if (quad) {
+        if (quad || quad_end) {
             AccSlot<F>* d_term = reinterpret_cast<AccSlot<F>*>(ws.seg_sums.p);
-            hipLaunchKernelGGL(k_msm_weigh_q<F>, dim3(ceil_div(K + rows, QUAD_JOBS), groups), dim3(QUAD_THREADS), 0, st, d_C, d_R, kbits, rows, d_term);
-            hipLaunchKernelGGL(k_msm_sum_q<F>, dim3(groups), dim3(QUAD_SUM_THREADS), 0, st, d_term, K + rows, d_out, grp.out_stride);
+            AccSlot<F>* d_qpart = d_term + (size_t)groups * (K + rows);
+            const int terms = K + rows, parts = (terms + QUAD_SUM_THREADS - 1) / QUAD_SUM_THREADS;
+            auto end = [&](auto big) {
+                constexpr bool BIG = decltype(big)::value;
+                hipLaunchKernelGGL((k_msm_weigh_q<F, BIG>), dim3(ceil_div(terms, QUAD_JOBS), groups), dim3(QUAD_THREADS), 0, st, d_C, d_R, kbits, rows, d_term);
+                if (parts > 1) {
+                    hipLaunchKernelGGL((k_msm_sum_q<F, false, BIG>), dim3(parts, groups), dim3(QUAD_SUM_THREADS), 0, st, d_term, terms, d_qpart, d_out, grp.out_stride);
+                    hipLaunchKernelGGL((k_msm_sum_q<F, true, BIG>), dim3(1, groups), dim3(QUAD_SUM_THREADS), 0, st, d_qpart, parts, d_qpart, d_out, grp.out_stride);
+                } else {
+                    hipLaunchKernelGGL((k_msm_sum_q<F, true, BIG>), dim3(1, groups), dim3(QUAD_SUM_THREADS), 0, st, d_term, terms, d_qpart, d_out, grp.out_stride);
+                }
+            };
+            if (quad) end(std::false_type{}); else end(std::true_type{});
             ZK_HIP(hipGetLastError());
             return st;
         }

@@ -14,6 +14,9 @@ constexpr int QUAD_JOBS = QUAD_THREADS / 4;
 #endif
 template <class F> struct QuadWaves { static constexpr int value = TailWaves<F>::value; };
 template <> struct QuadWaves<Fq2> { static constexpr int value = ZK_QUAD_G2_WAVES; };
+// BIG: the same kernels at the end of the tail of a LARGE product (msm_run: quad_end), where accumulations of other products do fill
+// the chip: the register budget of the one-lane tail kernels (TailWaves), so that a wave fits wherever one accumulation wave retires.
+template <class F, bool BIG> struct QuadWavesOf { static constexpr int value = BIG ? TailWaves<F>::value : QuadWaves<F>::value; };
 
 template <class F>
 __global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_merge_q(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_merge
     if (role == 0) img[b].a = acc;
 }
 
-template <class F>
-__global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_fold_q(FoldJob j0, FoldJob j1) {
+template <class F, bool BIG>
+__global__ __launch_bounds__(QUAD_THREADS, (QuadWavesOf<F, BIG>::value)) void k_msm_fold_q(FoldJob j0, FoldJob j1) {
     ZK_LATENCY_KERNEL();
     const bool second = blockIdx.x >= j0.blocks;
     const AccSlot<F>* in = reinterpret_cast<const AccSlot<F>*>(second ? j1.in : j0.in);
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_fold_
 }
 
 // term[group][j] as in k_msm_weigh, kept as accumulator images
-template <class F>
-__global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_weigh_q(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
+template <class F, bool BIG>
+__global__ __launch_bounds__(QUAD_THREADS, (QuadWavesOf<F, BIG>::value)) void k_msm_weigh_q(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
                                                      AccSlot<F>* __restrict__ term) {
     ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
@@ -72,23 +75,26 @@ __global__ __launch_bounds__(QUAD_THREADS, QuadWaves<F>::value) void k_msm_weigh
     if (role == 0) term[(size_t)g * (K + rows) + j].a = t;
 }
 
-// one workgroup per group (blockIdx.x): its 64 quads add the `count` terms (each quad its share, then a tree over LDS) -> out
+// Sums `count` accumulator images per group (blockIdx.y): workgroup x takes the images [256 x, 256 x + 256) -- each of its 64 quads its
+// share, then a tree over LDS.  FINAL: one workgroup per group, the sum goes out as a Jacobian point at (bytes) out + y out_stride;
+// otherwise the partial sums go to part[y gridDim.x + x] (a second launch with FINAL adds them).
 constexpr int QUAD_SUM_THREADS = 256;
-template <class F>
-__global__ __launch_bounds__(QUAD_SUM_THREADS, QuadWaves<F>::value) void k_msm_sum_q(const AccSlot<F>* __restrict__ in, int count, Jac<F>* __restrict__ out, size_t out_stride) {
+template <class F, bool FINAL, bool BIG>
+__global__ __launch_bounds__(QUAD_SUM_THREADS, (QuadWavesOf<F, BIG>::value)) void k_msm_sum_q(const AccSlot<F>* __restrict__ in, int count, AccSlot<F>* __restrict__ part,
+                                                            Jac<F>* __restrict__ out, size_t out_stride) {
     ZK_LATENCY_KERNEL();
     __shared__ AccSlot<F> sh[QUAD_SUM_THREADS / 4];
     constexpr int Q = QUAD_SUM_THREADS / 4;
-    in += (size_t)blockIdx.x * count;
-    out = reinterpret_cast<Jac<F>*>(reinterpret_cast<uint8_t*>(out) + (size_t)blockIdx.x * out_stride);
+    in += (size_t)blockIdx.y * count;
     const int q = threadIdx.x >> 2, role = threadIdx.x & 3;
+    const int lo = FINAL ? 0 : (int)blockIdx.x * QUAD_SUM_THREADS, hi = FINAL ? count : min(lo + QUAD_SUM_THREADS, count);
     typename AccOf<F>::type acc;
     acc_clear(acc);
-    for (int k = q; k < count; k += Q) acc = quad_add_xyzz(acc, in[k].a, role);
+    for (int k = lo + q; k < hi; k += Q) acc = quad_add_xyzz(acc, in[k].a, role);
     if (role == 0) sh[q].a = acc;
     __syncthreads();
     int d0 = Q / 2;
-    while (d0 >= 2 && d0 >= count) d0 >>= 1;   // quads at and behind `count` hold infinity
+    while (d0 >= 2 && d0 >= hi - lo) d0 >>= 1;   // quads at and behind the number of images hold infinity
     for (int d = d0; d >= 1; d >>= 1) {
         if (q < d) {
             acc = quad_add_xyzz(sh[q].a, sh[q + d].a, role);
@@ -96,6 +102,8 @@ __global__ __launch_bounds__(QUAD_SUM_THREADS, QuadWaves<F>::value) void k_msm_s
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = acc_store(sh[0].a);
+    if (threadIdx.x == 0) {
+        if (FINAL) *reinterpret_cast<Jac<F>*>(reinterpret_cast<uint8_t*>(out) + (size_t)blockIdx.y * out_stride) = acc_store(sh[0].a);
+        else part[(size_t)blockIdx.y * gridDim.x + blockIdx.x].a = sh[0].a;
+    }
 }
-
