@@ -309,11 +309,17 @@ constexpr int MSM_HEAVY_THREADS = 128;
 // heavy buckets.  Image j of bucket b: its own slot (j = 0) or slot j - 1 behind img[buckets + xbase[b]].
 // FINAL = false: one workgroup per queued (bucket, chunk) item sums the chunk's images (lanes stride over them, tree over LDS) into the
 // chunk's first image.  FINAL = true: one workgroup per multi-chunk bucket sums the chunks' first images into the bucket's slot.
+// (registers as the other tail kernels, TailWaves: left alone the Fq2 instance takes 256, and -- launched behind EVERY accumulation,
+// normally to find nothing to do -- waited ~1 ms for two accumulation waves of a SIMD to retire together, with the rest of the G2 tail
+// and the next proof's G2 sort queued behind it)
 template <class F, bool FINAL>
-__global__ __launch_bounds__(MSM_HEAVY_THREADS) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
+__global__ __launch_bounds__(MSM_HEAVY_THREADS, TailWaves<F>::value) void k_msm_merge_heavy(const uint32_t* __restrict__ start, int buckets, uint32_t T, const uint32_t* __restrict__ xbase,
                                                          AccSlot<F>* __restrict__ img, const uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
     ZK_LATENCY_KERNEL();
-    __shared__ AccSlot<F> sh[MSM_HEAVY_THREADS];   // 38 KiB for G2 images
+    // 38 KiB for G2 images.  Dynamic: with a static array the compiler sees that LDS already limits the kernel to two waves per SIMD
+    // and does not bother to stay within the three-wave register budget
+    extern __shared__ __attribute__((aligned(16))) uint8_t heavy_smem[];
+    AccSlot<F>* sh = reinterpret_cast<AccSlot<F>*>(heavy_smem);
     const uint32_t count = FINAL ? heavy[1] : heavy[0];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         const uint32_t b = FINAL ? heavy[heavy_cap - 1 - h] : heavy[2 + 2 * h], w = FINAL ? 0 : heavy[3 + 2 * h];
@@ -564,8 +570,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         // workgroups read the count and leave; a narrow top window makes 2^(top bits) buckets heavy at once); with few buckets and many
         // entries (small windows) nearly every bucket is heavy
         const unsigned heavy_grid = entries / T / (size_t)buckets > MSM_HEAVY / 2 ? (unsigned)std::min(buckets, 4096) : 256u;
-        hipLaunchKernelGGL((k_msm_merge_heavy<F, false>), dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
-        hipLaunchKernelGGL((k_msm_merge_heavy<F, true>), dim3(64), dim3(MSM_HEAVY_THREADS), 0, st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
+        hipLaunchKernelGGL((k_msm_merge_heavy<F, false>), dim3(heavy_grid), dim3(MSM_HEAVY_THREADS), MSM_HEAVY_THREADS * sizeof(AccSlot<F>), st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
+        hipLaunchKernelGGL((k_msm_merge_heavy<F, true>), dim3(64), dim3(MSM_HEAVY_THREADS), MSM_HEAVY_THREADS * sizeof(AccSlot<F>), st, ws.start.p, buckets, T, ws.xbase.p, d_img, ws.heavy.p, (uint32_t)heavy_cap);
         // column sums C[g][lo] (fold the row index, FOLD images per lane and pass), then row sums R[g][hi] (fold the column index)
         uint32_t FOLD = 2;   // images per lane and pass (msm_fold option), a power of two
         while (FOLD * 2 <= (uint32_t)std::max<long>(2, std::min<long>(ctx->opt_fold, 64))) FOLD *= 2;
