@@ -174,6 +174,43 @@ class QAP {
         c.check(zk_qap_upload_dense(c.get(), fu.data(), fv.data(), fw.data(), t[0].w.data(), m, n, input, &q), "QAP");
         return QAP(q);
     }
+    // From<RootRepresentation> for ANY root representation (circuit/mod.rs:201-214; fr.rs:140-173): u, v, w = one row per wire of
+    // (root, value) pairs, roots = the representation's distinct roots in gate order, `input` as RootRepresentation::input().  The
+    // wire polynomials are never interpolated (zk_qap_upload_sparse_roots): any size up to 2^22 gates, the reference's proof bytes.
+    typedef std::vector<std::vector<std::pair<FrLocal, FrLocal>>> Rows;
+    static QAP from_root_rep(const Context& c, const std::vector<FrLocal>& roots, const Rows& u, const Rows& v, const Rows& w, size_t input) {
+        const size_t n = roots.size(), m = u.size();
+        if (v.size() != m || w.size() != m) throw Error(ZK_ERR_ARG, "QAP: u, v, w must have one row per wire");
+        auto index_of = [&](const FrLocal& r) {
+            for (size_t j = 0; j < n; ++j) if (roots[j].w == r.w) return (uint32_t)j;
+            throw Error(ZK_ERR_ARG, "QAP: a row names a root that roots() does not list");
+        };
+        struct Csr { std::vector<uint64_t> ptr, val; std::vector<uint32_t> gate; };
+        auto pack = [&](const Rows& rows) {
+            Csr x;
+            x.ptr.push_back(0);
+            for (const auto& row : rows) {
+                for (const auto& e : row) {
+                    x.gate.push_back(index_of(e.first));
+                    x.val.insert(x.val.end(), e.second.w.begin(), e.second.w.end());
+                }
+                x.ptr.push_back(x.gate.size());
+            }
+            if (x.gate.empty()) { x.gate.push_back(0); x.val.resize(4); }   // non-null pointers for empty rows
+            return x;
+        };
+        Csr cu = pack(u), cv = pack(v), cw = pack(w);
+        std::vector<uint64_t> rw(4 * n);
+        for (size_t j = 0; j < n; ++j) std::copy(roots[j].w.begin(), roots[j].w.end(), rw.begin() + 4 * j);
+        zk_qap_sparse_desc d{};
+        d.log_n = 0; d.m = m; d.input = input;
+        d.u = zk_sparse_rows{cu.ptr.data(), cu.gate.data(), cu.val.data()};
+        d.v = zk_sparse_rows{cv.ptr.data(), cv.gate.data(), cv.val.data()};
+        d.w = zk_sparse_rows{cw.ptr.data(), cw.gate.data(), cw.val.data()};
+        zk_qap* q = nullptr;
+        c.check(zk_qap_upload_sparse_roots(c.get(), &d, rw.data(), n, &q), "QAP::from_root_rep");
+        return QAP(q);
+    }
     const zk_qap* get() const { return q_; }
     size_t degree() const { size_t n, m, l; int d; zk_qap_dims(q_, &n, &m, &l, &d); return n; }
     size_t wires() const { size_t n, m, l; int d; zk_qap_dims(q_, &n, &m, &l, &d); return m; }

@@ -119,6 +119,39 @@ static void bn_encrypt_deg_15_test(const Context& ctx) {
     std::puts("ok bn_encrypt_deg_15_test");
 }
 
+// single_mult_honest_bn's QAP written as the root representation it comes from (one gate at the root -250, circuit/mod.rs:201-214) and,
+// on a second circuit, roots that are neither 1..n nor roots of unity: QAP::from_root_rep (zk_qap_upload_sparse_roots) gives the bytes of
+// the dense struct literal under the same CRS and (r, s), and its own setup verifies.
+static void root_representation_over_any_roots(const Context& ctx) {
+    auto constant = [](uint64_t v) { return std::vector<FrLocal>{FrLocal(v)}; };
+    QAP dense = QAP::from_dense(ctx, {constant(0), constant(0), constant(1), constant(0)}, {constant(0), constant(0), constant(0), constant(1)},
+                                {constant(0), constant(1), constant(0), constant(0)}, {FrLocal(250), FrLocal(1)}, 2);
+    FrLocal root;
+    root.w = FrLocal::MODULUS;
+    root.w[0] -= 250;
+    QAP::Rows u(4), v(4), w(4);
+    u[2] = {{root, FrLocal(1)}}; v[3] = {{root, FrLocal(1)}}; w[1] = {{root, FrLocal(1)}};
+    QAP sparse = QAP::from_root_rep(ctx, {root}, u, v, w, 2);
+    std::vector<FrLocal> weights = {1, 51, 3, 17};
+    auto sigma = setup(ctx, dense);
+    FrLocal r = FrLocal::random_elem(), s = FrLocal::random_elem();
+    ASSERT(groth16::prove_with(ctx, dense, sigma, weights, r, s) == groth16::prove_with(ctx, sparse, sigma, weights, r, s));
+    auto sigma2 = setup(ctx, sparse);
+    ASSERT(verify(ctx, sigma2, {FrLocal(51), FrLocal(3)}, prove(ctx, sparse, sigma2, weights)));
+    ASSERT(!verify(ctx, sigma2, {FrLocal(52), FrLocal(3)}, prove(ctx, sparse, sigma2, weights)));
+    // two gates at the roots 7 and 1000003: out = (a * b) * c;  wires 1, out, a, b, c, t
+    std::vector<FrLocal> roots = {FrLocal(7), FrLocal(1000003)};
+    QAP::Rows u2(6), v2(6), w2(6);
+    u2[2] = {{roots[0], FrLocal(1)}}; v2[3] = {{roots[0], FrLocal(1)}}; w2[5] = {{roots[0], FrLocal(1)}};   // a * b = t
+    u2[5] = {{roots[1], FrLocal(1)}}; v2[4] = {{roots[1], FrLocal(1)}}; w2[1] = {{roots[1], FrLocal(1)}};   // t * c = out
+    QAP q2 = QAP::from_root_rep(ctx, roots, u2, v2, w2, 1);
+    auto s3 = setup(ctx, q2);
+    std::vector<FrLocal> wt = {1, 3 * 5 * 11, 3, 5, 11, 15};
+    ASSERT(verify(ctx, s3, {FrLocal(165)}, prove(ctx, q2, s3, wt)));
+    ASSERT(!verify(ctx, s3, {FrLocal(166)}, prove(ctx, q2, s3, wt)));
+    std::puts("ok root_representation_over_any_roots");
+}
+
 static void error_behaviour(const Context& ctx) {
     Field F(ctx);
     bool threw = false;
@@ -151,6 +184,7 @@ int main(int argc, char** argv) {
         bn_encrypt_quad_test(ctx);
         bn_encrypt_cubic_test(ctx);
         bn_encrypt_deg_15_test(ctx);
+        root_representation_over_any_roots(ctx);
         error_behaviour(ctx);
     } catch (const Error& e) {
         std::fprintf(stderr, "zksnark::Error %d: %s\n", e.status, e.what());

@@ -39,7 +39,7 @@ def test_reference_tests_through_cpp_api(tmp_path):
     res = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zk")], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     for name in ("simple_circuit_test", "single_mult_honest_bn", "bn_encrypt_quad_test", "bn_encrypt_cubic_test",
-                 "bn_encrypt_deg_15_test", "error_behaviour"):
+                 "bn_encrypt_deg_15_test", "root_representation_over_any_roots", "error_behaviour"):
         assert "ok " + name in res.stdout, res.stdout + res.stderr
 
 
