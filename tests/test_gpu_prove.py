@@ -68,6 +68,11 @@ def test_prove_sparse_matches_faithful_oracle(ctx, orc, log_n):
     # uploading the same CRS from host arrays gives the same proof (zk_crs_upload path)
     crs2 = ctx.crs_upload(inst["n"], inst["m"], inst["l"], arrs)
     assert ctx.prove(crs2, inst["qap"], inst["weights"], inst["r"], inst["s"]) == got
+    # blinding scalars at the edges: r = 0 and / or s = 0 (r delta, s delta2 and the whole fixed part of C are then the point at
+    # infinity inside k_assemble_pre, which adds alpha and beta2 to them), and r - 1
+    top = zk.R_MODULUS - 1
+    for r, s in ((0, 0), (0, inst["s"]), (inst["r"], 0), (top, top), (1, top)):
+        assert ctx.prove(crs, inst["qap"], inst["weights"], r, s) == orc.prove_sparse(inst["desc"], cdesc, inst["weights"], r, s, True), (r, s)
 
 
 @pytest.mark.parametrize("log_n", [8, 10])
