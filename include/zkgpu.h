@@ -88,7 +88,7 @@ int zk_ntt_fr(zk_ctx* ctx, uint64_t* data, unsigned log_n, int inverse, int cose
  * p(roots[k]) = values[k] -- what QAP::from does per wire polynomial with Lagrange sums (fr.rs:140-173, coefficient_poly.rs:159-200;
  * O(n^2) each) and the prover of an arbitrary-roots QAP (zk_qap_upload_sparse_roots) does per proof for U and V,
  * by a sub-product tree over batched NTTs in O(n log^2 n) (csrc/interp.hip).  1 <= n <= 2^23; ZK_ERR_ARG when two roots
- * coincide.  (The per-root-set tables cost O(n^2) field multiplications once.) */
+ * coincide. */
 int zk_interpolate_fr(zk_ctx* ctx, const uint64_t* roots, const uint64_t* values, size_t n, uint64_t* coeffs);
 
 /* sum_i scalars[i] * points[i]: the SigmaG1/SigmaG2 inner products of groth16::prove
@@ -168,8 +168,8 @@ int zk_qap_upload_sparse_integers(zk_ctx* ctx, const zk_qap_sparse_desc* desc, s
  * QAP::from(root_rep) (fr.rs:140-173) followed by the reference's coefficient-form prove -- byte-identical proofs -- but the 3 m wire
  * polynomials are never interpolated: the prover interpolates U = sum a_i u_i and V per proof from their values on the roots by a
  * sub-product tree (csrc/interp.hip, O(n log^2 n)), divides U V by t (the remainder is dropped) and takes its inner products with the
- * reference's own [x^i] arrays, so ANY CRS for the circuit serves (zk_setup, zk_crs_upload, a file).  Once per root set: O(n^2) field
- * multiplications (0.7 s at 2^18 gates, 11 s at 2^20).  ZK_ERR_ARG when two roots coincide.  One proof at a time or pipelined on one GPU, or
+ * reference's own [x^i] arrays, so ANY CRS for the circuit serves (zk_setup, zk_crs_upload, a file).  The tables of a root set (the tree,
+ * the weights 1 / N'(r_k) by a scaled remainder tree) are O(n log^2 n) too: 0.14 s at 2^20 gates.  ZK_ERR_ARG when two roots coincide.  One proof at a time or pipelined on one GPU, or
  * window-sharded (zk_prove_partial); batches and the scalar exchange take the two forms above (ZK_ERR_UNSUPPORTED). */
 int zk_qap_upload_sparse_roots(zk_ctx* ctx, const zk_qap_sparse_desc* desc, const uint64_t* roots, size_t n, zk_qap** out);
 

@@ -14,8 +14,13 @@
 //   * above, one level = batched transforms (ntt.hip, one launch per pass for ALL nodes of the level and all vectors): children padded
 //     to twice their size, forward DIF, P_l N_r + P_r N_l point-wise against the stored images of the children's N, inverse DIT;
 //   * leaves beyond n are empty (N = 1, P = 0), so n is arbitrary; a node's N has degree = its number of real leaves.
-// Per-QAP precompute: N'(r_k) = prod_{j != k} (r_k - r_j) directly (O(n^2) field multiplications, 0.6 s at 2^18, once per circuit),
-// the block matrices, the images of every node's N (2 npad elements per level), t = N_root.
+// Per-QAP precompute, O(n log^2 n) as well: the block matrices, the images of every node's N (2 npad elements per level), t = N_root,
+// and the weights 1 / N'(r_k) by the SCALED REMAINDER TREE over the same images (Bernstein): N'/N = sum_i c_i x^-i with
+// c = rev(N') / rev(N) as power series (one Newton inversion at the root); a node v keeps the first d_v terms of the fractional part of
+// N'/N_v as G_v = sum c_i x^(d_v - i), and a child's is a MIDDLE product of its parent's with the sibling's N -- coefficients
+// [d_sibling, d_parent) of the cyclic product of twice the child's size, which the transform does not wrap; at a block,
+// N' mod N_block = coefficients [d, 2 d) of G N_block, evaluated at the block's roots by Horner.  (The first version multiplied
+// prod_{j != k} (r_k - r_j) out directly: 10.9 s at 2^20 gates.)
 #include <vector>
 #include "pipeline.hpp"
 #include "interp.hpp"
@@ -25,24 +30,81 @@ namespace zk {
 constexpr int IB = INTERP_BLOCK;   // leaves per bottom block
 
 // ---- per-QAP tables ---------------------------------------------------------------------------------------------------------
-// d[k] = prod_{j != k} (r_k - r_j); flag |= 16 when two roots coincide
-__global__ void k_interp_nprime(const Fr* __restrict__ r, size_t n, Fr* __restrict__ out, int* __restrict__ flag) {
-    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const Fr rk = r[k];
-    Fr acc = Fr::one();
-    for (size_t j = 0; j < n; ++j) {
-        const Fr d = rk - r[j];
-        acc = acc * (j == k ? Fr::one() : d);
-    }
-    if (acc.is_zero()) { atomicOr(flag, 16); out[k] = Fr::zero(); return; }
-    out[k] = acc.inv();
+// number of real leaves under node `idx` of a level whose nodes cover `size` leaves each
+__device__ __host__ inline size_t interp_degree(size_t idx, size_t size, size_t n) {
+    const size_t lo = idx * size;
+    return lo >= n ? 0 : (n - lo < size ? n - lo : size);
+}
+
+// ---- weights: 1 / N'(r_k) by the scaled remainder tree ----
+// rev(N')[i] = (n - i) t_(n - i), i < n, zero padded to `size`
+__global__ void k_interp_rev_derivative(const Fr* __restrict__ t, size_t n, size_t size, Fr* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    if (i >= n) { out[i] = Fr::zero(); return; }
+    Fr k = Fr::zero();
+    const uint64_t f = (uint64_t)(n - i);
+    k.l[0] = (uint32_t)f; k.l[1] = (uint32_t)(f >> 32);
+    out[i] = Fr::from_canonical(k) * t[n - i];
+}
+// G_root[j] = c_(n - j) = series[n - 1 - j], j < n, zero padded to npad
+__global__ void k_interp_root_series(const Fr* __restrict__ series, size_t n, size_t npad, Fr* __restrict__ g) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npad) return;
+    g[j] = j < n ? series[n - 1 - j] : Fr::zero();
+}
+// out[c][j] = gimg[c / 2][j] nev[sibling of c][j], j < 2s: the images of the two middle products of every parent
+__global__ void k_interp_down_mul(const Fr* __restrict__ gimg, const Fr* __restrict__ nev, size_t s2, size_t children, Fr* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= children * s2) return;
+    const size_t c = g / s2, j = g - c * s2;
+    out[g] = gimg[(c >> 1) * s2 + j] * nev[(c ^ 1) * s2 + j];
+}
+// G_child[j] = cyc[child][d_sibling + j], j < d_child (children of s leaves; cyc: children x 2s), zero padded to s
+__global__ void k_interp_down_take(const Fr* __restrict__ cyc, size_t s, size_t children, size_t n, Fr* __restrict__ g) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= children * s) return;
+    const size_t c = t / s, j = t - c * s;
+    const size_t dc = interp_degree(c, s, n), ds = interp_degree(c ^ 1, s, n);
+    g[t] = j < dc ? cyc[c * 2 * s + ds + j] : Fr::zero();
+}
+// One workgroup per block: R = N' mod N_block = coefficients [d, 2d) of G N_block, w_k = 1 / R(r_k); flag |= 16 when a root repeats.
+// blk_poly: the blocks' N as full coefficient lists, 2 IB apart (what k_interp_blocks wrote)
+__global__ __launch_bounds__(INTERP_BLOCK) void k_interp_weights(const Fr* __restrict__ g, const Fr* __restrict__ blk_poly, const Fr* __restrict__ r, size_t n,
+                                                              Fr* __restrict__ w, int* __restrict__ flag) {
+    __shared__ Fr gs[IB], ns[IB + 1], rs_[IB];
+    const size_t blk = blockIdx.x, base = blk * IB;
+    const int k = threadIdx.x;
+    const int d = (int)(base >= n ? 0 : (n - base < (size_t)IB ? n - base : IB));
+    if (d == 0) return;
+    gs[k] = g[base + k];
+    ns[k] = blk_poly[blk * (size_t)(2 * IB) + k];
+    if (k == 0) ns[IB] = blk_poly[blk * (size_t)(2 * IB) + IB];
+    __syncthreads();
+    Fr acc = Fr::zero();
+    if (k < d)
+        for (int i = k; i < d; ++i) acc = acc + gs[i] * ns[d + k - i];     // (G N)[d + k]
+    rs_[k] = acc;
+    __syncthreads();
+    if (k >= d) return;
+    const Fr x = r[base + k];
+    Fr v = Fr::zero();
+    for (int i = d - 1; i >= 0; --i) v = v * x + rs_[i];
+    if (v.is_zero()) { atomicOr(flag, 16); w[base + k] = Fr::zero(); return; }
+    w[base + k] = v.inv();
+}
+// q[block][i][k] *= w_k
+__global__ void k_interp_scale_q(Fr* __restrict__ qmat, const Fr* __restrict__ w, size_t n, size_t npad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= npad * IB) return;
+    const size_t blk = g / ((size_t)IB * IB), k = g % IB, leaf = blk * IB + k;
+    if (leaf < n) qmat[g] = qmat[g] * w[leaf];
 }
 
 // One workgroup (IB lanes) per block of IB leaves.  Lane k: Q_k = prod_{j in block, j != k} (x - r_j) (IB coefficients, degree = real
-// leaves - 1), q[block][i][k] = w_k Q_k[i].  Lane 0 also writes the block's N = Q_0 (x - r_0) as a full coefficient list (degree
+// leaves - 1), q[block][i][k] = Q_k[i] (k_interp_scale_q multiplies by w_k once the weights exist).  Lane 0 also writes the block's N = Q_0 (x - r_0) as a full coefficient list (degree
 // d = real leaves of the block) into node[block * 2 IB ..] (zero padded to 2 IB: the layout of level 0).
-__global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __restrict__ r, const Fr* __restrict__ w, size_t n, Fr* __restrict__ qmat, Fr* __restrict__ node) {
+__global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __restrict__ r, size_t n, Fr* __restrict__ qmat, Fr* __restrict__ node) {
     __shared__ Fr rs[IB];
     const size_t blk = blockIdx.x, base = blk * IB;
     const int k = threadIdx.x;
@@ -62,9 +124,8 @@ __global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __rest
         c[0] = Fr::zero() - rj * c[0];
         ++deg;
     }
-    const Fr wk = k < real ? w[base + k] : Fr::zero();
     Fr* q = qmat + blk * (size_t)IB * IB;
-    for (int i = 0; i < IB; ++i) q[(size_t)i * IB + k] = (k < real && i <= deg) ? wk * c[i] : Fr::zero();
+    for (int i = 0; i < IB; ++i) q[(size_t)i * IB + k] = (k < real && i <= deg) ? c[i] : Fr::zero();
     if (k == 0) {
         Fr* out = node + blk * (size_t)(2 * IB);
         if (real == 0) {
@@ -82,12 +143,6 @@ __global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __rest
             for (int i = deg + 2; i < 2 * IB; ++i) out[i] = Fr::zero();
         }
     }
-}
-
-// number of real leaves under node `idx` of a level whose nodes cover `size` leaves each
-__device__ __host__ inline size_t interp_degree(size_t idx, size_t size, size_t n) {
-    const size_t lo = idx * size;
-    return lo >= n ? 0 : (n - lo < size ? n - lo : size);
 }
 
 // parents of a level from the cyclic products of their children (prod: parents x 2s, the product of two polynomials of degree <= s
@@ -165,12 +220,12 @@ std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, si
     t->roots.alloc(n);
     ZK_HIP(hipMemcpyAsync(t->roots.p, d_roots_mont, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     t->w.alloc(n);
-    hipLaunchKernelGGL(k_interp_nprime, dim3(ceil_div(n, 128)), dim3(128), 0, st, t->roots.p, n, t->w.p, d_flag);
     const size_t blocks = npad / IB;
     t->qmat.alloc(npad * IB);
-    DevBuf<Fr> node(2 * npad), prod(npad);
-    hipLaunchKernelGGL(k_interp_blocks, dim3(blocks), dim3(IB), 0, st, t->roots.p, t->w.p, n, t->qmat.p, node.p);
+    DevBuf<Fr> node(2 * npad), prod(npad), blk_poly(2 * npad);
+    hipLaunchKernelGGL(k_interp_blocks, dim3(blocks), dim3(IB), 0, st, t->roots.p, n, t->qmat.p, node.p);
     ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(blk_poly.p, node.p, 2 * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     // levels: children of s = IB << l leaves, images at size 2s
     unsigned lg = 0;
     while ((1u << lg) < (unsigned)IB) ++lg;
@@ -193,7 +248,34 @@ std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, si
         hipLaunchKernelGGL(k_interp_root, dim3(ceil_div(n + 1, 256)), dim3(256), 0, st, prod.p, npad, n, t->t.p);
         ZK_HIP(hipGetLastError());
     }
-    ZK_HIP(hipStreamSynchronize(st));   // node / prod go out of scope
+    // ---- the weights 1 / N'(r_k): scaled remainder tree, top down over the images stored above ----
+    {
+        unsigned lc = 1;
+        while (((size_t)1 << lc) < 2 * n) ++lc;
+        const size_t nc = (size_t)1 << lc;
+        DevBuf<Fr> one(1), ginv, series(nc);
+        const Fr o = Fr::one();
+        ZK_HIP(hipMemcpyAsync(one.p, &o, sizeof(Fr), hipMemcpyHostToDevice, st));
+        poly_rev_inverse_ntt(ctx, t->t.p, n, one.p, n, lc, ginv);                     // 1 / rev(N) mod x^n
+        hipLaunchKernelGGL(k_interp_rev_derivative, dim3(ceil_div(nc, 256)), dim3(256), 0, st, t->t.p, n, nc, series.p);
+        ntt_dif(ctx, series.p, lc, false, false);
+        fr_pointwise_mul(ctx, series.p, ginv.p, series.p, nc);
+        ntt_dit(ctx, series.p, lc, true, true, nullptr);                              // c_1 .. c_n = its first n coefficients
+        Fr* g = prod.p;                                                               // npad: G of the current level's nodes
+        hipLaunchKernelGGL(k_interp_root_series, dim3(ceil_div(npad, 256)), dim3(256), 0, st, series.p, n, npad, g);
+        for (unsigned l = L - lg; l-- > 0;) {
+            const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
+            ntt_dif(ctx, g, lg + l + 1, false, false, parents);                        // images of the parents' G (size 2s each)
+            hipLaunchKernelGGL(k_interp_down_mul, dim3(ceil_div(children * s2, 256)), dim3(256), 0, st, g, t->nev[l].p, s2, children, node.p);
+            ntt_dit(ctx, node.p, lg + l + 1, true, true, nullptr, children);
+            hipLaunchKernelGGL(k_interp_down_take, dim3(ceil_div(children * s, 256)), dim3(256), 0, st, node.p, s, children, n, g);
+            ZK_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_interp_weights, dim3(blocks), dim3(IB), 0, st, g, blk_poly.p, t->roots.p, n, t->w.p, d_flag);
+        hipLaunchKernelGGL(k_interp_scale_q, dim3(ceil_div(npad * IB, 256)), dim3(256), 0, st, t->qmat.p, t->w.p, n, npad);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));   // the temporaries go out of scope
+    }
     return t;
 }
 

@@ -48,6 +48,8 @@ void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);
 // out[i] = base^i * scale (natural order powers)
 void fr_powers(zk_ctx*, Fr base, Fr scale, Fr* out, size_t n);
 void ntt_host(zk_ctx*, uint64_t* data, unsigned log_n, int inverse, int coset);
+// qap.hip: NTT image (DIF order, size 2^log_size) of 1 / rev(t) mod x^K, t of degree d (d_cinv: 1 / its leading coefficient); synchronises
+void poly_rev_inverse_ntt(zk_ctx*, const Fr* t, size_t d, const Fr* d_cinv, size_t K, unsigned log_size, DevBuf<Fr>& out);
 void lazy29_batch(zk_ctx*, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n, uint64_t* out, int32_t* raw_out);
 
 // ---- msm.hip ----

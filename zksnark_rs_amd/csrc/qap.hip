@@ -276,18 +276,19 @@ static void reverse_prefix(zk_ctx* ctx, const Fr* src, size_t src_len, size_t co
     ZK_HIP(hipGetLastError());
 }
 
-void qap_ensure_tinv(zk_ctx* ctx, zk_qap& q, size_t K, unsigned log_size) {
-    if (q.t_rinv_ntt.p && q.tinv_log == log_size) return;
-    const size_t d = q.t_degree, size = (size_t)1 << log_size;
+// out = the NTT image (DIF order, size 2^log_size) of 1 / rev(t) mod x^K for a polynomial t of degree d (d + 1 coefficients, Montgomery;
+// d_cinv: 1 / its leading coefficient)
+void poly_rev_inverse_ntt(zk_ctx* ctx, const Fr* t, size_t d, const Fr* d_cinv, size_t K, unsigned log_size, DevBuf<Fr>& out) {
+    const size_t size = (size_t)1 << log_size;
     hipStream_t st = ctx->stream;
     // rt = rev(t): rt[i] = t[d - i], i <= d
     size_t bufsz = size;
     while (bufsz < 2 * K) bufsz <<= 1;
     DevBuf<Fr> rt(d + 1), g(bufsz), f(bufsz), e(bufsz), g2(bufsz);
-    reverse_prefix(ctx, q.dt.p, d + 1, d + 1, rt.p, d + 1);
+    reverse_prefix(ctx, t, d + 1, d + 1, rt.p, d + 1);
     // g0 = 1 / rt[0] = 1 / leading coefficient of t
     ZK_HIP(hipMemsetAsync(g.p, 0, bufsz * sizeof(Fr), st));
-    ZK_HIP(hipMemcpyAsync(g.p, q.t_cinv.p, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipMemcpyAsync(g.p, d_cinv, sizeof(Fr), hipMemcpyDeviceToDevice, st));
     for (size_t have = 1; have < K;) {
         const size_t want = std::min(2 * have, K);
         unsigned lg = 1;
@@ -308,12 +309,17 @@ void qap_ensure_tinv(zk_ctx* ctx, zk_qap& q, size_t K, unsigned log_size) {
         ZK_HIP(hipMemcpyAsync(g.p, f.p, want * sizeof(Fr), hipMemcpyDeviceToDevice, st));
         have = want;
     }
-    // NTT image of g mod x^K at the size the per-proof product uses
-    q.t_rinv_ntt.alloc(size);
-    ZK_HIP(hipMemsetAsync(q.t_rinv_ntt.p, 0, size * sizeof(Fr), st));
-    ZK_HIP(hipMemcpyAsync(q.t_rinv_ntt.p, g.p, K * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    ntt_dif(ctx, q.t_rinv_ntt.p, log_size, false, false);
+    // NTT image of g mod x^K at the size the product uses
+    out.alloc(size);
+    ZK_HIP(hipMemsetAsync(out.p, 0, size * sizeof(Fr), st));
+    ZK_HIP(hipMemcpyAsync(out.p, g.p, K * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dif(ctx, out.p, log_size, false, false);
     ZK_HIP(hipStreamSynchronize(st));
+}
+
+void qap_ensure_tinv(zk_ctx* ctx, zk_qap& q, size_t K, unsigned log_size) {
+    if (q.t_rinv_ntt.p && q.tinv_log == log_size) return;
+    poly_rev_inverse_ntt(ctx, q.dt.p, q.t_degree, q.t_cinv.p, K, log_size, q.t_rinv_ntt);
     q.tinv_log = log_size;
 }
 
