@@ -262,6 +262,29 @@ def test_gpu_uploaded_crs_change_of_basis_at_size(ctx, orc, tmp_path, n):
 
 
 @pytest.mark.gpu
+def test_gpu_uploaded_crs_beyond_the_change_of_basis(ctx, orc):
+    """Above 2^16 + 2^10 gates the O(n^2) change of basis is not attempted: an integer-roots QAP over a CRS that carries only the
+    reference's arrays proves through the sub-product tree of the roots 1..n instead (csrc/arbroots.hip) -- the same bytes, which
+    the closed form pins, from the uploaded CRS and again from the CRS zk_setup made (evaluation basis)."""
+    n = (1 << 17) + 5
+    m, l, u, v, w = chain_rows_integers(n)
+    rng = SplitMix64(9650)
+    x, avals = rng.fr(), [rng.fr() for _ in range(n)]
+    weights = chain_weights_integers(n, x, avals)
+    desc = ctx.sparse_desc(0, m, l, u, v, w)
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    up = ctx.crs_upload(n, m, l, ctx.crs_download(crs))
+    r, s = rng.fr(), rng.fr()
+    want = orc.trapdoor_proof_integers(desc, n, td, weights, r, s)
+    assert ctx.prove(up, qap, weights, r, s) == want
+    assert ctx.prove(crs, qap, weights, r, s) == want
+    bad = weights.copy(); bad[n // 3, 0] ^= np.uint64(1)
+    assert ctx.prove(up, qap, bad, r, s) == orc.trapdoor_proof_integers(desc, n, td, bad, r, s)
+
+
+@pytest.mark.gpu
 def test_gpu_integer_roots_limits_and_errors(ctx, tmp_path):
     n = 12
     circ = Circuit(chain_program(n))

@@ -67,6 +67,27 @@ zk_qap* qap_upload_sparse_roots(zk_ctx* ctx, const zk_qap_sparse_desc& desc, con
     return guard.release();
 }
 
+// An integer-roots QAP (aproots.hip) whose CRS carries only the reference's powers and is too large for the change of basis
+// (basis.hip: O(n^2) group operations) proves in THIS form instead: the roots 1..n as caller data.  Built on first use.
+__global__ void k_arb_integers(size_t n, Fr* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Fr v = Fr::zero();
+    v.l[0] = (uint32_t)(k + 1); v.l[1] = (uint32_t)((uint64_t)(k + 1) >> 32);
+    out[k] = Fr::from_canonical(v);
+}
+void arb_attach_integer_roots(zk_ctx* ctx, zk_qap& q) {
+    if (q.arb) return;
+    ZK_REQUIRE(q.n <= ((size_t)1 << (NTT_MAX_LOG - 2)), ZK_ERR_UNSUPPORTED,
+               "prove: an integer-roots QAP of more than 2^22 gates needs the CRS zk_setup made for it");
+    DevBuf<Fr> r(q.n);
+    DevBuf<int> flag(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_arb_integers, dim3(ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, q.n, r.p);
+    ZK_HIP(hipGetLastError());
+    arb_build_tables(ctx, q, r.p, flag.p);
+}
+
 void arb_download_roots(zk_ctx* ctx, const zk_qap& q, uint64_t* out) {
     DevBuf<Fr> tmp(q.n);
     fr_from_mont(ctx, q.arb->tree->roots.p, tmp.p, q.n);

@@ -19,6 +19,7 @@
 namespace zk {
 
 constexpr size_t BASIS_MAX_N = ((size_t)1 << 16) + 1024;
+size_t basis_max_n() { return BASIS_MAX_N; }
 constexpr int BASIS_GROUPS = 64;          // nodes per grouped MSM (the level-1 counters of 64 groups x 2^8 bins fill 64 KiB of LDS)
 
 __device__ __forceinline__ Fr fr_from_u64_dev(uint64_t v) {   // Montgomery form of a small integer

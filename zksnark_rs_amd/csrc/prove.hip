@@ -372,12 +372,20 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // one-off table construction happens before anything of this proof is enqueued
     // an integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1): change of basis, once per CRS
     ZK_REQUIRE(!(q.roots == 2 && xout), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange takes the roots-of-unity and integer-roots forms (an arbitrary-roots QAP proves on one GPU, or window-sharded)");
-    if (!xout && !q.dense && q.roots == 1 && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
+    // The form this proof takes: 0 roots of unity, 1 integer roots in the evaluation basis, 2 coefficients by the sub-product tree
+    // (arbroots.hip), 3 dense.  An integer-roots QAP over a CRS that carries only the powers gets the Lagrange-basis points by the
+    // change of basis (once per CRS) up to basis_max_n() gates; beyond, it proves in form 2 with the roots 1..n as caller data --
+    // the same bytes at half the rate, from ANY CRS.
+    int form = q.dense ? 3 : q.roots;
+    if (!xout && form == 1 && !crs.ap) {
+        if (q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
+        else { arb_attach_integer_roots(ctx, const_cast<zk_qap&>(q)); form = 2; }
+    }
     if (xout) {}   // scalars only: no inner product, no table (the ranks of a scalar exchange build only their own slices)
-    else if (q.dense || q.roots == 2) crs_ensure_tables(ctx, crs, false, 0);   // coefficient forms: the reference's [x^i], natural order
-    else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
+    else if (form >= 2) crs_ensure_tables(ctx, crs, false, 0);   // coefficient forms: the reference's [x^i], natural order
+    else if (form == 1) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
-    if ((q.dense || q.roots == 2) && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
+    if (form >= 2 && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
         unsigned lc0 = 1;
         while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
         qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
@@ -446,7 +454,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             for (auto& d : deferred)
                 if (d.first == order[pos]) { d.second(prev); prev = d.first; }
     };
-    if (!q.dense && q.roots == 1) {
+    if (form == 1) {
         // integer roots 1..n (aproots.hip): everything stays in the evaluation basis; bases = Lagrange-basis points
         const size_t M = (size_t)1 << q.ap->log_m;
         S.uv.ensure(2 * n); S.xy.ensure(3 * M);
@@ -477,7 +485,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
         ap_quotient_values(ctx, q, ue, ve, S.xy.p, hb_can);              // h on S = {n+1 .. 2n-1}
         launch(4, 2, crs.t_hb1, hb_can, 2 * n - 1, &ms->hb);
-    } else if (!q.dense && q.roots == 0) {
+    } else if (form == 0) {
         auto tabs = ntt_get_tables(ctx, q.log_n);
         ntt_ensure_coset_tables(ctx, *tabs);
         S.uv.ensure(2 * n); S.uvg.ensure(2 * n); S.xy.ensure(2 * n);
