@@ -457,7 +457,8 @@ impl GpuProver {
 
     /// The same circuits with a CRS the reference's own `setup` made (groth16::prove takes any (&SigmaG1, &SigmaG2), mod.rs:213-217):
     /// the library derives the Lagrange-basis points it multiplies with from [x^i]_1, [x^i]_2, [x^i t(x)/delta]_1 at the first proof
-    /// (public linear combinations; once per CRS, O(n^2): n <= 2^16 + 2^10 gates).
+    /// (public linear combinations; once per CRS, O(n^2): n <= 2^16 + 2^10 gates); above that size it proves the same bytes
+    /// through the sub-product tree of the roots 1..n.
     pub fn with_sigma_integers<R: RootRepresentation<FrLocal>>(rr: &R, sigma: (&SigmaG1<G1Local>, &SigmaG2<G2Local>)) -> Self {
         let mut index: HashMap<[u64; 4], u32> = HashMap::new();
         let mut k = FrLocal::from(1usize);
