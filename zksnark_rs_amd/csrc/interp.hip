@@ -208,6 +208,23 @@ __global__ void k_interp_combine(const Fr* __restrict__ tmp, const Fr* __restric
     out[(size_t)blockIdx.y * parents * s2 + g] = t[l] * nev[r] + t[r] * nev[l];
 }
 
+// The image (DIF order, 4s points) of a parent's 2s coefficients zero padded to 4s is [its 2s-point image | the 2s-point image of the
+// coefficients times w_4s^j]: the first stage of the larger transform only copies and twists.  The left half is what the combination just
+// produced; so a level costs one inverse and one forward transform of 2s points per node instead of one inverse of 2s and one forward of 4s.
+// next[v][p][half 2s + j] = src[v][p][j]
+__global__ void k_interp_half(const Fr* __restrict__ src, size_t s2, size_t total, int half, Fr* __restrict__ next) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t p = g / s2, j = g - p * s2;
+    next[p * 2 * s2 + (size_t)half * s2 + j] = src[g];
+}
+// coefficients times w_4s^j, w_4s^j = tw[j npad / 2s]  (tw[i] = w_(2 npad)^i)
+__global__ void k_interp_twist(Fr* __restrict__ c, const Fr* __restrict__ tw, size_t s2, size_t step, size_t total) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    c[g] = c[g] * tw[(g & (s2 - 1)) * step];
+}
+
 std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, size_t n, int* d_flag) {
     ZK_REQUIRE(n >= 1 && n <= ((size_t)1 << (NTT_MAX_LOG - 1)), ZK_ERR_SIZE, "interpolation: n must be in [1, 2^23]");
     auto t = std::make_shared<InterpTree>();
@@ -220,6 +237,8 @@ std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, si
     t->roots.alloc(n);
     ZK_HIP(hipMemcpyAsync(t->roots.p, d_roots_mont, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     t->w.alloc(n);
+    t->tw.alloc(npad);
+    fr_powers(ctx, host_root_of_unity(L + 1), Fr::one(), t->tw.p, npad);   // w_(2 npad)^i (interp_run: the twist of the doubled images)
     const size_t blocks = npad / IB;
     t->qmat.alloc(npad * IB);
     DevBuf<Fr> node(2 * npad), prod(npad), blk_poly(2 * npad);
@@ -288,16 +307,37 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
     hipLaunchKernelGGL(k_interp_bottom, dim3(ceil_div(npad, 256), count), dim3(256), 0, st, d_values, vstride, t.qmat.p, n, npad, cur);
     unsigned lg = 0;
     while ((1u << lg) < (unsigned)IB) ++lg;
-    for (unsigned l = 0; lg + l < t.log_npad; ++l) {
-        const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
-        hipLaunchKernelGGL(k_interp_pad, dim3(ceil_div(2 * npad * count, 256)), dim3(256), 0, st, cur, s, 2 * npad * count, tmp);
-        ntt_dif(ctx, tmp, lg + l + 1, false, false, children * count);
-        Fr* nxt = cur == d_out ? alt : d_out;
-        hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, nxt);
-        ntt_dit(ctx, nxt, lg + l + 1, true, true, nullptr, parents * count);
-        cur = nxt;
+    const unsigned levels = t.log_npad - lg;
+    if (npad * count < ((size_t)1 << 20)) {
+        // small trees: three more launches per level cost more than a third of its transforms saves -- zero pad and transform at 4s
+        for (unsigned l = 0; l < levels; ++l) {
+            const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
+            hipLaunchKernelGGL(k_interp_pad, dim3(ceil_div(2 * npad * count, 256)), dim3(256), 0, st, cur, s, 2 * npad * count, tmp);
+            ntt_dif(ctx, tmp, lg + l + 1, false, false, children * count);
+            Fr* nxt = cur == d_out ? alt : d_out;
+            hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, nxt);
+            ntt_dit(ctx, nxt, lg + l + 1, true, true, nullptr, parents * count);
+            cur = nxt;
+        }
+        if (cur != d_out) ZK_HIP(hipMemcpyAsync(d_out, cur, count * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        ZK_HIP(hipGetLastError());
+        return;
     }
-    if (cur != d_out) ZK_HIP(hipMemcpyAsync(d_out, cur, count * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    if (levels) {   // images of the bottom blocks at twice their size
+        hipLaunchKernelGGL(k_interp_pad, dim3(ceil_div(2 * npad * count, 256)), dim3(256), 0, st, cur, (size_t)IB, 2 * npad * count, tmp);
+        ntt_dif(ctx, tmp, lg + 1, false, false, (npad / IB) * count);
+    }
+    for (unsigned l = 0; l < levels; ++l) {
+        const size_t s2 = (size_t)IB << (l + 1), parents = npad / s2, total = npad * count;
+        hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, alt);   // parents' images, 2s points
+        if (l + 1 < levels) hipLaunchKernelGGL(k_interp_half, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, s2, total, 0, tmp);
+        ntt_dit(ctx, alt, lg + l + 1, true, true, nullptr, parents * count);          // their coefficients
+        if (l + 1 == levels) break;
+        hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tw.p, s2, npad / s2, total);
+        ntt_dif(ctx, alt, lg + l + 1, false, false, parents * count);
+        hipLaunchKernelGGL(k_interp_half, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, s2, total, 1, tmp);
+    }
+    if (levels) ZK_HIP(hipMemcpyAsync(d_out, alt, count * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ZK_HIP(hipGetLastError());
 }
 
