@@ -365,7 +365,7 @@ class Context:
         self._check(self.lib.zk_qap_dims(p, C.byref(n), C.byref(m), C.byref(l), C.byref(dense)))
         q.n, q.m, q.input, q.dense = n.value, m.value, l.value, bool(dense.value)
         kind = self.lib.zk_qap_kind(p)
-        q.roots = "integers" if kind == 2 else ("unity" if kind == 0 else None)
+        q.roots = {0: "unity", 2: "integers", 3: "arbitrary"}.get(kind)
         if kind == 0:
             q.log_n = q.n.bit_length() - 1      # roots of unity: n = 2^log_n
         return q
