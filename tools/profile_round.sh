@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): the bench lines, kernel-trace statistics, the PMC passes (traffic at 2^20 and 2^16, the counters
+# Runs on the GPU box (through gpurun; build tools/_bin/ubench_assemble first: see tools/ubench_assemble.hip): the bench lines, kernel-trace statistics, the PMC passes (traffic at 2^20 and 2^16, the counters
 # of the accumulation, the VALU budget of a proof) and the timelines of the bench command.  Outputs land in gpurun_out/prof/; copy
 # the summaries into profiles/ as rN_*.  The serialized legs need the measurement build (make -C zksnark_rs_amd/csrc measure).
 set -u
@@ -48,6 +48,14 @@ find $OUT/prof_stats_ser -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats
 python tools/trace_csv.py "$(find $OUT/trace -name '*kernel_trace.csv' | head -1)" 8 10 > $OUT/timeline_pipelined_2p20.txt 2>&1
 python tools/trace_one_proof.py "$(find $OUT/trace16 -name '*kernel_trace.csv' | head -1)" > $OUT/timeline_lone_2p16.txt 2>&1
 python tools/trace_kernels.py "$(find $OUT/prof_stats_ser -name '*kernel_trace.csv' | head -1)" > $OUT/kernels_serialized_by_grid.txt 2>&1
+# lone-proof latency split (host enqueue / wait), the closing kernel's parts, once-per-root-set and once-per-CRS costs, the multi-GPU emulation
+{
+  for n in 16 14 12 4 20; do python tools/lone_breakdown.py --log-n $n; done
+  [ -x tools/_bin/ubench_assemble ] && timeout 60 tools/_bin/ubench_assemble
+  python tools/time_root_tables.py 16 18 20 22
+  python tools/time_change_of_basis.py
+} > $OUT/lone.txt 2>/dev/null
+for w in 2 4 8; do python bench.py --emulate-world $w --steps 20 --warmup 4 2>/dev/null | tail -1; done > $OUT/emul.txt
 # the raw per-dispatch traces are large; keep only the summaries
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_acc $OUT/pmc_acc16 $OUT/prof_stats_ser $OUT/prof_stats $OUT/trace $OUT/trace16
 ls -la $OUT
