@@ -3,8 +3,8 @@
 //
 // QAP::from (/root/reference/src/groth16/fr.rs:140-173) interpolates every wire polynomial through the roots of the
 // RootRepresentation (circuit/mod.rs:201-214: `roots()` is caller data) with Lagrange sums (coefficient_poly.rs:159-200, O(n^2) per
-// polynomial).  The prover only ever needs the three combinations U = sum a_i u_i, V, and the interpolant E of the products U_k V_k
-// (aproots.hip: W + rem = E), so it interpolates THOSE, per proof, from their values on the roots (the SpMV output):
+// polynomial).  The prover only ever needs the two combinations U = sum a_i u_i and V (arbroots.hip: the quotient of U V alone by t is
+// h), so it interpolates THOSE, per proof, from their values on the roots (the SpMV output):
 //     F(x) = sum_k a_k N(x) / (x - r_k),   a_k = F_k / N'(r_k),   N(x) = prod_k (x - r_k)
 // by the sub-product tree: a node that covers the leaves [lo, hi) holds N_node = prod (x - r_k) and P_node = sum a_k N_node / (x - r_k);
 //     P_parent = P_left N_right + P_right N_left,   N_parent = N_left N_right.
