@@ -284,3 +284,28 @@ def test_arbitrary_roots_window_and_point_sharded(ctx):
                 assert ctx.prove_combine(crs, buf.data_ptr(), world, r, s) == want, (by_points, world)
     finally:
         ctx.set_option("msm_shard_points", 0)
+
+
+def test_arbitrary_roots_refused_by_the_scalar_exchange(ctx):
+    """zk_mgpu_* (scalar exchange) takes the roots-of-unity and integer-roots forms: an arbitrary-roots QAP is refused with
+    ZK_ERR_UNSUPPORTED at the first push, and the prover object says so instead of hanging its peers."""
+    import torch
+    from zksnark_rs_amd.distributed import Comm, MgpuProver
+    rng = SplitMix64(8300)
+    n, m, l = 100, 220, 2
+    roots = ints_to_limbs(distinct_roots(rng, n)).reshape(n, 4)
+    u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
+    qap = ctx.qap_sparse_roots(roots, m, l, u, v, w)
+    crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
+    wts = ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)])
+    dw = torch.from_numpy(wts.view(np.int64)).cuda()
+    comm = Comm(ctx, 0, 1)
+    try:
+        with pytest.raises(zk.ZkError) as e:
+            mp = MgpuProver(ctx, comm, crs, qap)
+            mp.push(dw.data_ptr(), m, 5, 7)
+            mp.pop()
+        assert e.value.status == zk._lib.ZK_ERR_UNSUPPORTED
+    finally:
+        comm.close()
+    assert ctx.prove(crs, qap, wts, 5, 7)      # the context is still usable

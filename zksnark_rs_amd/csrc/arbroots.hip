@@ -12,8 +12,8 @@
 //     W and E have degree < n, so U V = h t + E and the quotient of U V ALONE by t is h, for EVERY witness (aproots.hip has the same
 //     argument).  W is never evaluated; the product and the division by t (monic, degree n; Newton's iteration on rev(t) once per QAP,
 //     long division below 512 quotient coefficients) are the coefficient-form tail the dense form already has (prove.hip, qap.hip).
-// Same group elements as the reference's proof, hence the same 259 bytes.  Per root set, once: the tree (interp.hip, O(n^2) multiplications
-// for N'(r_k)), t = prod (x - r_k) and the power-series inverse of rev(t).
+// Same group elements as the reference's proof, hence the same 259 bytes.  Per root set, once, O(n log^2 n) too: the tree with its
+// weights 1 / N'(r_k) (interp.hip), t = prod (x - r_k) and the power-series inverse of rev(t).
 #include <algorithm>
 #include <vector>
 #include "pipeline.hpp"
