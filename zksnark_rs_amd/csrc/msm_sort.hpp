@@ -242,8 +242,22 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
     const int per = (subs + SORT2_THREADS - 1) / SORT2_THREADS;
     const int lo = min((int)threadIdx.x * per, subs), hi = min(lo + per, subs);
     uint32_t sum = 0;
-    for (int b = lo; b < hi; ++b)
-        for (int p = 0; p < parts; ++p) sum += rows[(size_t)p * subs + b];
+    // 2^11 sub-buckets: a lane owns 8 consecutive counters of every part -- two 16-byte accesses, coalesced over the workgroup (read
+    // counter by counter the same loop was 72 dependent 4-byte loads at a 32-byte stride per lane and pass: 80 us per launch)
+    const bool vec = per == 8 && hi - lo == 8;
+    if (vec) {
+        uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
+        for (int p = 0; p < parts; ++p) {
+            const uint4* r4 = reinterpret_cast<const uint4*>(rows + (size_t)p * subs + lo);
+            const uint4 a = r4[0], b = r4[1];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        sum = s0.x + s0.y + s0.z + s0.w + s1.x + s1.y + s1.z + s1.w;
+    } else {
+        for (int b = lo; b < hi; ++b)
+            for (int p = 0; p < parts; ++p) sum += rows[(size_t)p * subs + b];
+    }
     part_sum[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < SORT2_THREADS; d <<= 1) {
@@ -253,6 +267,30 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
         __syncthreads();
     }
     uint32_t run = bin_start[bin] + (threadIdx.x ? part_sum[threadIdx.x - 1] : 0);
+    if (vec) {
+        // per sub-bucket b the positions run over the parts: first pass the column totals (in registers), then the offsets
+        uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = 0; p < parts; ++p) {
+            const uint4* r4 = reinterpret_cast<const uint4*>(rows + (size_t)p * subs + lo);
+            const uint4 a = r4[0], b = r4[1];
+            col[0] += a.x; col[1] += a.y; col[2] += a.z; col[3] += a.w; col[4] += b.x; col[5] += b.y; col[6] += b.z; col[7] += b.w;
+        }
+        uint32_t at[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { at[i] = run; run += col[i]; }
+        uint4* st4 = reinterpret_cast<uint4*>(start + (size_t)bin * subs + lo);
+        st4[0] = make_uint4(at[0], at[1], at[2], at[3]);
+        st4[1] = make_uint4(at[4], at[5], at[6], at[7]);
+        for (int p = 0; p < parts; ++p) {
+            uint4* r4 = reinterpret_cast<uint4*>(rows + (size_t)p * subs + lo);
+            const uint4 a = r4[0], b = r4[1];
+            r4[0] = make_uint4(at[0], at[1], at[2], at[3]);
+            r4[1] = make_uint4(at[4], at[5], at[6], at[7]);
+            at[0] += a.x; at[1] += a.y; at[2] += a.z; at[3] += a.w; at[4] += b.x; at[5] += b.y; at[6] += b.z; at[7] += b.w;
+        }
+        if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = bin_start[bins];
+        return;
+    }
     for (int b = lo; b < hi; ++b) {
         start[(size_t)bin * subs + b] = run;
         for (int p = 0; p < parts; ++p) {
