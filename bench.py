@@ -339,6 +339,9 @@ def main():
         else:                              # the C pipeline (zk_mgpu_push / zk_mgpu_pop) over a loop-back transport
             from zksnark_rs_amd.distributed import Comm, MgpuProver, loopback_comm
             if args.transport == "zk":     # the library's own loop-back (copies on the collectives' stream): stream-ordered hand-overs
+                if ctx.get_option("measure_build") != 1:
+                    raise SystemExit("--emulate-world --transport zk uses ZK_COMM_LOOPBACK, a measurement switch: load the ZK_MEASURE build "
+                                     "(ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so) or pass --transport zk-gloo")
                 os.environ["ZK_COMM_LOOPBACK"] = "1"
                 lb = Comm(ctx, 0, W, bytes(zk.COMM_ID_BYTES) if hasattr(zk, "COMM_ID_BYTES") else bytes(128))
             else:                          # zk-gloo: a caller's transport (Python callbacks), hand-overs through the host

@@ -241,9 +241,15 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
         // only way to execute this file's RCCL calls on a one-GPU box (tests/test_gpu_bench.py)
         const char* force = std::getenv("ZK_COMM_FORCE_RCCL");
         // ZK_COMM_LOOPBACK=1 (bench.py --emulate-world): rank 0 of `world` ranks with copies in place of the collectives -- one rank's
-        // work of a `world`-GPU run through the same code path (stream-ordered hand-overs included); the proofs are NOT valid
+        // work of a `world`-GPU run through the same code path (stream-ordered hand-overs included).  The sums it forms are NOT
+        // proofs, so the switch exists in the measurement build only (ZK_MEASURE; zk_mgpu_pop then hands out zero bytes); the
+        // product library refuses the variable instead of ignoring it -- a stray setting must not change what a prover returns.
         const char* loop = std::getenv("ZK_COMM_LOOPBACK");
-        if (world > 1 && loop && loop[0] == '1' && rank == 0) {
+        const bool want_loop = world > 1 && loop && loop[0] == '1';
+#ifndef ZK_MEASURE
+        ZK_REQUIRE(!want_loop, ZK_ERR_UNSUPPORTED, "zk_comm_init: ZK_COMM_LOOPBACK is a measurement switch (libzkgpu_measure.so); unset it");
+#endif
+        if (want_loop && rank == 0) {
             c->loopback = true;
         } else if (world > 1 || (force && force[0] == '1' && id)) {
             ZK_HIP(hipSetDevice(ctx->device));
@@ -426,8 +432,11 @@ static int mgpu_push(zk_mgpu* g, const void* d_weights, size_t m, const uint64_t
             const int st = g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars);
             ctx->submit_wait_evt = nullptr;
             be_check(g, st, "scalars_submit");
-            ZK_HIP(hipEventRecord(g->ev_scal[e], prove_ticket_stream(ctx, R.t_scalars)));
+            // the range flag's copy to pinned memory is enqueued by prove_release on the ticket's stream: the event is recorded BEHIND
+            // it, so that whatever follows ev_scal (the exchange, the inner products, the pop's synchronisation) also follows the copy
+            hipStream_t fin = prove_ticket_stream(ctx, R.t_scalars);
             prove_release(ctx, R.t_scalars, &g->h_flag[e]);
+            ZK_HIP(hipEventRecord(g->ev_scal[e], fin));
             R.t_scalars = -1;
         } else {
             be_check(g, g->be.scalars_submit(g->be.user, d_weights, m, r, s, g->comm->world, g->send[k & 1], &R.t_scalars), "scalars_submit");
@@ -472,7 +481,8 @@ int zk_mgpu_pop(zk_mgpu* g, uint8_t proof_out[ZK_PROOF_BYTES]) {
             g->first = k + 1;
             g->gpu->ctx->resolve_profile(-2);
             ZK_REQUIRE(!g->h_flag[e], ZK_ERR_RANGE, "prove: witness element >= r");
-            std::memcpy(proof_out, g->h_proof, ZK_PROOF_BYTES);
+            if (c->loopback) std::memset(proof_out, 0, ZK_PROOF_BYTES);   // timing run: what was assembled is not a proof
+            else std::memcpy(proof_out, g->h_proof, ZK_PROOF_BYTES);
             return;
         }
         be_check(g, g->be.wait(g->be.user, R.t_msm), "wait (inner products)");

@@ -28,7 +28,22 @@
 #define ZK_MONT_CHAINS 2
 #endif
 
+// Hand-scheduled multipliers (mont_asm.inc, generated and checked by tools/gen_mont_asm.py): device code only; the C++ forms
+// below stay the definition (host code, -DZK_MONT_ASM=0 builds for A/B) and produce the same limbs.
+#ifndef ZK_MONT_ASM
+#define ZK_MONT_ASM 1
+#endif
+#if ZK_MONT_ASM && defined(__HIP_DEVICE_COMPILE__)
+#define ZK_MONT_ASM_ON 1
+#else
+#define ZK_MONT_ASM_ON 0
+#endif
+
 namespace zk {
+
+#if ZK_MONT_ASM_ON
+#include "mont_asm.inc"
+#endif
 
 template <class PR>
 struct FpR {
@@ -79,6 +94,11 @@ struct FpR {
     // a*b*2^-261 mod p in normal form.  Requires |a limbs| <= 2^30, |b limbs| < 2^29 (or vice versa).
     template <bool SQR>
     ZK_HD static FpR mont(const FpR& a, const FpR& b) {
+#if ZK_MONT_ASM_ON
+        FpR o;
+        if (SQR) mont_asm_sqr<PR>(o.v, a.v); else mont_asm_mul<PR>(o.v, a.v, b.v);
+        return o;
+#else
         int32_t m[9], a2[9];
         if (SQR) {
 #pragma unroll
@@ -143,12 +163,19 @@ struct FpR {
         r.v[8] = (int32_t)carry;
         ZK_SCHED_FENCE();
         return r;
+#endif
     }
     // (a*b - c*d) * 2^-261 mod p with ONE reduction (243 multiply-adds instead of 324).  Requires
     // |limb| < 2^29 on all four operands (normal forms or differences of two normal forms): a column
     // then holds at most 18 products < 2^58 plus 9 reduction terms < 2^58 plus the carry, < 2^63.
     // Output: normal form, |value| < 2 * (8p)^2 / 2^261 + p < 3p.
     ZK_HD static FpR mont_diff(const FpR& a, const FpR& b, const FpR& c, const FpR& d) {
+#if ZK_MONT_ASM_ON
+        FpR o;
+        const FpR nc = c.neg();
+        mont_asm_sum<PR>(o.v, a.v, b.v, nc.v, d.v);
+        return o;
+#else
         int32_t m[9];
         FpR r;
         int64_t carry = 0;
@@ -176,6 +203,7 @@ struct FpR {
         r.v[8] = (int32_t)carry;
         ZK_SCHED_FENCE();
         return r;
+#endif
     }
     ZK_HD FpR operator*(const FpR& b) const { return mont<false>(*this, b); }
     ZK_HD FpR sqr() const { return mont<true>(*this, *this); }
@@ -250,6 +278,11 @@ struct Fp2R {
     // Columns: 18 products < 2^58 + 9 reduction terms < 2^58 + carry < 2^63.  Output in normal form,
     // |value| < 2 (8p)^2 / 2^261 + p < 2p.
     ZK_HD Fp2R operator*(const Fp2R& o) const {
+#if ZK_MONT_ASM_ON
+        Fp2R w;
+        mont_asm_fp2<PR>(w.c0.v, w.c1.v, c0.v, c1.v, o.c0.v, o.c1.v);
+        return w;
+#else
         typedef FpR<PR> L;
         int32_t m0[9], m1[9], nb1[9];
 #pragma unroll
@@ -290,6 +323,7 @@ struct Fp2R {
         r.c1.v[8] = (int32_t)carry1;
         ZK_SCHED_FENCE();
         return r;
+#endif
     }
     // (a0 + a1)(a0 - a1) + 2 a0 a1 i; the doubled limbs (<= 2^30) sit on one side of the second product
     ZK_HD Fp2R sqr() const {

@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             acc_clear(acc);
         }
     } else {
-#pragma unroll Shape::UNROLL
-        while (k < k1) {
+        // one entry: the next point's gather is issued before the addition.  (Written out instead of #pragma unroll: the unroller
+        // declines loops that contain the inline-asm multipliers of mont_asm.inc.)
+        auto step = [&] {
             if constexpr (Shape::DEAD) {
                 if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
             }
@@ -248,6 +249,11 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             e = e_next;
             e_next = e_next2;
             k = kn;
+        };
+        while (k < k1) {
+            step();
+            if constexpr (Shape::UNROLL >= 2) { if (k >= k1) break; step(); }
+            if constexpr (Shape::UNROLL >= 3) { if (k >= k1) break; step(); }
         }
     }
     img[run.dest].a = acc;

@@ -22,6 +22,7 @@
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
 #include "lazy29.cuh"
+#include <sys/random.h>
 
 namespace zk {
 
@@ -241,7 +242,50 @@ struct ProveSlot {
 };
 struct ProveState {
     static constexpr int SLOTS = ZK_MAX_IN_FLIGHT;
-    std::mt19937_64 rng{std::random_device{}()};   // blinding factors only (AssembleBlind); never anything that reaches the proof bytes
+    // Blinding factors only (AssembleBlind): nothing drawn here reaches the proof bytes, but lambda hides the witness-dependent Z from
+    // the trip count of the closing inversions, so it has to be unpredictable: a ChaCha20 key stream under 256 bits of OS entropy
+    // (getrandom), not a 32-bit-seeded Mersenne twister.
+    struct BlindRng {
+        uint32_t key[8], block[16];
+        uint64_t counter = 0;
+        int used = 16;
+        BlindRng() {
+            size_t got = 0;
+            while (got < sizeof(key)) {
+                const ssize_t r = getrandom(reinterpret_cast<uint8_t*>(key) + got, sizeof(key) - got, 0);
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            if (got < sizeof(key)) {   // no getrandom (very old kernel): every word from the C++ entropy source
+                std::random_device rd;
+                for (uint32_t& w : key) w = rd();
+            }
+        }
+        static uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+        void refill() {
+            uint32_t x[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                              (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+            uint32_t w[16];
+            std::memcpy(w, x, sizeof(w));
+            auto qr = [&](int a, int b, int c, int d) {
+                w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 12);
+                w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 7);
+            };
+            for (int round = 0; round < 10; ++round) {
+                qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+                qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+            }
+            for (int i = 0; i < 16; ++i) block[i] = w[i] + x[i];
+            ++counter;
+            used = 0;
+        }
+        uint64_t operator()() {
+            if (used > 14) refill();
+            const uint64_t v = (uint64_t)block[used] | ((uint64_t)block[used + 1] << 32);
+            used += 2;
+            return v;
+        }
+    } rng;
     AssembleBlind draw_blind() {
         auto fq = [&] {
             Fq x;
