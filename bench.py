@@ -31,31 +31,44 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_instance(zk, ctx, log_n, seed, witness="uniform", roots="unity"):
+WITNESS_SETS = 4   # distinct (witness, r, s) the timed region cycles through (the sort and the bucket occupancy are data-dependent)
+
+
+def build_instance(zk, ctx, log_n, seed, witness="uniform", roots="unity", sets=1):
+    """The metric's circuit with `sets` distinct (witness, r, s).  Set 0 is drawn exactly as in rounds 1-3 (same generator, same
+    order), so its proof -- config.proof_sha -- is comparable across rounds; set j > 0 comes from its own generator."""
     from zksnark_rs_amd.circuits import chain_rows, chain_weights
-    rng = zk.SplitMix64(seed)
     n = 1 << log_n
     m, l, u, v, w = chain_rows(log_n)
-    x = rng.fr()
-    if witness == "boolean":    # inputs a_k in {0, 1}: half of all wires are bits (one very heavy MSM bucket)
-        avals = [rng.next() & 1 for _ in range(n)]
-    elif witness == "small":    # 32-bit inputs
-        avals = [rng.next() & 0xFFFFFFFF for _ in range(n)]
-    else:
-        avals = [rng.fr() for _ in range(n)]
-    weights = chain_weights(log_n, x, avals)
+
+    def draw(rng):
+        x = rng.fr()
+        if witness == "boolean":    # inputs a_k in {0, 1}: half of all wires are bits (one very heavy MSM bucket)
+            avals = [rng.next() & 1 for _ in range(n)]
+        elif witness == "small":    # 32-bit inputs
+            avals = [rng.next() & 0xFFFFFFFF for _ in range(n)]
+        else:
+            avals = [rng.fr() for _ in range(n)]
+        return chain_weights(log_n, x, avals)
+
+    rng = zk.SplitMix64(seed)
+    weights = draw(rng)
     td = zk.ints_to_limbs([rng.fr() for _ in range(5)])
     r, s = rng.fr(), rng.fr()
+    wsets = [dict(weights=weights, r=r, s=s)]
+    for j in range(1, sets):
+        g = zk.SplitMix64(seed + 1000003 * j)
+        wj = draw(g)
+        wsets.append(dict(weights=wj, r=g.fr(), s=g.fr()))
     # the same rows over the roots w^j (the metric's workload) or over ASTParser's roots 1..n (DESIGN 3b)
     if roots == "arbitrary":    # affine images a k + b of the integers, handed over as caller data (DESIGN 3c): treated as arbitrary field elements
-        import numpy as np
         a, b = rng.fr() | 1, rng.fr()
         k = np.arange(1, n + 1, dtype=object)
         qap = ctx.qap_sparse_roots(zk.ints_to_limbs([int(v_) for v_ in (a * k + b) % zk.R_MODULUS]).reshape(n, 4), m, l, u, v, w)
     else:
         qap = ctx.qap_sparse(log_n, m, l, u, v, w) if roots == "unity" else ctx.qap_sparse_integers(n, m, l, u, v, w)
     crs = ctx.setup(qap, td)      # groth16::setup on the GPU, outside the timed region
-    return dict(n=n, m=m, l=l, rows=(u, v, w), qap=qap, crs=crs, weights=weights, td=td, r=r, s=s, log_n=log_n)
+    return dict(n=n, m=m, l=l, rows=(u, v, w), qap=qap, crs=crs, weights=weights, td=td, r=r, s=s, log_n=log_n, sets=wsets)
 
 
 def cpu_baseline(zk, ctx, seed, main_inst, full=False):
@@ -132,16 +145,31 @@ def cpu_baseline(zk, ctx, seed, main_inst, full=False):
 
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
-PMC_FILES = {20: "r3_pmc_traffic.json", 16: "r3_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
-PMC_ACC_FILES = {20: "r3_pmc_acc.json", 16: "r3_pmc_acc_2p16.json"}
+# counter passes of THIS round's build (tools/profile_round.sh); a missing file makes the fields null, nothing is typed in here
+PMC_FILES = {20: "r4_pmc_traffic.json", 16: "r4_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
+PMC_ACC_FILES = {20: "r4_pmc_acc.json", 16: "r4_pmc_acc_2p16.json"}
+UBENCH_FILE = "r2_ubench_valu.txt"   # tools/ubench_valu.hip: sustained issue rates per instruction class, waves per SIMD and chains
 
-# VALU issue ceiling of gfx950 for the two instruction classes of the multiplier, from tools/ubench_valu.hip (>= 5 ms kernels, in-kernel
-# shader / wall clocks, cross-checked with SQ_INSTS_VALU and GRBM_GUI_ACTIVE: profiles/r2_ubench_valu.txt, r2_ubench_valu_pmc.txt):
+# VALU issue ceiling of gfx950 for the two instruction classes of the multiplier:
 #   64-bit / integer-multiply class (v_mad_u64_u32, v_mad_i64_i32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64, carry adds): 4 cycles
-#   per wave-instruction and SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614 G/s (measured 585 at 8 waves/SIMD, 546 at 3, clock 2.36-2.40 GHz);
-#   plain 32-bit class (v_and, v_add_u32, v_mov, shifts): 2 cycles -> 1229 G/s (measured 1062).
+#   per wave-instruction and SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614 G/s; plain 32-bit class (v_and, v_add_u32, v_mov, shifts): 2 cycles.
+# What the hardware SUSTAINS of that (585 / 1062 G/s at 8 waves per SIMD) is read from the micro-benchmark's committed output.
 VALU_PEAK_G = {"slow": 1024 * 2.4 / 4.0, "fast": 1024 * 2.4 / 2.0}
-VALU_MEASURED_G = {"slow": 585.0, "fast": 1062.0}
+
+
+def ubench_sustained():
+    """{"slow": G/s, "fast": G/s} = the best sustained rate of v_mad_u64_u32 / v_add_u32 over the runs of tools/ubench_valu.hip
+    (profiles/r2_ubench_valu.txt: op, chains, waves per SIMD, cycles, MHz, G wave-instructions per second, ms); None if missing."""
+    try:
+        best = {}
+        with open(os.path.join(ROOT, "profiles", UBENCH_FILE)) as f:
+            for line in f:
+                p = line.split()
+                if len(p) >= 6 and not line.startswith("#"):
+                    best[p[0]] = max(best.get(p[0], 0.0), float(p[5]))
+        return {"slow": best["mad_u64_u32"], "fast": best["add_u32"]}
+    except Exception:
+        return None
 
 
 def pmc_acc(name, log_n=20):
@@ -172,15 +200,55 @@ def msm_window(count, opt=0, g2=False):
     return 17 if lg >= 17 else 16 if lg >= 16 else 15 if lg >= 14 else 13 if lg >= 11 else 8
 
 
-def pmc_traffic(name, log_n=20):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this round's build (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs of this same command, tools/pmc_summary.py -> profiles/r2_pmc_traffic.json; FETCH_SIZE corrected
-    as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: null when the file is missing."""
+def pmc_file(log_n):
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILES[log_n])) as f:
-            return json.load(f)["kernels"][PMC_KERNEL[name]]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)
     except Exception:
         return None
+
+
+def pmc_traffic(name, log_n=20):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this round's build (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this same command, tools/pmc_summary.py -> profiles/r4_pmc_traffic.json; FETCH_SIZE corrected
+    as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: null when the file is missing."""
+    d = pmc_file(log_n)
+    try:
+        return d["kernels"][PMC_KERNEL[name]]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
+def pmc_whole_proof(log_n=20):
+    """(HBM bytes per proof summed over every kernel of a proof, commit of the build the passes were taken on) or (None, None)"""
+    d = pmc_file(log_n)
+    if not d or "hbm_bytes_per_proof_corrected" not in d:
+        return None, (d or {}).get("commit")
+    return d["hbm_bytes_per_proof_corrected"], d.get("commit")
+
+
+def bounded(fn, seconds, what, device=None):
+    """fn() in a worker thread, at most `seconds`: a rendezvous, a communicator set-up or a collective that never completes must end
+    in the degraded path, not in a hung job.  The worker is a daemon: if it never returns the process still exits."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if device is not None:       # the current device is per thread
+                import torch
+                torch.cuda.set_device(device)
+            box["v"] = fn()
+        except BaseException as e:   # noqa: BLE001 -- re-raised in the caller
+            box["e"] = e
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        raise TimeoutError("%s did not complete within %d s" % (what, seconds))
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
 
 
 def main():
@@ -227,6 +295,10 @@ def main():
                     help="QAP domain: unity = w^j (the metric's workload); integers = 1..n, what ASTParser gives the same circuit "
                          "(zk_qap_upload_sparse_integers); arbitrary = caller-supplied field elements (zk_qap_upload_sparse_roots: the prover "
                          "interpolates per proof by a sub-product tree).  N = 1, no batches; secondary measurements, no CPU baseline")
+    ap.add_argument("--timeout", type=int, default=180,
+                    help="N > 1: bound (s) of every wait on a peer -- rendezvous, communicator set-up, each collective inside the library, "
+                         "each leg; what does not complete in time degrades to independent provers")
+    ap.add_argument("--sets", type=int, default=WITNESS_SETS, help="distinct (witness, r, s) the timed region cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-times", action="store_true",
                     help="event-time every launch group of a proof, not only the bucket accumulations (kernel_ms_per_proof then lists them "
@@ -273,15 +345,40 @@ def main():
 
     ctx = zk.Context(device)
     comm = None
-    if use_zk and args.transport == "zk":
-        from zksnark_rs_amd.distributed import bootstrap_comm
-        comm = bootstrap_comm(ctx, rank, world)     # RCCL communicator inside libzkgpu.so
-    elif use_zk:
-        from zksnark_rs_amd.distributed import gloo_comm
-        comm = gloo_comm(ctx, dist, rank, world)
-        store_port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+    # Every wait on a peer is bounded (--timeout / ZK_BENCH_TIMEOUT_S): the rendezvous and ncclCommInitRank here, the collectives
+    # inside the library (ZK_COMM_TIMEOUT_MS -> zk_comm timeouts), each leg of the run below.  What does not complete ends in the
+    # `degraded` path (independent provers, said so in the line), never in a hung job.
+    TMO = int(os.environ.get("ZK_BENCH_TIMEOUT_S", str(args.timeout)))
+    os.environ.setdefault("ZK_COMM_TIMEOUT_MS", str(1000 * TMO))
+    boot_err = None
+    store = None
+    if use_zk:
         from datetime import timedelta
-        comm._store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), store_port, world, rank == 0, timeout=timedelta(seconds=300))
+        store_port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+        try:
+            store = bounded(lambda: torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), store_port, world, rank == 0,
+                                                               timeout=timedelta(seconds=TMO)), TMO + 5, "the rendezvous store", device)
+        except Exception as e:   # noqa: BLE001
+            boot_err = "%s: %s" % (type(e).__name__, str(e)[:200])
+    if use_zk and store is not None:
+        try:
+            if args.transport == "zk":       # RCCL communicator inside libzkgpu.so; the id travels through the store
+                from zksnark_rs_amd.distributed import Comm
+
+                def join():
+                    if os.environ.get("ZK_BENCH_TEST_HANG_INIT") and rank == world - 1:
+                        time.sleep(10 * TMO)
+                    if rank == 0:
+                        store.set("zk_comm_id", Comm.unique_id())
+                    return Comm(ctx, rank, world, bytes(store.get("zk_comm_id")))
+                comm = bounded(join, TMO, "zk_comm_init (ncclCommInitRank)", device)
+            else:
+                from zksnark_rs_amd.distributed import gloo_comm
+                comm = gloo_comm(ctx, dist, rank, world)
+            comm._store = store
+        except Exception as e:   # noqa: BLE001
+            boot_err = "%s: %s" % (type(e).__name__, str(e)[:200])
+            comm = None
 
     def barrier():
         if comm is not None:
@@ -308,26 +405,27 @@ def main():
     for kv in args.opt:
         key, val = kv.split("=", 1)
         ctx.set_option(key, int(val))
-    inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness, args.roots)
-    d_w = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
+    single_set = world > 1 and args.transport == "torch"      # the round-1 Python drivers are bound to one witness
+    nsets = 1 if (single_set or args.emulate_world) else max(1, args.sets)
+    inst = build_instance(zk, ctx, args.log_n, args.seed, args.witness, args.roots, nsets)
+    sets = inst["sets"]
+    d_ws = [torch.from_numpy(st["weights"].view(np.int64)).cuda() for st in sets]
+    d_w = d_ws[0]
     m = inst["m"]
     exchange = world > 1 and args.mode == "exchange"
     shard = shard_mode = world > 1 and args.mode == "shard"
     mprover = None
-    if exchange and use_zk:
-        from zksnark_rs_amd.distributed import MgpuProver
-        mprover = MgpuProver(ctx, comm, inst["crs"], inst["qap"])
-    elif exchange:
-        from zksnark_rs_amd.distributed import GpuExchangeProver, prove_exchange_stream
-        xprover = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
-    if shard and use_zk:
-        from zksnark_rs_amd.distributed import prove_sharded_abi
-    elif shard:
-        from zksnark_rs_amd.distributed import GpuProver, prove_sharded, prove_sharded_stream
-        prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
-        bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
+    if world > 1 and not use_zk:
+        from zksnark_rs_amd.distributed import GpuExchangeProver, GpuProver, prove_exchange_stream, prove_sharded, prove_sharded_stream
+        if exchange:
+            xprover = GpuExchangeProver(ctx, inst["crs"], inst["qap"], d_w, m)
+        if shard:
+            prover = GpuProver(ctx, inst["crs"], inst["qap"], d_w, m)
+            bufs = (prover.new_buffer(zk.PARTIAL_BYTES), prover.new_buffer(world * zk.PARTIAL_BYTES))
+    if use_zk:
+        from zksnark_rs_amd.distributed import MgpuProver, prove_sharded_abi
 
-    depth = args.depth or (4 if (shard or args.emulate_world > 1) else 2)
+    depth = args.depth or (4 if ((shard and not use_zk) or args.emulate_world > 1) else 2)
     if args.emulate_world and world == 1 and args.mode == "exchange":
         # rank 0's work in rounds of W proofs: one SpMV/NTT stage + W sets of inner products over 1/W of the points;
         # the all-to-alls are local copies of the same size, so the proofs are NOT valid -- timing only
@@ -383,165 +481,262 @@ def main():
                           "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
         return
 
-    state = {"degraded": None}
-    host_w = None
-    if args.witness_from != "hbm" and world == 1:
-        host_w = ctx.host_alloc(inst["weights"].shape) if args.witness_from == "pinned" else np.empty_like(inst["weights"])
-        host_w[...] = inst["weights"]
 
-    def run(k, local=False):
-        """k steps, all submitted and completed inside this call; returns the proof bytes (local: independent provers)."""
-        local = local or state["degraded"] is not None
-        shard = shard_mode and not local
-        if exchange and not local:
+    state = {"degraded": boot_err, "submit_s": 0.0, "submits": 0}
+    host_ws = None
+    if args.witness_from != "hbm" and world == 1:
+        host_ws = []
+        for st in sets:
+            hw = ctx.host_alloc(st["weights"].shape) if args.witness_from == "pinned" else np.empty_like(st["weights"])
+            hw[...] = st["weights"]
+            host_ws.append(hw)
+
+    def job(i, shared=False):
+        """the i-th job of a run on this rank: which (witness, r, s).  shared: every rank proves the SAME proof (the latency form)"""
+        return (i if shared else i + rank) % len(sets)
+
+    def run(k, mode):
+        """k steps in `mode` ("single" = this GPU alone: N = 1 and the replicas leg), all submitted and completed inside the call;
+        returns [(set index, proof bytes)]"""
+        if mode == "exchange":
             if os.environ.get("ZK_BENCH_TEST_FAIL_EXCHANGE"):   # tests/test_gpu_bench.py: exercises the fallback below
                 raise RuntimeError("injected failure of the exchange protocol")
-            if mprover is not None:     # zk_mgpu_push / zk_mgpu_pop, two rounds pushed ahead of every pop
-                return list(mprover.prove_stream([(d_w.data_ptr(), m, inst["r"], inst["s"])] * k, ahead=2))
-            return list(prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k))   # k rounds = k * world proofs
-        if shard and use_zk:
-            return [prove_sharded_abi(ctx, comm, inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
-        if shard and depth == 1:
-            return [prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs) for _ in range(k)]
-        if shard:
-            return list(prove_sharded_stream(prover, dist, rank, world, [(inst["r"], inst["s"])] * k, depth))
+            if os.environ.get("ZK_BENCH_TEST_HANG_EXCHANGE") and rank == world - 1:
+                time.sleep(100 * TMO)                             # ... and a peer that never arrives
+            idx = [job(i) for i in range(k)]
+            if use_zk:      # zk_mgpu_push / zk_mgpu_pop, two rounds pushed ahead of every pop
+                return list(zip(idx, state["mprover"].prove_stream([(d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"]) for j in idx], ahead=2)))
+            return list(zip(idx, prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k)))   # k rounds = k * world proofs
+        if mode in ("shard", "window_shard"):
+            idx = [job(i, shared=True) for i in range(k)]
+            if use_zk:
+                return [(j, prove_sharded_abi(ctx, comm, inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"])) for j in idx]
+            if depth == 1:
+                return [(0, prove_sharded(prover, dist, rank, world, inst["r"], inst["s"], bufs)) for _ in range(k)]
+            return [(0, pr) for pr in prove_sharded_stream(prover, dist, rank, world, [(inst["r"], inst["s"])] * k, depth)]
+        idx = [job(i) for i in range(k)]
         if args.batch > 1:
-            out, inflight, left = [], [], k
+            out, inflight, left, at = [], [], k, 0
             while left or inflight:
                 if left and len(inflight) < 2:
                     g = min(args.batch, left)
-                    inflight.append((ctx.prove_batch_submit(inst["crs"], inst["qap"], [d_w.data_ptr()] * g, [m] * g, [inst["r"]] * g, [inst["s"]] * g), g))
+                    js = idx[at:at + g]
+                    inflight.append((ctx.prove_batch_submit(inst["crs"], inst["qap"], [d_ws[j].data_ptr() for j in js], [m] * g,
+                                                            [sets[j]["r"] for j in js], [sets[j]["s"] for j in js]), js))
                     left -= g
+                    at += g
                 else:
-                    t, g = inflight.pop(0)
-                    out.extend(ctx.prove_batch_wait(t, g))
+                    t, js = inflight.pop(0)
+                    out.extend(zip(js, ctx.prove_batch_wait(t, len(js))))
             return out
-        if host_w is not None:
-            out, inflight = [], []
-            for _ in range(k):
-                if len(inflight) == depth:
-                    out.append(ctx.prove_wait(inflight.pop(0)))
-                inflight.append(ctx.prove_submit_host(inst["crs"], inst["qap"], host_w.ctypes.data, m, inst["r"], inst["s"]))
-            while inflight:
-                out.append(ctx.prove_wait(inflight.pop(0)))
-            return out
-        if depth == 1:
-            return [ctx.prove_dev(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]) for _ in range(k)]
+        if depth == 1 and host_ws is None:
+            return [(j, ctx.prove_dev(inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"])) for j in idx]
         out, inflight = [], []
-        for _ in range(k):
+        for j in idx:
             if len(inflight) == depth:
-                out.append(ctx.prove_wait(inflight.pop(0)))
+                jj, t = inflight.pop(0)
+                out.append((jj, ctx.prove_wait(t)))
             t_s = time.perf_counter()
-            inflight.append(ctx.prove_submit(inst["crs"], inst["qap"], d_w.data_ptr(), m, inst["r"], inst["s"]))
-            state["submit_s"] = state.get("submit_s", 0.0) + time.perf_counter() - t_s
-            state["submits"] = state.get("submits", 0) + 1
+            if host_ws is not None:
+                t = ctx.prove_submit_host(inst["crs"], inst["qap"], host_ws[j].ctypes.data, m, sets[j]["r"], sets[j]["s"])
+            else:
+                t = ctx.prove_submit(inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"])
+            state["submit_s"] += time.perf_counter() - t_s
+            state["submits"] += 1
+            inflight.append((j, t))
         while inflight:
-            out.append(ctx.prove_wait(inflight.pop(0)))
+            jj, t = inflight.pop(0)
+            out.append((jj, ctx.prove_wait(t)))
         return out
 
-    proof = None
-    # The collectives of the sharded protocols have only ever run over gloo before the driver's multi-GPU runs.  If the
-    # warm-up fails on any rank (a collective RCCL refuses), every rank falls back to independent provers and the
-    # line says so ("degraded") instead of the job producing no number at all.
-    err = None
-    # Before the W warm-up steps: PRIME untimed steps of one-off setup -- the window tables are built by the first proof, and every
-    # proof slot / exchange buffer set the steady state uses is allocated the first time it is touched (three rounds are in flight in
-    # the exchange pipeline, so W = 2 alone would leave first-use allocations inside the timed region at N > 1).
+    # ---- untimed: one-off set-up and the expected bytes --------------------------------------------------------------------
+    # Every set's proof by ONE synchronous single-GPU zk_prove_dev: the bytes every leg of the run (pipelined, batched, from host memory,
+    # exchanged, window-sharded, replicated; at N > 1 on every rank) must reproduce.  This also builds the window tables and -- with
+    # the PRIME pipelined steps behind it -- touches every proof slot the steady state uses (allocations happen on first use).
     PRIME = 4
-    try:
-        for p in run(args.warmup + PRIME):
-            proof = p
-    except Exception as e:   # noqa: BLE001 -- reported in the JSON line
+    expected = [ctx.prove_dev(inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"]) for j in range(len(sets))]
+    sha = lambda b: __import__("hashlib").sha256(b).hexdigest()[:16]   # noqa: E731
+    for j, pr in run(args.warmup + PRIME, "single"):
+        assert pr == expected[j], "pipelined proof differs from the synchronous one"
+    torch.cuda.synchronize()
+
+    def agree(tag, bad):
+        """True if ANY rank reports `bad` (through the rendezvous store; a rank that never answers counts as bad)"""
         if world == 1:
-            raise
-        err = "%s: %s" % (type(e).__name__, str(e)[:300])
-    if world > 1:
-        if comm is not None:
-            # agreement through the bootstrap store (a failed collective may have left the communicator unusable)
-            comm._store.set("warm_%d" % rank, b"1" if err else b"0")
-            failed = any(bytes(comm._store.get("warm_%d" % g)) == b"1" for g in range(world))
-        else:
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
+            return bool(bad)
+        if store is None:
+            if not dist:
+                return bool(bad)
+            flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            failed = bool(int(flag.item()))
-        if failed:
-            state["degraded"] = err or "another rank failed in the warm-up of --mode %s" % args.mode
-            torch.cuda.synchronize()
-            for t in range(zk.MAX_IN_FLIGHT):   # tickets the failed protocol left in flight
-                try:
-                    ctx.prove_wait(t, partial=True)
-                except zk.ZkError:
-                    pass
-            for p in run(args.warmup + PRIME):
-                proof = p
-    ctx.set_option("profile", 0 if (args.latency or args.no_profile) else 2 if args.kernel_times else 1)
-    state["submit_s"], state["submits"] = 0.0, 0
-    ctx.profile_reset()
-    degraded_now = state["degraded"] is not None    # a failed communicator is not used again: barrier through the bootstrap store
+            return bool(int(flag.item()))
+        try:
+            store.set("%s_%d" % (tag, rank), b"1" if bad else b"0")
+            return any(bytes(store.get("%s_%d" % (tag, g))) == b"1" for g in range(world))
+        except Exception:   # noqa: BLE001 -- the store's own timeout
+            return True
 
     def store_barrier(tag):
-        comm._store.set("%s_%d" % (tag, rank), b"1")
+        store.set("%s_%d" % (tag, rank), b"1")
         for g in range(world):
-            comm._store.get("%s_%d" % (tag, g))
-    torch.cuda.synchronize()
-    if degraded_now and comm is not None:
-        store_barrier("b0")
-    else:
-        barrier()
-    t0 = time.perf_counter()
-    proofs_out = run(args.steps)
-    torch.cuda.synchronize()
-    if degraded_now and comm is not None:
-        store_barrier("b1")
-    else:
-        barrier()
-    elapsed = time.perf_counter() - t0
-    if degraded_now and comm is not None:
-        comm._store.set("t_%d" % rank, repr(elapsed).encode())
-        elapsed = max(float(bytes(comm._store.get("t_%d" % g)).decode()) for g in range(world))
-    else:
-        elapsed = reduce_max(elapsed)
-    prof = ctx.profile()
-    ctx.set_option("profile", 0)
-    # beside the window-sharded line (north_star, configs[4]): the same K steps as independent provers, one
-    # per GPU, no collective -- the throughput mode.  Reported as a secondary object, never as `value`.
-    replicas = None
-    if state["degraded"] is not None:
+            store.get("%s_%d" % (tag, g))
+
+    def leg_barrier(tag, collective):
+        if world == 1:
+            return
+        if collective and comm is not None and state["degraded"] is None:
+            comm.barrier()
+        elif store is not None:
+            store_barrier(tag)
+        elif dist:
+            dist.barrier()
+
+    def leg_max(tag, x, collective):
+        if world == 1:
+            return x
+        if collective and comm is not None and state["degraded"] is None:
+            return comm.max_f64(float(x))
+        if store is not None:
+            store.set("%s_%d" % (tag, rank), repr(float(x)).encode())
+            return max(float(bytes(store.get("%s_%d" % (tag, g))).decode()) for g in range(world))
+        return reduce_max(x)
+
+    def timed_leg(mode, tag, profile=False):
+        """W untimed + K timed steps of `mode`, bracketed by barrier + device synchronisation on both sides, max over ranks.
+        Returns (elapsed seconds, mismatches against the expected bytes, kernel profile)."""
+        collective = mode != "single"
+        run(args.warmup, mode)
+        torch.cuda.synchronize()
+        prof_ = None
+        if profile:
+            ctx.set_option("profile", 0 if (args.latency or args.no_profile) else 2 if args.kernel_times else 1)
+            state["submit_s"], state["submits"] = 0.0, 0
+            ctx.profile_reset()
+        leg_barrier(tag + "_b0", collective)
+        t0 = time.perf_counter()
+        outs = run(args.steps, mode)
+        torch.cuda.synchronize()
+        leg_barrier(tag + "_b1", collective)
+        elapsed = leg_max(tag + "_t", time.perf_counter() - t0, collective)
+        if profile:
+            prof_ = ctx.profile()
+            ctx.set_option("profile", 0)
+        wrong = sum(1 for j, pr in outs if pr != expected[j])
+        return elapsed, wrong, prof_
+
+    def leg_record(name, mode, elapsed, wrong, per_step):
+        return {"mode": name, "value": round(per_step * args.steps / elapsed, 4), "unit": "proofs/s", "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                "scaling": "strong" if mode in ("shard", "window_shard") else "weak",
+                "bytes_equal_to_single_gpu_prove": wrong == 0, **({"mismatches": wrong} if wrong else {})}
+
+    # ---- the legs ------------------------------------------------------------------------------------------------------------
+    # N = 1: one leg.  N > 1: the scalar exchange (`value`, --mode exchange), the window-sharded latency form (config 5's wording:
+    # MSM windows sharded over the GPUs, one collective of the partial sums) and independent replicas -- all in ONE line, each with
+    # its own rate and its byte equality against a single-GPU zk_prove_dev of the same inputs.  A leg that fails or does not complete
+    # within the bound is reported as such; if it is the primary one, every rank agrees on that through the store and `value` becomes
+    # the replicas' (the line says `degraded`).
+    legs = {}
+    primary = "single" if world == 1 else ("exchange" if exchange else "shard" if shard else "single")
+    order = [primary]
+    if world > 1:
+        if use_zk:
+            order += [x for x in ("exchange", "window_shard") if x != primary and not (x == "window_shard" and primary == "shard" and args.shard == "windows")]
+        if "single" not in order:
+            order.append("single")
+    prof, elapsed, wrong_primary, raw_elapsed = {}, None, 0, {}
+    for mode in order:
+        collective = mode != "single"
+        if collective and state["degraded"] is not None:
+            continue
+        err = None
+        try:
+            if mode == "exchange" and use_zk and state.get("mprover") is None:
+                state["mprover"] = mprover = bounded(lambda: MgpuProver(ctx, comm, inst["crs"], inst["qap"]), TMO, "zk_mgpu_create", device)
+            if mode in ("shard", "window_shard"):
+                ctx.set_option("msm_shard_points", 0 if mode == "window_shard" else (1 if args.shard == "points" else 0))
+            if collective:
+                res = bounded(lambda: timed_leg(mode, "leg_" + mode, profile=(mode == primary)), max(TMO, 4 * TMO if args.steps > 200 else TMO), "the %s leg" % mode, device)
+            else:
+                res = timed_leg(mode, "leg_" + mode, profile=(mode == primary))
+        except Exception as e:   # noqa: BLE001 -- reported in the JSON line
+            if not collective:
+                raise
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            res = None
+        if collective:
+            failed = agree("ok_" + mode, err is not None)
+            if failed:
+                err = err or "another rank failed or timed out in the %s leg" % mode
+                legs[mode] = {"mode": mode, "error": err}
+                # a communicator that failed is not used again: abort it (its kernels leave the GPU), release the tickets it left
+                if comm is not None and args.transport == "zk":
+                    comm.abort()
+                if mode == primary or True:
+                    state["degraded"] = err
+                try:
+                    bounded(torch.cuda.synchronize, 30, "device synchronisation after a failed leg", device)
+                except Exception:   # noqa: BLE001
+                    pass
+                for t in range(zk.MAX_IN_FLIGHT):
+                    try:
+                        ctx.prove_wait(t, partial=True)
+                    except zk.ZkError:
+                        pass
+                continue
+        el, wrong, pf = res
+        per_step = world if mode in ("exchange", "single") and world > 1 else 1
+        name = {"single": "replicas x%d (independent provers, no collective)" % world if world > 1 else "single GPU",
+                "exchange": "scalar exchange by point ranges x%d (zk_mgpu_*: all-to-all of scalars and partial sums)" % world,
+                "shard": "msm-%s-shard x%d, one proof at a time (latency form)" % ("point-range" if args.shard == "points" else "window", world),
+                "window_shard": "MSM windows w = rank (mod %d) per GPU, one proof at a time, all-gather of the partial sums (BASELINE config 5)" % world}[mode]
+        legs[mode] = leg_record(name, mode, el, wrong, per_step)
+        raw_elapsed[mode] = el
+        if mode == "exchange" and state.get("mprover") is not None:
+            # zk_mgpu_destroy gives the inner-product streams their whole chip back (option comm_cu_reserve): the legs behind this one
+            # -- the window-sharded form, the replicas -- are not measured with compute units set aside for an exchange they do not run
+            state["mprover"].close()
+            state["mprover"] = None
+        if mode == primary:
+            prof, elapsed, wrong_primary = pf or {}, el, wrong
+    if primary not in legs or "error" in legs.get(primary, {}):     # degraded: `value` is the replicas leg
+        primary = "single"
+        if "single" not in legs:
+            el, wrong, pf = timed_leg("single", "leg_single", profile=True)
+            legs["single"] = leg_record("replicas x%d (independent provers, no collective)" % world, "single", el, wrong, world)
+            prof, elapsed, wrong_primary = pf or {}, el, wrong
+        else:
+            elapsed = raw_elapsed["single"]
         shard = exchange = False
-    if shard or exchange:
-        run(args.warmup, local=True)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        rep_out = run(args.steps, local=True)
-        torch.cuda.synchronize()
-        barrier()
-        e2 = reduce_max(time.perf_counter() - t1)
-        assert all(p == proofs_out[0] for p in rep_out), "replica proof differs from the sharded proof"
-        replicas = {"mode": "replicas x%d (independent provers, no collective)" % world, "value": round(world * args.steps / e2, 4),
-                    "unit": "proofs/s", "scaling": "weak", "ms_per_step": round(1e3 * e2 / args.steps, 3)}
-    for p in proofs_out:
-        assert proof is None or p == proof, "non-deterministic proof bytes"
-        proof = p
+    assert wrong_primary == 0, "proof bytes differ from the synchronous single-GPU proof of the same inputs"
+    for k_, v_ in legs.items():
+        assert v_.get("bytes_equal_to_single_gpu_prove", True), "the %s leg produced different proof bytes" % k_
+    proof = expected[0]
+
     # beside the resident-witness line: the same steps with every proof's witness handed over in page-locked HOST memory, as the
-    # reference's prove(&[T]) does (mod.rs:213-217) -- 96 MB over PCIe per proof at 2^20.  Secondary object, never `value`.
+    # reference's prove(&[T]) does (mod.rs:213-217) -- 67 MB over PCIe per proof at 2^20.  Secondary object, never `value`.
     pcie = None
-    if world == 1 and host_w is None and args.batch <= 1 and not shard_mode and not args.latency:
-        host_w = ctx.host_alloc(inst["weights"].shape)
-        host_w[...] = inst["weights"]
+    if world == 1 and host_ws is None and args.batch <= 1 and not args.latency:
+        host_ws = []
+        for st in sets:
+            hw = ctx.host_alloc(st["weights"].shape)
+            hw[...] = st["weights"]
+            host_ws.append(hw)
         k2 = max(min(args.steps, 40), 1)
-        run(min(args.warmup, 4) or 1)
+        run(min(args.warmup, 4) or 1, "single")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        out2 = run(k2)
+        out2 = run(k2, "single")
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t1
-        assert all(p == proof for p in out2), "proof from a host-memory witness differs"
+        assert all(pr == expected[j] for j, pr in out2), "proof from a host-memory witness differs"
         pcie = {"value": round(k2 / e2, 4), "unit": "proofs/s", "witness_from": "pinned host memory (zk_prove_submit_host)", "steps": k2,
                 "host_to_device_MB_per_proof": round(inst["weights"].nbytes / 1e6, 1)}
-        ctx.host_free(host_w)
-        host_w = None
+        for hw in host_ws:
+            ctx.host_free(hw)
+        host_ws = None
 
+    shard = primary in ("shard", "window_shard")
+    exchange = primary == "exchange"
     proofs = args.steps * (world if (world > 1 and not shard) else 1)   # exchange / replicas: a step is `world` proofs
     value = proofs / elapsed
     if rank == 0:
@@ -568,6 +763,7 @@ def main():
             gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
             traffic = pmc_traffic(name, args.log_n) if (args.log_n in PMC_FILES and world == 1 and not args.window_bits and args.batch <= 1
                                                        and args.roots == "unity") else None
+            traffic_commit = pmc_whole_proof(args.log_n)[1] if args.log_n in PMC_FILES else None
             adds = pairs * windows
             measured = pmc_acc(name, args.log_n) if args.log_n in PMC_ACC_FILES else None
             valu = None
@@ -575,22 +771,25 @@ def main():
                 winst, slow, src = measured
                 g_inst = adds / (avg_ms * 1e-3) / 64.0 * winst / 1e9
                 peak_mix = 1.0 / (slow / VALU_PEAK_G["slow"] + (1.0 - slow) / VALU_PEAK_G["fast"])
-                meas_mix = 1.0 / (slow / VALU_MEASURED_G["slow"] + (1.0 - slow) / VALU_MEASURED_G["fast"])
+                sus = ubench_sustained()
+                meas_mix = 1.0 / (slow / sus["slow"] + (1.0 - slow) / sus["fast"]) if sus else None
                 valu = {"achieved": round(g_inst, 1), "unit": "G wave-instr/s", "peak": round(peak_mix, 1), "frac": round(g_inst / peak_mix, 3),
-                        "peak_measured_ubench": round(meas_mix, 1), "frac_of_measured_peak": round(g_inst / meas_mix, 3),
+                        "peak_measured_ubench": round(meas_mix, 1) if meas_mix else None, "frac_of_measured_peak": round(g_inst / meas_mix, 3) if meas_mix else None,
+                        "peak_measured_source": "profiles/%s" % UBENCH_FILE,
                         "additions_per_launch": round(adds), "windows_per_product": wins, "G_additions_per_s": round(adds / (avg_ms * 1e-3) / 1e9, 2),
                         "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
                         "int64_share": src.get("int64_share"), "int32_share": src.get("int32_share"),
                         "sustained_clock_GHz_stand_alone": src.get("sustained_clock_GHz"),
                         "source": "profiles/%s (SQ_INSTS_VALU / additions; SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU)" % PMC_ACC_FILES[args.log_n],
                         "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
-                                "tools/ubench_valu.hip sustains (585 / 1062 G/s).  Under this kernel the chip clocks below 2.4 GHz "
+                                "tools/ubench_valu.hip sustains (read from peak_measured_source).  Under this kernel the chip clocks below 2.4 GHz "
                                 "(sustained_clock_GHz_stand_alone), i.e. at the sustained clock the issue fraction is frac x 2.4 / clock; other "
                                 "kernels of the pipeline share the SIMDs during this measurement"}
             roofline = {
                 # the roofline the metric names: SURVEY 8(d) algorithmic bytes of one launch / its event-timed duration against HBM
                 "bound": "valu", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": "profiles/%s" % PMC_FILES[args.log_n] if traffic else None, "traffic_source_commit": traffic_commit if traffic else None,
                 "traffic_over_algorithmic": round(traffic / bytes_per_launch, 2) if traffic else None,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": bytes_per_launch, "pairs_per_launch": round(pairs),
                 "launches": e["launches"],
@@ -605,28 +804,44 @@ def main():
                                 "frac": round(1404.0 * n * value / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
                                 "note": "SURVEY 8(d): 1404 n bytes per proof; per GPU"},
             }
+        hbm_proof, hbm_commit = pmc_whole_proof(args.log_n) if (args.log_n in PMC_FILES and args.roots == "unity" and not args.window_bits and args.batch <= 1) else (None, None)
+        xg = None
+        if world > 1 and use_zk and "exchange" in legs and "error" not in legs["exchange"]:
+            el4 = [int(x_) for x_ in ctx.prove_exchange_elems(inst["qap"], world)]
+            if el4:
+                xg = int(sum(el4) * 32 * (world - 1) // world + zk.PARTIAL_BYTES * (world - 1))
         out = {
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
-            "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d)" % (args.witness, args.seed),
+            "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d; %d distinct (witness, r, s) cycled through the timed region)" % (args.witness, args.seed, len(sets)),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM%s"
                                    % (args.log_n, m, "" if args.roots == "unity" else "; QAP over the integer roots 1..n" if args.roots == "integers" else "; QAP over caller-supplied (arbitrary) roots"),
-                       "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("point-range" if args.shard == "points" else "window", world)) if shard
+                       "parallelism": ("msm-%s-shard x%d + RCCL all-gather" % ("window" if (primary == "window_shard" or args.shard == "windows") else "point-range", world)) if shard
                                       else ("msm point-range shard x%d, NTT stage by proof owner, RCCL all-to-all of scalars and partial sums (%s); "
                                             "a step = one round of %d proofs" % (world, "zk_comm / zk_mgpu inside libzkgpu.so" if use_zk else "torch.distributed", world)) if exchange
                                       else ("replicas x%d" % world),
                        "north_star_deviations": "MSM = fixed-base Pippenger over precomputed window tables with ONE shared set of 2^(c-1) buckets; bucket "
                                                 "sums live in registers / HBM images, not LDS (2^16 XYZZ buckets = 9.4 MB against 160 KB); balanced lanes "
                                                 "instead of one wavefront per window (DESIGN 4c).  NTT tiles exchange through LDS, not wave shuffles (a 254-bit "
-                                                "element is 9 dwords).  N > 1 default = scalar exchange by point ranges; the window-sharded form is --mode shard",
-                       "setup_steps_before_warmup": PRIME, "witness_from": args.witness_from, "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto", "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16]},
+                                                "element is 9 dwords).  N > 1: `value` = scalar exchange by point ranges; config 5's window-sharded form is the "
+                                                "`window_shard` object of the same line",
+                       "setup_steps_before_warmup": PRIME + len(sets), "witness_from": args.witness_from, "witness_sets": len(sets),
+                       "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto",
+                       "proof_sha": sha(expected[0]), "proof_shas": [sha(e_) for e_ in expected],
+                       "expected_bytes_from": "one synchronous single-GPU zk_prove_dev per set in the untimed set-up; every timed proof is compared with it"},
             "roofline": roofline,
-            **({"replicas": replicas} if replicas else {}),
+            **({k_: v_ for k_, v_ in (("exchange", legs.get("exchange")), ("window_shard", legs.get("window_shard") or (legs.get("shard") if args.shard == "windows" else None)),
+                                      ("shard", legs.get("shard") if args.shard != "windows" else None), ("replicas", legs.get("single"))) if v_ and world > 1}),
+            **({"rccl_ranks": comm.rccl_ranks() if (comm is not None and state["degraded"] is None) else 0, "xgmi_bytes_sent_per_rank_per_round": xg,
+                "comm_cu_reserve_per_xcd": ctx.get_option("comm_cu_reserve") if (use_zk and args.transport == "zk") else 0, "wait_bound_s": TMO} if world > 1 else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),
             **({"degraded": "fell back to independent provers: " + state["degraded"]} if state["degraded"] is not None else {}),
             "hbm_algorithmic_GBps_whole_proof": round(1404.0 * n * value / 1e9, 2),
+            "hbm_measured_GBps_whole_proof": round(hbm_proof * value / max(world, 1) / 1e9, 1) if (hbm_proof and world == 1) else None,
+            "hbm_measured_source": {"file": "profiles/%s" % PMC_FILES[args.log_n], "commit": hbm_commit, "bytes_per_proof": hbm_proof,
+                                    "note": "sum over every kernel of a proof of (corrected FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes of this command, x value"} if hbm_proof else None,
             "kernel_ms_per_proof": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             **({"host": {"submit_ms_per_proof": round(1e3 * state["submit_s"] / state["submits"], 3),
                          "note": "wall time of zk_prove_submit on the host (everything of a proof is enqueued inside it)"}} if state.get("submits") else {}),
@@ -634,9 +849,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(zk, ctx, args.seed, inst, args.cpu_baseline == "full")
             out["cpu_baseline"]["cores_on_host"] = os.cpu_count()
-        print(json.dumps(out))
-    if mprover is not None and state["degraded"] is None:
-        mprover.close()
+        print(json.dumps(out), flush=True)
+    hung = state["degraded"] is not None and world > 1
+    if hung:
+        # a communicator that failed or timed out may still hold a blocked worker thread or a blocked peer: leave without the
+        # orderly tear-down (which would wait for them)
+        sys.stdout.flush()
+        os._exit(0)
+    if state.get("mprover") is not None:
+        state["mprover"].close()
     if comm is not None:
         comm.close()
     if dist:

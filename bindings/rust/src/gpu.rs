@@ -77,6 +77,8 @@ extern "C" {
     fn zk_comm_unique_id(id_out: *mut u8) -> c_int;
     fn zk_comm_init(ctx: *mut ZkCtx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut ZkComm) -> c_int;
     fn zk_comm_destroy(c: *mut ZkComm);
+    fn zk_comm_set_timeout(c: *mut ZkComm, ms: std::os::raw::c_long) -> c_int;
+    fn zk_comm_rccl_ranks(c: *const ZkComm) -> c_int;
     fn zk_mgpu_create(ctx: *mut ZkCtx, comm: *mut ZkComm, crs: *const ZkCrs, qap: *const ZkQap, out: *mut *mut ZkMgpu) -> c_int;
     fn zk_mgpu_push_host(p: *mut ZkMgpu, weights: *const u64, m: usize, r: *const u64, s: *const u64) -> c_int;
     fn zk_mgpu_pop(p: *mut ZkMgpu, proof_out: *mut u8) -> c_int;
@@ -641,6 +643,11 @@ impl MultiGpuProver {
         self.prove_stream(std::iter::once((weights, FrLocal::random_elem(), FrLocal::random_elem()))).pop().unwrap()
     }
     pub fn world(&self) -> usize { self.world }
+    /// Bound of every wait for a peer (default 120 s): a pop whose round does not complete in time panics with the library's
+    /// message instead of blocking for ever, and the communicator is aborted.
+    pub fn set_timeout_ms(&self, ms: u64) { unsafe { zk_comm_set_timeout(self.comm, ms as std::os::raw::c_long); } }
+    /// Ranks of the RCCL communicator as RCCL counts them (0 when `world` is 1).
+    pub fn rccl_ranks(&self) -> usize { unsafe { zk_comm_rccl_ranks(self.comm) as usize } }
     pub fn single(&self) -> &GpuProver { &self.inner }
 }
 impl Drop for MultiGpuProver {

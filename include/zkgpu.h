@@ -68,7 +68,10 @@ const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last fai
  * the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the reference's long
  * division; default 0 = power-series inverse above 512 quotient coefficients), "msm_quad_buckets" (inner products of at most this
  * many buckets run their reduction tail with four lanes per point addition: shorter dependency chains for small circuits; default
- * 65536, 0 = never).  Each is exercised by a -m gpu test.
+ * 65536, 0 = never), "interp_large_log" (arbitrary-roots interpolation: trees of at least 2^value coefficients per level take the
+ * form that re-uses the children's transforms; default 20; both forms give the same coefficients), "comm_cu_reserve" (zk_mgpu_create
+ * over an RCCL communicator of more than one rank: compute units per XCD that the inner-product streams leave to the collectives'
+ * kernels; default 1, 0 = none).  Each is exercised by a -m gpu test.
  * A library built with -DZK_MEASURE (make -C zksnark_rs_amd/csrc measure; zk_get_option(ctx, "measure_build") == 1) also accepts the
  * measurement switches of bench.py --opt / --serialize ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole",
  * "msm_small_lanes", "msm_unchain_lanes", "chain_order"); the product build answers ZK_ERR_UNSUPPORTED to them and to unknown keys. */
@@ -373,6 +376,15 @@ int zk_comm_init_custom(zk_ctx* ctx /* may be NULL */, const zk_comm_ops* ops, i
 void zk_comm_destroy(zk_comm* comm);
 int zk_comm_rank(const zk_comm* comm);
 int zk_comm_world(const zk_comm* comm);
+/* ranks of the RCCL communicator behind this zk_comm as RCCL counts them (ncclCommCount); 0 = none (one rank, a caller's transport,
+ * aborted).  Evidence for the bench line that a world-N run really went through an N-rank RCCL communicator. */
+int zk_comm_rccl_ranks(const zk_comm* comm);
+/* Every host wait for a collective (zk_comm_barrier / _max_f64 / _all_to_all / _all_gather, zk_mgpu_pop) is bounded: after `ms`
+ * milliseconds (default 120000, or ZK_COMM_TIMEOUT_MS at zk_comm_init; 0 = unbounded) the RCCL communicator is aborted and the call
+ * returns ZK_ERR_COMM, as does every later one.  The reference's prove (mod.rs:213-217) cannot hang on a peer; neither may this. */
+int zk_comm_set_timeout(zk_comm* comm, long ms);
+/* Gives up on the peers now (ncclCommAbort): callable from another thread while a collective is being waited for. */
+int zk_comm_abort(zk_comm* comm);
 int zk_comm_barrier(zk_comm* comm);
 int zk_comm_max_f64(zk_comm* comm, double* value);      /* *value = max over the ranks (timing of the slowest rank) */
 int zk_comm_all_to_all(zk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);   /* complete on return */

@@ -54,10 +54,12 @@ def test_interpolation_matches_lagrange_sums(ctx, n):
     assert [limbs_to_int(x) for x in got] == lagrange_coeffs(roots, values)
 
 
-@pytest.mark.parametrize("log_n", [10, 14, 17])
+@pytest.mark.parametrize("log_n", [10, 14, 17, 20])
 def test_interpolation_on_permuted_roots_of_unity(ctx, log_n):
     """Size-independent check: when the nodes are the 2^k-th roots of unity in a scrambled order the interpolant is the inverse
-    transform of the unscrambled values (zk_ntt_fr, pinned to the reference's dft KATs through the oracle)."""
+    transform of the unscrambled values (zk_ntt_fr, pinned to the reference's dft KATs through the oracle).  2^20 nodes take the
+    large-tree form of interp_run (2^20 coefficients per level and more: csrc/interp.hip), which every arbitrary-roots QAP of more
+    than 2^18 gates proves through."""
     n = 1 << log_n
     gen = np.random.default_rng(log_n)
     perm = gen.permutation(n)
@@ -69,6 +71,29 @@ def test_interpolation_on_permuted_roots_of_unity(ctx, log_n):
     want = ctx.ntt_fr(natural, inverse=True)
     got = ctx.interpolate_fr(w_pows[perm], vals)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [64, 65, 1000, 4096, 5000, (1 << 15) + 17])
+def test_interpolation_small_and_large_tree_forms_agree(n):
+    """interp_run has two forms of the upward pass (zero-padded 4s-point transforms below 2^20 coefficients per level; above, the
+    parents' images assembled from the children's 2s-point ones and a twisted second half).  Option interp_large_log moves the
+    switch: both forms on the same nodes and values must give the same coefficients, which also evaluate back at the nodes."""
+    rng = SplitMix64(515 + n)
+    roots = [rng.fr() for _ in range(n)]
+    values = [rng.fr() for _ in range(n)]
+    rl, vl = ints_to_limbs(roots).reshape(n, 4), ints_to_limbs(values).reshape(n, 4)
+    got = []
+    for log in (40, 0):      # always the small-tree form, always the large-tree form
+        c = zk.Context(0)
+        c.set_option("interp_large_log", log)
+        got.append(c.interpolate_fr(rl, vl))
+    assert np.array_equal(got[0], got[1])
+    coef = [limbs_to_int(x) for x in got[1]]
+    for k in (0, n // 3, n - 1):
+        acc = 0
+        for cf in reversed(coef):
+            acc = (acc * roots[k] + cf) % R
+        assert acc == values[k], k
 
 
 def test_interpolation_with_n_not_a_power_of_two_evaluates_back(ctx):
@@ -180,12 +205,13 @@ def test_the_integers_as_arbitrary_roots(ctx, n):
         assert ctx.prove(ca, qa, wts, r, s) == ctx.prove(ci, qi, wts, r, s)
 
 
-@pytest.mark.parametrize("n", [1000, (1 << 16) + 3, 1 << 18])
+@pytest.mark.parametrize("n", [1000, (1 << 16) + 3, 1 << 18, (1 << 19) + 1])
 def test_affine_images_of_the_integers_match_the_closed_form(ctx, orc, n):
     """Size-independent property.  Over the roots r_k = a k + b the wire polynomials are u_i((x - b) / a), so a proof with trapdoor x'
     is the integer-roots proof with trapdoor x = (x' - b) / a (A, B and every term of C are values of the same polynomials) -- which
     the oracle's closed form gives at any size.  The device treats the roots as arbitrary field elements (dense form at 2^18 gates:
-    3 m n x 32 B = 13 TB).  Valid and invalid witness; zk_verify accepts / rejects; pipelined submissions."""
+    3 m n x 32 B = 13 TB).  Valid and invalid witness; zk_verify accepts / rejects; pipelined submissions.  2^19 + 1 gates: the tree is
+    padded to 2^20 leaves and the two vectors of a proof make 2^21 coefficients per level -- the large-tree form of interp_run."""
     m, l, u, v, w = chain_rows_integers(n)
     rng = SplitMix64(7900 + (n & 0xFFFF))
     x, avals = rng.fr(), [rng.fr() for _ in range(n)]

@@ -35,6 +35,14 @@ def short(n):
     return re.sub(r"<.*", "", n) + ("<G2>" if g2 else "")
 
 
+def commit():
+    """the commit the profiled build was made from: tools/gpu.sh writes it into .build_commit before the snapshot leaves (the GPU box has no .git)"""
+    try:
+        return open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".build_commit")).read().strip()
+    except OSError:
+        return None
+
+
 def main():
     d, log_n = sys.argv[1], int(sys.argv[2])
     from bench import msm_window
@@ -64,7 +72,7 @@ def main():
     out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES "
                      "GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --log-n %d (counter passes "
                      "serialise the kernels: stand-alone durations)" % log_n,
-           "log_n": log_n, "proofs": proofs, "kernels": {}}
+           "log_n": log_n, "proofs": proofs, "commit": commit(), "kernels": {}}
     for k, pts in counts.items():
         if not calls[k]:
             continue

@@ -46,6 +46,21 @@ def main():
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; corrected = (factor * fetch + write) * 1024 bytes, factor = 2 "
                     "(streams, 128 B gathers) or 1 (64 B gathers: k_msm_accumulate<Fq>), see profiles/r1_fetch_calibration.txt",
            "kernels": {}}
+    # kernels of the one-off set-up (CRS, window tables) do not belong to a proof
+    setup = ("k_msm_precompute", "k_fixed_base_mul", "k_fixed_table", "k_setup_", "k_lagrange_at", "k_powers", "k_mid_table", "k_points_brev",
+             "k_pts_on_curve", "k_pts_to_mont", "k_g2_subgroup")
+    proofs = max(len(fetch.get("zk::k_assemble", [])), len(write.get("zk::k_assemble", [])), 1)
+    total = 0.0
+    for name in sorted(set(fetch) | set(write)):
+        if any(t in name for t in setup):
+            continue
+        total += (FETCH_FACTOR.get(name, 2.0) * sum(fetch.get(name, [])) + sum(write.get(name, []))) * 1024
+    out["proofs_sampled"] = proofs
+    out["hbm_bytes_per_proof_corrected"] = int(total / proofs)
+    try:
+        out["commit"] = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".build_commit")).read().strip()
+    except OSError:
+        out["commit"] = None
     for name in sorted(set(fetch) | set(write)):
         f, w = fetch.get(name, []), write.get(name, [])
         fa = sum(f) / len(f) if f else 0.0

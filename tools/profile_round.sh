@@ -41,7 +41,7 @@ python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.jso
 python tools/pmc_summary.py $OUT/pmc_fetch16 $OUT/pmc_write16 > $OUT/pmc_traffic_2p16.json
 python tools/pmc_acc_summary.py $OUT/pmc_acc 20 > $OUT/pmc_acc.json
 python tools/pmc_acc_summary.py $OUT/pmc_acc16 16 > $OUT/pmc_acc_2p16.json
-python tools/valu_budget.py $OUT/pmc_acc "round-3 build, 2^20 gates" > $OUT/valu_budget.txt
+python tools/valu_budget.py $OUT/pmc_acc "round-4 build, 2^20 gates" > $OUT/valu_budget.txt
 python tools/pmc_counters.py $OUT/pmc_acc k_msm k_ntt > $OUT/pmc_counters.txt
 find $OUT/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/prof_stats_ser -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_serialized.csv \;
@@ -55,7 +55,8 @@ python tools/trace_kernels.py "$(find $OUT/prof_stats_ser -name '*kernel_trace.c
   python tools/time_root_tables.py 16 18 20 22
   python tools/time_change_of_basis.py
 } > $OUT/lone.txt 2>/dev/null
-for w in 2 4 8; do python bench.py --emulate-world $w --steps 20 --warmup 4 2>/dev/null | tail -1; done > $OUT/emul.txt
+for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --steps 20 --warmup 4 2>/dev/null | tail -1; done > $OUT/emul.txt
+ZK_COMM_FORCE_RCCL=1 python tools/rccl_starvation.py > $OUT/rccl_starvation.txt 2>&1
 # the raw per-dispatch traces are large; keep only the summaries
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch16 $OUT/pmc_write16 $OUT/pmc_acc $OUT/pmc_acc16 $OUT/prof_stats_ser $OUT/prof_stats $OUT/trace $OUT/trace16
 ls -la $OUT

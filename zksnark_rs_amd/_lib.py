@@ -147,6 +147,9 @@ SIGNATURES = {
     "zk_comm_destroy": (None, [C.c_void_p]),
     "zk_comm_rank": (C.c_int, [C.c_void_p]),
     "zk_comm_world": (C.c_int, [C.c_void_p]),
+    "zk_comm_rccl_ranks": (C.c_int, [C.c_void_p]),
+    "zk_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_long]),
+    "zk_comm_abort": (C.c_int, [C.c_void_p]),
     "zk_comm_barrier": (C.c_int, [C.c_void_p]),
     "zk_comm_max_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "zk_comm_all_to_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -9,6 +9,35 @@
 
 using namespace zk;
 
+namespace zk {
+// Re-creates the inner-product streams so that their kernels leave `per_xcd` compute units of every XCD alone (0 = the plain
+// mid-priority streams of zk_ctx_create).  Used by the multi-GPU exchange (zk_mgpu_create, option comm_cu_reserve): RCCL's send /
+// receive kernels run on the collectives' stream, which is not masked, and always find those units free instead of waiting ~2 ms
+// (p90 5 ms) for an accumulation wave to retire (profiles/r3_rccl_starvation.txt, r4_rccl_starvation.txt).  Mask layout measured
+// with tools/ubench_cumask.hip: clearing bits 0 .. 8 R - 1 takes R units from each of the 8 XCDs.
+void ctx_reserve_cus(zk_ctx* ctx, int per_xcd) {
+    per_xcd = std::max(0, std::min(per_xcd, 8));
+    if (per_xcd == ctx->msm_cu_reserved) return;
+    ZK_HIP(hipSetDevice(ctx->device));
+    ZK_HIP(hipDeviceSynchronize());
+    int prio_least = 0, prio_greatest = 0;
+    ZK_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const int prio_mid = (prio_least + prio_greatest) / 2;
+    const uint32_t words = (uint32_t)((ctx->cu_count + 31) / 32);
+    std::vector<uint32_t> mask(words, 0xffffffffu);
+    for (int b = 0; b < 8 * per_xcd && b < ctx->cu_count; ++b) mask[b / 32] &= ~(1u << (b % 32));
+    for (int i = 0; i < zk_ctx::MSM_STREAMS; ++i) {
+        if (i == 3) continue;
+        hipStream_t fresh = nullptr;
+        if (per_xcd) ZK_HIP(hipExtStreamCreateWithCUMask(&fresh, words, mask.data()));
+        else ZK_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio_mid));
+        if (ctx->msm_stream[i]) (void)hipStreamDestroy(ctx->msm_stream[i]);
+        ctx->msm_stream[i] = fresh;
+    }
+    ctx->msm_cu_reserved = per_xcd;
+}
+}  // namespace zk
+
 extern "C" {
 
 const char* zk_strerror(int status) {
@@ -98,6 +127,8 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "dense_long_division")) return &ctx->opt_long_division;
     if (!std::strcmp(key, "msm_shard_points")) return &ctx->opt_shard_points;
     if (!std::strcmp(key, "msm_quad_buckets")) return &ctx->opt_quad_buckets;
+    if (!std::strcmp(key, "interp_large_log")) return &ctx->opt_interp_large_log;
+    if (!std::strcmp(key, "comm_cu_reserve")) return &ctx->opt_comm_cu_reserve;
 #ifdef ZK_MEASURE
     // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;

@@ -14,9 +14,11 @@
 // (zk_prove_scalars_submit / zk_prove_msm_submit / zk_prove_wait / zk_prove_combine); tests may substitute CPU stand-ins
 // so that the pipeline logic and the collectives' order run under world-size-2 gloo without a GPU.
 #include <rccl/rccl.h>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <thread>
 #include <functional>
 #include <vector>
 #include "pipeline.hpp"
@@ -32,6 +34,8 @@ struct zk_comm {
     bool loopback = false;          // TIMING ONLY (ZK_COMM_LOOPBACK=1): several ranks played by device-to-device copies on this stream
     hipStream_t stream = nullptr;   // collectives run here, never on the compute streams
     int* d_flag = nullptr;          // barrier / max-reduce scratch (device)
+    long timeout_ms = 120000;       // every host wait for a collective is bounded by this (zk_comm_set_timeout; ZK_COMM_TIMEOUT_MS)
+    bool aborted = false;           // a wait timed out or the caller gave up: the RCCL communicator is gone, every later call is refused
 };
 
 struct zk_mgpu {
@@ -50,6 +54,7 @@ struct zk_mgpu {
     size_t first = 0;               // round number of rounds.front()
     std::string last_error;
     bool failed = false;            // a stage or a collective failed: the pipeline state is unknown, every later call is refused
+    bool cu_reserved = false;       // zk_mgpu_create masked the inner-product streams (comm_cu_reserve): undone by zk_mgpu_destroy
     // stream-ordered hand-overs (the library's own GPU stages over the library's own transport, see inner_products): events of round
     // k at index k % 3 -- scalars written, scalars exchanged, inner products done -- and the pinned landing places of the range flag
     // and of the proof
@@ -69,7 +74,9 @@ namespace zk {
     } while (0)
 
 // ---- transport ----------------------------------------------------------------------------------
+static void comm_live(const zk_comm* c);
 static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    comm_live(c);
     if (c->custom) {
         ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
         return;
@@ -88,6 +95,7 @@ static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t
     ZK_NCCL(ncclGroupEnd());
 }
 static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    comm_live(c);
     if (c->custom) {
         ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
         return;
@@ -99,8 +107,33 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
     }
     ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->nccl, c->stream));
 }
+// Tears the RCCL communicator down without waiting for its peers (ncclCommAbort makes the collectives' kernels exit), so that a
+// rank whose peer died or never arrived gets its stream back instead of hanging in a device synchronisation for ever.
+static void comm_abort(zk_comm* c) {
+    c->aborted = true;
+    if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }
+}
+// Host wait for everything enqueued on the collectives' stream, BOUNDED: polls the stream (a spin for the first 2 ms -- the normal
+// case is a few hundred microseconds --, then 50 us sleeps) and, when timeout_ms pass, aborts the communicator and reports
+// ZK_ERR_COMM.  A custom transport completes inside the caller's callback.
 static void comm_sync(zk_comm* c) {
-    if (!c->custom) ZK_HIP(hipStreamSynchronize(c->stream));
+    if (c->custom) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery (collectives' stream)"};
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (c->timeout_ms > 0 && ms > (double)c->timeout_ms) {
+            comm_abort(c);
+            (void)hipStreamSynchronize(c->stream);   // returns once the aborted kernels have left
+            throw StatusError{ZK_ERR_COMM, "zk_comm: a collective did not complete within " + std::to_string(c->timeout_ms) + " ms (a peer is missing or hung); the communicator was aborted"};
+        }
+        if (ms > 2.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+static void comm_live(const zk_comm* c) {
+    ZK_REQUIRE(!c->aborted, ZK_ERR_COMM, "zk_comm: the communicator was aborted (an earlier collective timed out); create a new one");
 }
 
 // ---- the default backend: this library's GPU stages -----------------------------------------------
@@ -239,6 +272,7 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
         ZK_HIP(hipMalloc((void**)&c->d_flag, 64));
         // ZK_COMM_FORCE_RCCL=1: a one-rank communicator too goes through RCCL (self send / recv, all-gather, all-reduce) -- the
         // only way to execute this file's RCCL calls on a one-GPU box (tests/test_gpu_bench.py)
+        if (const char* tmo = std::getenv("ZK_COMM_TIMEOUT_MS")) c->timeout_ms = std::atol(tmo);
         const char* force = std::getenv("ZK_COMM_FORCE_RCCL");
         // ZK_COMM_LOOPBACK=1 (bench.py --emulate-world): rank 0 of `world` ranks with copies in place of the collectives -- one rank's
         // work of a `world`-GPU run through the same code path (stream-ordered hand-overs included).  The sums it forms are NOT
@@ -282,14 +316,37 @@ void zk_comm_destroy(zk_comm* c) {
 }
 int zk_comm_rank(const zk_comm* c) { return c ? c->rank : -1; }
 int zk_comm_world(const zk_comm* c) { return c ? c->world : 0; }
+/* ranks of the RCCL communicator behind this zk_comm as RCCL itself counts them (ncclCommCount); 0 = no RCCL communicator
+ * (one rank without ZK_COMM_FORCE_RCCL, a caller's transport, the loop-back of the measurement build, or aborted) */
+int zk_comm_rccl_ranks(const zk_comm* c) {
+    if (!c || !c->nccl) return 0;
+    int n = 0;
+    return ncclCommCount(c->nccl, &n) == ncclSuccess ? n : 0;
+}
+/* bound (ms) of every host wait for a collective of this communicator: barrier, max, all-to-all, all-gather, zk_mgpu_pop.
+ * 0 = wait for ever.  Default 120000, or the environment variable ZK_COMM_TIMEOUT_MS at zk_comm_init. */
+int zk_comm_set_timeout(zk_comm* c, long ms) {
+    if (!c || ms < 0) return ZK_ERR_ARG;
+    c->timeout_ms = ms;
+    return ZK_OK;
+}
+/* gives up on the peers: the RCCL communicator is aborted (its kernels leave the GPU), later collectives answer ZK_ERR_COMM.
+ * May be called from another thread while a collective of this communicator is being waited for. */
+int zk_comm_abort(zk_comm* c) {
+    if (!c) return ZK_ERR_ARG;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    comm_abort(c);
+    return ZK_OK;
+}
 
 /* Every rank blocks until all have arrived (an all-gather of one flag per rank). */
 int zk_comm_barrier(zk_comm* c) {
     if (!c) return ZK_ERR_ARG;
     if (c->custom) return c->ops.barrier ? c->ops.barrier(c->ops.user) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
+        comm_live(c);
         if (c->nccl) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, c->nccl, c->stream));
-        ZK_HIP(hipStreamSynchronize(c->stream));
+        comm_sync(c);
     });
 }
 /* *value = max over the ranks of *value (the bench's "time of the slowest rank") */
@@ -297,12 +354,13 @@ int zk_comm_max_f64(zk_comm* c, double* value) {
     if (!c || !value) return ZK_ERR_ARG;
     if (c->custom) return c->ops.max_f64 ? c->ops.max_f64(c->ops.user, value) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
+        comm_live(c);
         if (!c->nccl) return;
         double* d = reinterpret_cast<double*>(c->d_flag) + 2;
         ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
         ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, c->nccl, c->stream));
         ZK_HIP(hipMemcpyAsync(value, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        ZK_HIP(hipStreamSynchronize(c->stream));
+        comm_sync(c);
     });
 }
 /* Byte collectives on device buffers, for callers that drive the stages themselves; complete on return. */
@@ -375,10 +433,23 @@ static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, z
 int zk_mgpu_create(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out) {
     if (!ctx || !c || !crs || !qap || !out) return ZK_ERR_ARG;
     if (qap->dense) return ZK_ERR_UNSUPPORTED;
+    // an integer-roots QAP over a powers-only CRS beyond the change of basis proves on one GPU through the sub-product tree only:
+    // refused at creation, not in the middle of the first round
+    if (qap->roots == 1 && !crs->ap && qap->n > zk::basis_max_n()) return ZK_ERR_UNSUPPORTED;
+    if (qap->roots == 2) return ZK_ERR_UNSUPPORTED;
     GpuBackend* gpu = new (std::nothrow) GpuBackend{ctx, crs, qap};
     if (!gpu) return ZK_ERR_HIP;
     zk_mgpu_backend be{gpu, gpu_elems, gpu_alloc, gpu_free, gpu_scalars, gpu_msm, gpu_wait, gpu_combine};
-    return mgpu_create(c, &be, gpu, out);
+    // over RCCL the inner-product streams leave comm_cu_reserve units per XCD to the collectives' kernels (a straggling exchange on
+    // one rank stalls every peer); a lone rank or a caller's transport keeps the whole chip
+    const bool reserve = c->nccl && c->world > 1 && ctx->opt_comm_cu_reserve > 0;
+    if (reserve) {
+        const int rc = comm_guard(c, nullptr, [&] { ctx_reserve_cus(ctx, (int)ctx->opt_comm_cu_reserve); });
+        if (rc != ZK_OK) { delete gpu; return rc; }
+    }
+    const int rc = mgpu_create(c, &be, gpu, out);
+    if (rc == ZK_OK) (*out)->cu_reserved = reserve;
+    return rc;
 }
 int zk_mgpu_create_custom(zk_comm* c, const zk_mgpu_backend* be, zk_mgpu** out) {
     if (!c || !be || !out || !be->elems || !be->alloc || !be->free || !be->scalars_submit || !be->msm_submit || !be->wait || !be->combine) return ZK_ERR_ARG;
@@ -390,6 +461,9 @@ void zk_mgpu_destroy(zk_mgpu* g) {
     if (g->gpu) {   // whatever is still enqueued (released tickets, collectives) must end before the buffers go
         (void)hipSetDevice(g->gpu->ctx->device);
         (void)hipDeviceSynchronize();
+    }
+    if (g->gpu && g->cu_reserved) {
+        try { ctx_reserve_cus(g->gpu->ctx, 0); } catch (...) {}
     }
     for (auto& R : g->rounds) {   // tickets still held
         if (R.t_msm >= 0) (void)g->be.wait(g->be.user, R.t_msm);
@@ -476,7 +550,7 @@ int zk_mgpu_pop(zk_mgpu* g, uint8_t proof_out[ZK_PROOF_BYTES]) {
             ZK_HIP(hipStreamWaitEvent(c->stream, g->ev_msm[e], 0));
             comm_all_to_all(c, g->part_send[set], g->part_recv[set], ZK_PARTIAL_BYTES);
             prove_combine_on(g->gpu->ctx, *g->gpu->crs, g->part_recv[set], world, R.r, R.s, c->stream, g->h_proof);
-            ZK_HIP(hipStreamSynchronize(c->stream));   // the round's one host synchronisation
+            comm_sync(c);   // the round's one host synchronisation (bounded: zk_comm_set_timeout)
             g->rounds.pop_front();
             g->first = k + 1;
             g->gpu->ctx->resolve_profile(-2);

@@ -99,6 +99,8 @@ struct zk_ctx {
     long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges
     long opt_long_division = 0;   // dense form: always use the reference's long division (A/B check of the Newton form)
     long opt_rank_tables = 1;     // multi-GPU scalar exchange: window tables of this rank's point ranges only (prove_msm_submit)
+    long opt_comm_cu_reserve = 1; // multi-GPU exchange over RCCL: compute units per XCD the inner-product streams leave free, so that the collectives' kernels never wait for an accumulation wave to retire (comm.hip, capi.hip ctx_reserve_cus); 0 = none
+    int msm_cu_reserved = 0;      // what the inner-product streams are currently masked to leave free (per XCD)
     // tuning values: fixed in the product build, settable in a ZK_MEASURE build (capi.hip: option_slot)
     long opt_serialize = 0;       // 1: every kernel of a proof on one stream (stand-alone kernel timings)
     long opt_ablate = 0;          // bit 0: reuse the previous sorted list of a workspace (repeated inputs only; prices the sort)
@@ -108,6 +110,7 @@ struct zk_ctx {
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
     long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
+    long opt_interp_large_log = 20; // interp.hip: trees of at least 2^this elements per level take the form that halves the upward transforms
     long opt_quad_buckets = 65536; // inner products of at most this many buckets run their reduction tail with four lanes per addition (msm_quad.hpp)
     std::map<std::string, zk::ProfEntry> prof;
     std::vector<zk::PendingEvent> pending;

@@ -308,7 +308,7 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
     unsigned lg = 0;
     while ((1u << lg) < (unsigned)IB) ++lg;
     const unsigned levels = t.log_npad - lg;
-    if (npad * count < ((size_t)1 << 20)) {
+    if (npad * count < ((size_t)1 << std::min<long>(std::max<long>(ctx->opt_interp_large_log, 0), 40))) {
         // small trees: three more launches per level cost more than a third of its transforms saves -- zero pad and transform at 4s
         for (unsigned l = 0; l < levels; ++l) {
             const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;

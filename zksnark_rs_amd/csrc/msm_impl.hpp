@@ -138,7 +138,13 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, 
 // waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 145 VGPRs) fits 3
 // waves; the G2 body (XYZZ over Fq2: 72 accumulator limbs + the affine point before any temporary)
 // fits 2 with 16 dwords of scratch.
-template <class F> struct AccWaves { static constexpr int value = 3; };
+#ifndef ZK_ACC_G1_LDS
+#define ZK_ACC_G1_LDS 0
+#endif
+#ifndef ZK_ACC_G1_WAVES
+#define ZK_ACC_G1_WAVES 3
+#endif
+template <class F> struct AccWaves { static constexpr int value = ZK_ACC_G1_WAVES; };
 template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 
 // Shape of the accumulation loop per field.  The loop body is ~6 k (G1) / ~19 k (G2) instructions whose register allocation and
@@ -563,7 +569,9 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         {
             ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, st);
-            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), 0, st, tab.table.p + point_offset, ws.sorted.p, d_runs, d_info, d_img);
+            // dynamic LDS nobody touches: an occupancy cap (ZK_ACC_G1_LDS bytes per workgroup; 160 KiB per compute unit) that is independent of
+            // the register budget the kernel is compiled for
+            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), g2 ? 0 : ZK_ACC_G1_LDS, st, tab.table.p + point_offset, ws.sorted.p, d_runs, d_info, d_img);
         }
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     }

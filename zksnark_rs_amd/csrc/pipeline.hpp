@@ -145,6 +145,7 @@ int prove_submit_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* wei
 void prove_wait(zk_ctx*, int ticket, uint8_t* proof_out);
 // stream-ordered use of tickets (comm.hip): the stream a ticket completes on, and release of its slot WITHOUT waiting (h_flag_pinned,
 // may be null: where the witness range flag of a scalars ticket is copied once the ticket is complete)
+void ctx_reserve_cus(zk_ctx*, int per_xcd);   // capi.hip: inner-product streams masked to leave compute units to the collectives
 hipStream_t prove_ticket_stream(zk_ctx*, int ticket);
 void prove_release(zk_ctx*, int ticket, int* h_flag_pinned);
 // prove_combine without the host synchronisation: everything on `st`, the proof lands in h_proof_pinned

@@ -421,6 +421,10 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // change of basis (once per CRS) up to basis_max_n() gates; beyond, it proves in form 2 with the roots 1..n as caller data --
     // the same bytes at half the rate, from ANY CRS.
     int form = q.dense ? 3 : q.roots;
+    // the scalar exchange has no form-2 fallback: refuse the pair HERE, before a round's scalars are produced and exchanged (the inner
+    // products of the round would fail on every rank, mid-pipeline, with the peers inside their collectives -- ADVICE r3)
+    ZK_REQUIRE(!(xout && form == 1 && !crs.ap && q.n > basis_max_n()), ZK_ERR_UNSUPPORTED,
+               "prove: the scalar exchange of an integer-roots QAP over a powers-only CRS needs the change of basis, which stops at 2^16 + 2^10 gates (use a CRS from zk_setup, or prove on one GPU / window-sharded)");
     if (!xout && form == 1 && !crs.ap) {
         if (q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
         else { arb_attach_integer_roots(ctx, const_cast<zk_qap&>(q)); form = 2; }

@@ -73,6 +73,16 @@ class Comm:
     def all_gather(self, d_send, d_recv, bytes_per_rank):
         self._check(self.lib.zk_comm_all_gather(self.ptr, C.c_void_p(d_send), C.c_void_p(d_recv), bytes_per_rank))
 
+    def rccl_ranks(self):
+        """ranks of the RCCL communicator as RCCL counts them (0: none -- one rank, a caller's transport, aborted)"""
+        return int(self.lib.zk_comm_rccl_ranks(self.ptr))
+
+    def set_timeout(self, ms):
+        self._check(self.lib.zk_comm_set_timeout(self.ptr, int(ms)))
+
+    def abort(self):
+        self.lib.zk_comm_abort(self.ptr)
+
     def close(self):
         if getattr(self, "ptr", None):
             self.lib.zk_comm_destroy(self.ptr)
