@@ -144,6 +144,11 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
 }
 int zk_set_option(zk_ctx* ctx, const char* key, long value) {
     if (!ctx || !key) return ZK_ERR_ARG;
+#ifdef ZK_MEASURE
+    // measurement build: mask the inner-product streams NOW (what zk_mgpu_create does over a multi-rank RCCL communicator), so that
+    // tools/rccl_starvation.py can price the reservation on one GPU
+    if (!std::strcmp(key, "apply_cu_reserve")) return guarded(ctx, [&] { zk::ctx_reserve_cus(ctx, (int)value); });
+#endif
     long* s = option_slot(ctx, key);
     if (!s) return ZK_ERR_UNSUPPORTED;
     *s = value;
