@@ -277,17 +277,16 @@ def test_arbitrary_roots_container_limits_and_errors(ctx, tmp_path):
     td_bad = td.copy(); td_bad[4] = roots[9]
     with pytest.raises(zk.ZkError):
         ctx.setup(qap, td_bad)
-    # batches take the other two sparse forms
+    # a batch of one is a proof
     import torch
     d = torch.from_numpy(wts.view(np.int64)).cuda()
-    with pytest.raises(zk.ZkError) as e:
-        ctx.prove_batch_submit(crs, qap, [d.data_ptr()], [m], [r], [s])
-    assert e.value.status == zk._lib.ZK_ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert ctx.prove_batch_wait(ctx.prove_batch_submit(crs, qap, [d.data_ptr()], [m], [r], [s]), 1) == [ctx.prove(crs, qap, wts, r, s)]
 
 
 def test_arbitrary_roots_window_and_point_sharded(ctx):
     """zk_prove_partial for every rank of worlds 1, 2, 3, 8 (partial sums by Pippenger windows and by point ranges) + zk_prove_combine ==
-    zk_prove: the latency form of the multi-GPU prover takes this QAP form as it is (the scalar exchange does not)."""
+    zk_prove: the latency form of the multi-GPU prover takes this QAP form as it is."""
     import torch
     rng = SplitMix64(8200)
     n, m, l = 700, 1500, 2
@@ -312,26 +311,53 @@ def test_arbitrary_roots_window_and_point_sharded(ctx):
         ctx.set_option("msm_shard_points", 0)
 
 
-def test_arbitrary_roots_refused_by_the_scalar_exchange(ctx):
-    """zk_mgpu_* (scalar exchange) takes the roots-of-unity and integer-roots forms: an arbitrary-roots QAP is refused with
-    ZK_ERR_UNSUPPORTED at the first push, and the prover object says so instead of hanging its peers."""
+@pytest.mark.parametrize("n", [100, 700, 5000])
+def test_arbitrary_roots_in_batches_and_in_the_scalar_exchange(ctx, n):
+    """Round 4: the arbitrary-roots form is a first-class citizen of every entry point.  Batches (zk_prove_batch_*: whole, truncated and
+    unsatisfying witnesses in one batch, two batches in flight) and the scalar exchange (zk_prove_scalars_submit -> all-to-all by
+    slicing -> zk_prove_msm_submit per rank over the rank's own window tables -> zk_prove_combine) at worlds 1, 2, 3, 8, all ranks played
+    by one device; then the C pipeline (zk_mgpu_*) at world 1.  Every proof == zk_prove's bytes (which the oracle pins above)."""
     import torch
     from zksnark_rs_amd.distributed import Comm, MgpuProver
-    rng = SplitMix64(8300)
-    n, m, l = 100, 220, 2
+    rng = SplitMix64(8300 + n)
+    m, l = 2 * n + 20, 2
     roots = ints_to_limbs(distinct_roots(rng, n)).reshape(n, 4)
     u, v, w = (random_rows(rng, n, m, 3) for _ in range(3))
     qap = ctx.qap_sparse_roots(roots, m, l, u, v, w)
     crs = ctx.setup(qap, ints_to_limbs([rng.fr() for _ in range(5)]))
-    wts = ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)])
-    dw = torch.from_numpy(wts.view(np.int64)).cuda()
+    proofs = [(ints_to_limbs([1] + [rng.fr() for _ in range(m - 1)]), rng.fr(), rng.fr()),
+              (ints_to_limbs([1] + [rng.fr() for _ in range(m - 4)]), rng.fr(), rng.fr()),     # truncated (zip, mod.rs:233-253)
+              (ints_to_limbs([1] + [rng.next() & 1 for _ in range(m - 1)]), rng.fr(), rng.fr())]  # boolean: heavy buckets
+    want = [ctx.prove(crs, qap, wt, r, s) for wt, r, s in proofs]
+    dws = [torch.from_numpy(np.ascontiguousarray(wt).view(np.int64)).cuda() for wt, _, _ in proofs]
+    torch.cuda.synchronize()
+    # batches
+    args = lambda idx: ([dws[j].data_ptr() for j in idx], [proofs[j][0].shape[0] for j in idx], [proofs[j][1] for j in idx], [proofs[j][2] for j in idx])   # noqa: E731
+    t1 = ctx.prove_batch_submit(crs, qap, *args([0, 1, 2]))
+    t2 = ctx.prove_batch_submit(crs, qap, *args([2, 0]))
+    assert ctx.prove_batch_wait(t1, 3) == want and ctx.prove_batch_wait(t2, 2) == [want[2], want[0]]
+    # the scalar exchange, rank by rank
+    for world in (1, 2, 3, 8):
+        elems = ctx.prove_exchange_elems(qap, world)
+        assert all(e % world == 0 for e in elems) and elems[1] >= n and elems[3] >= 2 * n - 1
+        send = [[torch.zeros(32 * e, dtype=torch.uint8, device="cuda") for e in elems] for _ in proofs]
+        for j, (wt, r, s) in enumerate(proofs):
+            ctx.prove_wait(ctx.prove_scalars_submit(crs, qap, dws[j].data_ptr(), wt.shape[0], r, s, world, [x.data_ptr() for x in send[j]]), partial=True)
+        blobs = [[None] * world for _ in proofs]
+        for g in range(world):
+            recv = []
+            for k, e in enumerate(elems):
+                c = 32 * e // world
+                recv.append(torch.cat([send[j][k][g * c:(g + 1) * c] for j in range(len(proofs))]))
+            part = torch.zeros(len(proofs) * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            ctx.prove_wait(ctx.prove_msm_submit(crs, qap, len(proofs), g, world, [x.data_ptr() for x in recv], part.data_ptr()), partial=True)
+            for j in range(len(proofs)):
+                blobs[j][g] = part[j * zk.PARTIAL_BYTES:(j + 1) * zk.PARTIAL_BYTES].clone()
+        for j, (wt, r, s) in enumerate(proofs):
+            assert ctx.prove_combine(crs, torch.cat(blobs[j]).data_ptr(), world, r, s) == want[j], (world, j)
     comm = Comm(ctx, 0, 1)
-    try:
-        with pytest.raises(zk.ZkError) as e:
-            mp = MgpuProver(ctx, comm, crs, qap)
-            mp.push(dw.data_ptr(), m, 5, 7)
-            mp.pop()
-        assert e.value.status == zk._lib.ZK_ERR_UNSUPPORTED
-    finally:
-        comm.close()
-    assert ctx.prove(crs, qap, wts, 5, 7)      # the context is still usable
+    mp = MgpuProver(ctx, comm, crs, qap)
+    jobs = [(dws[j].data_ptr(), proofs[j][0].shape[0], proofs[j][1], proofs[j][2]) for j in (0, 1, 2, 0)]
+    assert list(mp.prove_stream(jobs, ahead=2)) == [want[0], want[1], want[2], want[0]]
+    mp.close()
+    comm.close()

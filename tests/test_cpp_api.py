@@ -126,7 +126,23 @@ dw = torch.from_numpy(np.ascontiguousarray(wts).view(np.int64)).cuda(); torch.cu
 mp = MgpuProver(ctx, comm, crs, qap)
 got = list(mp.prove_stream([(dw.data_ptr(), m, r, s)] * 4, ahead=2))
 assert got == [want] * 4
-mp.close(); comm.close()
+mp.close()
+assert comm.rccl_ranks() == 1
+# option comm_cu_reserve: over an RCCL communicator the inner-product streams leave compute units to the collectives; same bytes,
+# and zk_mgpu_destroy gives the streams the whole chip back (a lone prove afterwards still works)
+ctx.set_option("comm_cu_reserve", 2)
+mp = MgpuProver(ctx, comm, crs, qap)
+assert list(mp.prove_stream([(dw.data_ptr(), m, r, s)] * 3, ahead=2)) == [want] * 3
+mp.close()
+assert ctx.prove(crs, qap, wts, r, s) == want
+comm.set_timeout(5000)
+comm.abort()
+try:
+    comm.barrier()
+    raise SystemExit("an aborted communicator answered a collective")
+except zk.ZkError as e:
+    assert e.status == zk._lib.ZK_ERR_COMM
+comm.close()
 print("ok rccl world 1")
 """
     res = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)

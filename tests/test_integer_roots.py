@@ -281,7 +281,21 @@ def test_gpu_uploaded_crs_beyond_the_change_of_basis(ctx, orc):
     assert ctx.prove(up, qap, weights, r, s) == want
     assert ctx.prove(crs, qap, weights, r, s) == want
     bad = weights.copy(); bad[n // 3, 0] ^= np.uint64(1)
-    assert ctx.prove(up, qap, bad, r, s) == orc.trapdoor_proof_integers(desc, n, td, bad, r, s)
+    want_bad = orc.trapdoor_proof_integers(desc, n, td, bad, r, s)
+    assert ctx.prove(up, qap, bad, r, s) == want_bad
+    # round 4: every entry point decides the form in one place (prove_form) -- a batch and the multi-GPU pipeline over the uploaded CRS
+    # take the same fall-back and give the same bytes (they used to answer ZK_ERR_UNSUPPORTED after the scalars had been exchanged)
+    torch = pytest.importorskip("torch")
+    from zksnark_rs_amd.distributed import Comm, MgpuProver
+    dw, db = (torch.from_numpy(np.ascontiguousarray(x_).view(np.int64)).cuda() for x_ in (weights, bad))
+    torch.cuda.synchronize()
+    t = ctx.prove_batch_submit(up, qap, [dw.data_ptr(), db.data_ptr()], [m, m], [r, r], [s, s])
+    assert ctx.prove_batch_wait(t, 2) == [want, want_bad]
+    comm = Comm(ctx, 0, 1)
+    mp = MgpuProver(ctx, comm, up, qap)
+    assert list(mp.prove_stream([(dw.data_ptr(), m, r, s), (db.data_ptr(), m, r, s)], ahead=1)) == [want, want_bad]
+    mp.close()
+    comm.close()
 
 
 @pytest.mark.gpu

@@ -433,16 +433,12 @@ static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, z
 int zk_mgpu_create(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap, zk_mgpu** out) {
     if (!ctx || !c || !crs || !qap || !out) return ZK_ERR_ARG;
     if (qap->dense) return ZK_ERR_UNSUPPORTED;
-    // an integer-roots QAP over a powers-only CRS beyond the change of basis proves on one GPU through the sub-product tree only:
-    // refused at creation, not in the middle of the first round
-    if (qap->roots == 1 && !crs->ap && qap->n > zk::basis_max_n()) return ZK_ERR_UNSUPPORTED;
-    if (qap->roots == 2) return ZK_ERR_UNSUPPORTED;
     GpuBackend* gpu = new (std::nothrow) GpuBackend{ctx, crs, qap};
     if (!gpu) return ZK_ERR_HIP;
     zk_mgpu_backend be{gpu, gpu_elems, gpu_alloc, gpu_free, gpu_scalars, gpu_msm, gpu_wait, gpu_combine};
     // over RCCL the inner-product streams leave comm_cu_reserve units per XCD to the collectives' kernels (a straggling exchange on
     // one rank stalls every peer); a lone rank or a caller's transport keeps the whole chip
-    const bool reserve = c->nccl && c->world > 1 && ctx->opt_comm_cu_reserve > 0;
+    const bool reserve = c->nccl && ctx->opt_comm_cu_reserve > 0;   // an RCCL communicator (several ranks, or one with ZK_COMM_FORCE_RCCL)
     if (reserve) {
         const int rc = comm_guard(c, nullptr, [&] { ctx_reserve_cus(ctx, (int)ctx->opt_comm_cu_reserve); });
         if (rc != ZK_OK) { delete gpu; return rc; }

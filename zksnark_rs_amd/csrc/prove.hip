@@ -194,6 +194,7 @@ struct ProveSlot {
     // pass for both): uv = V | U evaluations / coefficients, uvg = V | U on the coset, xy = U.V on <w> | on g<w>; each half
     // holds `count` vectors of n elements (count = 1 outside batches)
     DevBuf<Fr> uv, uvg, xy;
+    DevBuf<Fr> arb_vals, arb_work;   // form 2 (arbitrary roots): SpMV outputs U | V, scratch of the interpolation
     MsmWorkspace ws[zk_ctx::MSM_STREAMS];
     DevBuf<MsmResults> ms;
     DevBuf<AssembleScratch> as;
@@ -359,6 +360,68 @@ static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr&
     ZK_HIP(hipGetLastError());
 }
 
+// The form a proof over (crs, q) takes, decided in ONE place for every entry point (a single proof, a batch, the scalars and the
+// inner products of the multi-GPU exchange -- ADVICE r3: they used to differ):
+//   0 roots of unity, 1 integer roots in the evaluation basis, 2 coefficients by the sub-product tree (arbroots.hip), 3 dense.
+// An integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1) gets the Lagrange-basis points by the change
+// of basis, once per CRS, up to basis_max_n() gates; beyond, it proves in form 2 with the roots 1..n as caller data -- the same bytes
+// from ANY CRS.  One-off tables of forms 2 / 3 (the power-series inverse of rev(t)) are built here, before anything is enqueued.
+static int prove_form(zk_ctx* ctx, zk_crs& crs, const zk_qap& q) {
+    int form = q.dense ? 3 : q.roots;
+    if (form == 1 && !crs.ap) {
+        if (q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
+        else { arb_attach_integer_roots(ctx, const_cast<zk_qap&>(q)); form = 2; }
+    }
+    if (form >= 2 && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
+        unsigned lc0 = 1;
+        while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
+        qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
+    }
+    return form;
+}
+
+// Form 2, one proof: the SpMV outputs (values of U, V on the caller's roots) are interpolated by the sub-product tree, A and B take the
+// coefficients, h is the quotient of U V by t.  vc_can / uc_can: n canonical scalars each; hb_can: h (n - 1) | r v + s u (n).
+// `uv_ready` is called when uc_can and vc_can exist (their inner products can start while the quotient is computed).
+template <class Ready>
+static void arb_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, const Fr* a_mont, size_t a_len, const Fr& r_mont, const Fr& s_mont,
+                             Fr* vc_can, Fr* uc_can, Fr* hb_can, Ready&& uv_ready) {
+    const size_t n = q.n;
+    hipStream_t st = ctx->stream;
+    unsigned lc = 1;
+    while (((size_t)1 << lc) < 2 * n) ++lc;
+    const size_t nc = (size_t)1 << lc;
+    S.ue.ensure(n); S.ve.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
+    S.arb_vals.ensure(2 * n); S.arb_work.ensure(arb_work_elems(q));
+    // W is not needed: U V = h t + E with E = the interpolant of U_k V_k (degree < n), so the quotient of U V alone is h.
+    spmv(ctx, q.u_gate, a_mont, a_len, S.arb_vals.p);
+    spmv(ctx, q.v_gate, a_mont, a_len, S.arb_vals.p + n);
+    arb_coefficients(ctx, q, S.arb_vals.p, S.arb_work.p, S.ue.p, S.ve.p);
+    fr_from_mont(ctx, S.ue.p, uc_can, n);
+    fr_from_mont(ctx, S.ve.p, vc_can, n);
+    uv_ready();
+    fr_lincomb_to_canonical(ctx, S.ve.p, r_mont, S.ue.p, s_mont, hb_can + (n - 1), n);   // bases: xi_t (n-1) | xi (n)
+    ZK_HIP(hipMemsetAsync(S.prod_a.p, 0, nc * sizeof(Fr), st));
+    ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
+    ZK_HIP(hipMemcpyAsync(S.prod_a.p, S.ue.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ZK_HIP(hipMemcpyAsync(S.prod_b.p, S.ve.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    ntt_dif(ctx, S.prod_a.p, lc, false, false);
+    ntt_dif(ctx, S.prod_b.p, lc, false, false);
+    fr_pointwise_mul(ctx, S.prod_a.p, S.prod_b.p, S.prod_a.p, nc);
+    ntt_dit(ctx, S.prod_a.p, lc, true, true, nullptr);                // U*V coefficients, natural order
+    ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
+    const size_t len_r = 2 * n - 1, d = q.t_degree;                   // t is monic of degree n: n - 1 quotient coefficients
+    if (len_r > d) {
+        if (len_r - d >= 512 && !ctx->opt_long_division) {
+            S.div_work.ensure(nc);
+            poly_divide_newton(ctx, q, S.prod_a.p, len_r, lc, S.div_work.p, S.prod_b.p);
+        } else {
+            poly_divide(ctx, S.prod_a.p, len_r, q.dt.p, d, q.t_cinv.p, S.prod_b.p);
+        }
+    }
+    if (n > 1) fr_from_mont(ctx, S.prod_b.p, hb_can, n - 1);
+}
+
 // SpMV / NTT stage of one proof in the roots-of-unity form: the scalars of the inner products B2 (vc), A (uc) and
 // H + r B1 + s A (hb: h | r v + s u) from the Montgomery-form witness in S.a_mont.  `launch(k, after, scalars, count)`
 // is called as soon as the scalars of product k exist (k = MSM stream: 1 L, 0 B2, 2 A, 4 HB).
@@ -415,29 +478,12 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
     // one-off table construction happens before anything of this proof is enqueued
     // an integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1): change of basis, once per CRS
-    ZK_REQUIRE(!(q.roots == 2 && xout), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange takes the roots-of-unity and integer-roots forms (an arbitrary-roots QAP proves on one GPU, or window-sharded)");
-    // The form this proof takes: 0 roots of unity, 1 integer roots in the evaluation basis, 2 coefficients by the sub-product tree
-    // (arbroots.hip), 3 dense.  An integer-roots QAP over a CRS that carries only the powers gets the Lagrange-basis points by the
-    // change of basis (once per CRS) up to basis_max_n() gates; beyond, it proves in form 2 with the roots 1..n as caller data --
-    // the same bytes at half the rate, from ANY CRS.
-    int form = q.dense ? 3 : q.roots;
-    // the scalar exchange has no form-2 fallback: refuse the pair HERE, before a round's scalars are produced and exchanged (the inner
-    // products of the round would fail on every rank, mid-pipeline, with the peers inside their collectives -- ADVICE r3)
-    ZK_REQUIRE(!(xout && form == 1 && !crs.ap && q.n > basis_max_n()), ZK_ERR_UNSUPPORTED,
-               "prove: the scalar exchange of an integer-roots QAP over a powers-only CRS needs the change of basis, which stops at 2^16 + 2^10 gates (use a CRS from zk_setup, or prove on one GPU / window-sharded)");
-    if (!xout && form == 1 && !crs.ap) {
-        if (q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
-        else { arb_attach_integer_roots(ctx, const_cast<zk_qap&>(q)); form = 2; }
-    }
+    int form = prove_form(ctx, crs, q);
+    ZK_REQUIRE(!(form == 3 && xout), ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs a sparse QAP form");
     if (xout) {}   // scalars only: no inner product, no table (the ranks of a scalar exchange build only their own slices)
     else if (form >= 2) crs_ensure_tables(ctx, crs, false, 0);   // coefficient forms: the reference's [x^i], natural order
     else if (form == 1) crs_ensure_tables(ctx, crs, false, 0, true);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
-    if (form >= 2 && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
-        unsigned lc0 = 1;
-        while (((size_t)1 << lc0) < 2 * q.n) ++lc0;
-        qap_ensure_tinv(ctx, const_cast<zk_qap&>(q), 2 * q.n - 1 - q.t_degree, lc0);
-    }
     if (!d_partial_out && !xout) crs_ensure_fixed_tables(ctx, crs);
 
     const size_t n = q.n, m = q.m, l = q.input;
@@ -560,25 +606,41 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
                                 else if (k == 2) launch(2, after, crs.t_xi1, scalars, count, &ms->a);      // A
                                 else launch(4, after, crs.t_hb1, scalars, count, &ms->hb);                // H + r B1 + s A: last in the chain
                             });
+    } else if (form == 2) {
+        // sparse rows over the caller's roots (arbroots.hip), or an integer-roots QAP over a powers-only CRS beyond the change of basis
+        Fr *vc_can, *uc_can, *hb_can;
+        if (xout) {
+            // exchange layout: `world` equal chunks per product, zero scalars behind the last point
+            const ExchangeDims xd = exchange_dims(q, world);
+            vc_can = xout[1]; uc_can = xout[2]; hb_can = xout[3];
+            ZK_HIP(hipMemsetAsync(xout[0], 0, xd.cl * world * sizeof(Fr), st));
+            if (n_l) ZK_HIP(hipMemcpyAsync(xout[0], d_weights + l + 1, n_l * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+            if (xd.cn * world > n) {
+                ZK_HIP(hipMemsetAsync(vc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+                ZK_HIP(hipMemsetAsync(uc_can + n, 0, (xd.cn * world - n) * sizeof(Fr), st));
+            }
+            ZK_HIP(hipMemsetAsync(hb_can + (2 * n - 1), 0, (xd.ch * world - (2 * n - 1)) * sizeof(Fr), st));
+        } else {
+            S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
+            vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
+        }
+        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        arb_scalar_stage(ctx, S, q, S.a_mont.p, a_len, r_mont, s_mont, vc_can, uc_can, hb_can, [&] {
+            launch(2, 1, crs.t_xi1, uc_can, n, &ms->a);
+            launch(0, 2, crs.t_xi2, vc_can, n, &ms->b2);
+        });
+        launch(4, 0, crs.t_hb1, hb_can, 2 * n - 1, &ms->hb);
     } else {
+        // dense form: the literal coefficient matrices of QAP<CoefficientPoly>
         unsigned lc = 1;
         while (((size_t)1 << lc) < 2 * n) ++lc;
         size_t nc = (size_t)1 << lc;
         S.ue.ensure(n); S.ve.ensure(n); S.wc.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
         S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        if (q.dense) {
-            dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
-            dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
-            dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
-        } else {
-            // sparse rows over the caller's roots (arbroots.hip): the values of U, V on the roots, interpolated by the sub-product tree.
-            // W is not needed: U V = h t + E with E = the interpolant of U_k V_k (degree < n), so the quotient of U V alone is h.
-            S.uv.ensure(2 * n); S.xy.ensure(arb_work_elems(q));
-            spmv(ctx, q.u_gate, S.a_mont.p, a_len, S.uv.p);
-            spmv(ctx, q.v_gate, S.a_mont.p, a_len, S.uv.p + n);
-            arb_coefficients(ctx, q, S.uv.p, S.xy.p, S.ue.p, S.ve.p);
-        }
+        dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
+        dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
+        dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
         fr_from_mont(ctx, S.ue.p, S.uc_can.p, n);
         fr_from_mont(ctx, S.ve.p, S.vc_can.p, n);
         launch(2, 1, crs.t_xi1, S.uc_can.p, n, &ms->a);
@@ -592,7 +654,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ntt_dif(ctx, S.prod_b.p, lc, false, false);
         fr_pointwise_mul(ctx, S.prod_a.p, S.prod_b.p, S.prod_a.p, nc);
         ntt_dit(ctx, S.prod_a.p, lc, true, true, nullptr);                // U*V coefficients, natural order
-        if (q.dense) fr_sub_inplace(ctx, S.prod_a.p, S.wc.p, n);          // - W
+        fr_sub_inplace(ctx, S.prod_a.p, S.wc.p, n);                       // - W
         // quotient by t (degree d); remainder dropped (coefficient_poly.rs:148-157)
         ZK_HIP(hipMemsetAsync(S.prod_b.p, 0, nc * sizeof(Fr), st));
         size_t len_r = 2 * n - 1, d = q.t_degree;
@@ -651,7 +713,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
                      const Fr* d_l, const Fr* d_vc, const Fr* d_uc, const Fr* d_hb, void* d_partials_out) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense && q.roots != 2, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange takes the roots-of-unity and integer-roots forms");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: the scalar exchange needs a sparse QAP form");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
@@ -659,9 +721,12 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     const ExchangeDims xd = exchange_dims(q, world);
     // world > 1: tables of this rank's point ranges only (option rank_tables; 0 = slices of the full tables, as a lone prover has them)
     const bool rt = world > 1 && ctx->opt_rank_tables;
-    if (q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
-    if (rt) crs_ensure_rank_tables(ctx, crs, !q.roots, q.log_n, q.roots != 0, rank, world, xd.cl, xd.cn, xd.ch);
-    else if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true);
+    // the bases follow the form the scalars were made in (prove_form: the same decision as in the scalars stage): bit-reversed powers
+    // (0), Lagrange-basis points (1), the reference's own powers in natural order (2)
+    const int form = prove_form(ctx, crs, q);
+    if (rt) crs_ensure_rank_tables(ctx, crs, form == 0, q.log_n, form == 1, rank, world, xd.cl, xd.cn, xd.ch);
+    else if (form == 1) crs_ensure_tables(ctx, crs, false, 0, true);
+    else if (form == 2) crs_ensure_tables(ctx, crs, false, 0);
     else crs_ensure_tables(ctx, crs, true, q.log_n);
     StreamSwap swap_guard(ctx, (ticket & 1) ? ctx->main_alt : ctx->stream);
     hipStream_t st = ctx->stream;
@@ -723,14 +788,16 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
                        const uint64_t* r, const uint64_t* s) {
     zk_crs& crs = const_cast<zk_crs&>(crs_c);
     ZK_REQUIRE(crs.n == q.n && crs.m == q.m && crs.input == q.input, ZK_ERR_ARG, "prove: CRS and QAP dimensions differ");
-    ZK_REQUIRE(!q.dense && q.roots != 2, ZK_ERR_UNSUPPORTED, "prove: batches take the roots-of-unity and integer-roots forms");
+    ZK_REQUIRE(!q.dense, ZK_ERR_UNSUPPORTED, "prove: batches take the sparse QAP forms");
     ZK_REQUIRE(count >= 1 && count <= ZK_MAX_BATCH, ZK_ERR_ARG, "prove: batch size out of range");
     ProveState& ps = prove_state(ctx);
     const int ticket = ps.next;
     ProveSlot& S = ps.slot[ticket];
     ZK_REQUIRE(!S.busy, ZK_ERR_ARG, "prove: too many proofs in flight (call zk_prove_wait first)");
-    if (q.roots && !crs.ap) crs_lagrange_from_powers(ctx, crs, q);
-    if (q.roots) crs_ensure_tables(ctx, crs, false, 0, true); else crs_ensure_tables(ctx, crs, true, q.log_n);
+    const int form = prove_form(ctx, crs, q);
+    if (form == 1) crs_ensure_tables(ctx, crs, false, 0, true);
+    else if (form == 2) crs_ensure_tables(ctx, crs, false, 0);
+    else crs_ensure_tables(ctx, crs, true, q.log_n);
     crs_ensure_fixed_tables(ctx, crs);
     if (!S.h_b_proofs) {
         ZK_HIP(hipHostMalloc((void**)&S.h_b_proofs, (size_t)ZK_MAX_BATCH * ZK_PROOF_BYTES));
@@ -783,7 +850,22 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         if (n_l[j]) ZK_HIP(hipMemcpyAsync(S.bx_l.p + (size_t)j * cl, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     }
     launch(1, -1, crs.t_sum_delta1, S.bx_l.p, cl, nl, &ms->l);
-    if (q.roots) {
+    if (form == 2) {
+        // arbitrary roots (arbroots.hip): every proof interpolates its own U, V (the tree's transforms are per proof); the inner products
+        // of the batch run grouped like those of the other forms
+        const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
+        S.a_mont.ensure(amax * cnt);
+        ZK_HIP(hipMemsetAsync(S.bx_h.p, 0, 2 * n * cnt * sizeof(Fr), st));
+        for (size_t j = 0; j < cnt; ++j) {
+            Fr* a_mont = S.a_mont.p + j * amax;
+            fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
+            arb_scalar_stage(ctx, S, q, a_mont, a_len[j], Fr::from_canonical(S.h_b_rs[2 * j]), Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+                             S.bx_v.p + j * n, S.bx_u.p + j * n, S.bx_h.p + j * 2 * n, [] {});
+        }
+        launch(2, 1, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
+        launch(0, 2, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
+        launch(4, 0, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n - 1, &ms->hb);      // bases: xi_t (n-1) | xi (n); group stride 2n
+    } else if (form == 1) {
         // integer roots (aproots.hip): evaluation values as scalars of A and B, h on {n+1..2n-1} by one batched convolution
         const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1), M = (size_t)1 << q.ap->log_m;
         S.uv.ensure(2 * n * cnt); S.xy.ensure(3 * M * cnt); S.a_mont.ensure(amax * cnt);
