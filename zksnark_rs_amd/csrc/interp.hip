@@ -24,6 +24,7 @@
 #include <vector>
 #include "pipeline.hpp"
 #include "interp.hpp"
+#include "lazy29.cuh"
 
 namespace zk {
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(INTERP_BLOCK) void k_interp_weights(const Fr* __res
 __global__ void k_interp_scale_q(Fr* __restrict__ qmat, const Fr* __restrict__ w, size_t n, size_t npad) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= npad * IB) return;
-    const size_t blk = g / ((size_t)IB * IB), k = g % IB, leaf = blk * IB + k;
+    const size_t blk = g / ((size_t)IB * IB), k = (g / IB) % IB, leaf = blk * IB + k;   // layout q[block][k][i]
     if (leaf < n) qmat[g] = qmat[g] * w[leaf];
 }
 
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(INTERP_BLOCK) void k_interp_blocks(const Fr* __rest
         ++deg;
     }
     Fr* q = qmat + blk * (size_t)IB * IB;
-    for (int i = 0; i < IB; ++i) q[(size_t)i * IB + k] = (k < real && i <= deg) ? c[i] : Fr::zero();
+    // stored as q[block][k][i]: the lanes of k_interp_bottom (one per output coefficient i) read consecutive elements
+    for (int i = 0; i < IB; ++i) q[(size_t)k * IB + i] = (k < real && i <= deg) ? c[i] : Fr::zero();
     if (k == 0) {
         Fr* out = node + blk * (size_t)(2 * IB);
         if (real == 0) {
@@ -179,17 +181,36 @@ __global__ void k_interp_mul_pairs(const Fr* __restrict__ node, size_t s2, size_
 }
 
 // ---- per proof --------------------------------------------------------------------------------------------------------------
-// P of the bottom blocks: out[v][blk IB + i] = sum_k values[v][blk IB + k] q[blk][i][k]   (values beyond n are not read)
-__global__ void k_interp_bottom(const Fr* __restrict__ values, size_t vstride, const Fr* __restrict__ qmat, size_t n, size_t npad, Fr* __restrict__ out) {
+// P of the bottom blocks: out[v][blk IB + i] = sum_k values[v][blk IB + k] q[blk][k][i]   (values beyond n are not read).
+// One lane per output coefficient serves all CNT vectors of the launch, so the matrix (64 x 32 B per coefficient: 2.1 GB at 2^20
+// leaves) is read once, coalesced; the sums run in the lazy radix-2^29 form of lazy29.cuh -- two products per Montgomery reduction
+// (mont_sum), limb-wise accumulation, one closing multiplication by 1 that contracts the sum before it is stored exactly.
+// (Round 3: one launch row per vector, rows of q strided by 2 KB across the lanes, 8 x 32 multiplications: 2.3 ms per 2^20-gate proof.)
+template <int CNT>
+__global__ __launch_bounds__(256) void k_interp_bottom(const Fr* __restrict__ values, size_t vstride, int v0, const Fr* __restrict__ qmat, size_t n, size_t npad,
+                                                       Fr* __restrict__ out) {
+    typedef FpR<FrParams> L;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= npad) return;
-    const size_t blk = g / IB, base = blk * IB;
-    const Fr* f = values + (size_t)blockIdx.y * vstride + base;
-    const Fr* q = qmat + g * IB;
+    const size_t blk = g / IB, base = blk * IB, i = g - base;
+    const Fr* q = qmat + base * IB + i;
     const int real = (int)(base >= n ? 0 : (n - base < (size_t)IB ? n - base : IB));
-    Fr acc = Fr::zero();
-    for (int k = 0; k < real; ++k) acc = acc + f[k] * q[k];
-    out[(size_t)blockIdx.y * npad + g] = acc;
+    L acc[CNT];
+#pragma unroll
+    for (int v = 0; v < CNT; ++v) acc[v] = L::load(Fr::zero());
+    for (int k = 0; k < real; k += 2) {
+        const bool two = k + 1 < real;
+        const L q0 = L::load(q[(size_t)k * IB]), q1 = two ? L::load(q[(size_t)(k + 1) * IB]) : L::load(Fr::zero());
+#pragma unroll
+        for (int v = 0; v < CNT; ++v) {
+            const Fr* f = values + (size_t)(v0 + v) * vstride + base;
+            const L f0 = L::load(f[k]), f1 = two ? L::load(f[k + 1]) : L::load(Fr::zero());
+            acc[v] = (acc[v] + L::mont_sum(f0, q0, f1, q1)).norm();       // <= 32 terms of |value| < 3p: limbs stay in range
+        }
+    }
+    const L one = L::load(Fr::one());
+#pragma unroll
+    for (int v = 0; v < CNT; ++v) out[(size_t)(v0 + v) * npad + g] = (acc[v] * one).store_exact();
 }
 // children (size s, contiguous) -> zero padded to 2s
 __global__ void k_interp_pad(const Fr* __restrict__ cur, size_t s, size_t total2, Fr* __restrict__ tmp) {
@@ -199,13 +220,17 @@ __global__ void k_interp_pad(const Fr* __restrict__ cur, size_t s, size_t total2
     tmp[g] = j < s ? cur[c * s + j] : Fr::zero();
 }
 // out[v][p][j] = P_l[j] N_r[j] + P_r[j] N_l[j], j < 2s; nev: the images of the level's children N (same order), shared by the vectors
-__global__ void k_interp_combine(const Fr* __restrict__ tmp, const Fr* __restrict__ nev, size_t s2, size_t parents, Fr* __restrict__ out) {
+// keep: the result is also left in the left child's slot of tmp -- the first half of the parent's image at twice the size, i.e. what
+// k_interp_half(.., 0, ..) would copy there (only this lane reads or writes those two slots, so the update in place is safe)
+__global__ void k_interp_combine(Fr* tmp, const Fr* __restrict__ nev, size_t s2, size_t parents, Fr* __restrict__ out, bool keep) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= parents * s2) return;
     const size_t p = g / s2, j = g - p * s2;
-    const Fr* t = tmp + (size_t)blockIdx.y * parents * 2 * s2;
+    Fr* t = tmp + (size_t)blockIdx.y * parents * 2 * s2;
     const size_t l = (2 * p) * s2 + j, r = (2 * p + 1) * s2 + j;
-    out[(size_t)blockIdx.y * parents * s2 + g] = t[l] * nev[r] + t[r] * nev[l];
+    const Fr v = t[l] * nev[r] + t[r] * nev[l];
+    out[(size_t)blockIdx.y * parents * s2 + g] = v;
+    if (keep) t[l] = v;
 }
 
 // The image (DIF order, 4s points) of a parent's 2s coefficients zero padded to 4s is [its 2s-point image | the 2s-point image of the
@@ -304,7 +329,10 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
     Fr* cur = d_out;                      // count x npad
     Fr* tmp = d_work;                     // count x 2 npad
     Fr* alt = d_work + 2 * count * npad;  // count x npad
-    hipLaunchKernelGGL(k_interp_bottom, dim3(ceil_div(npad, 256), count), dim3(256), 0, st, d_values, vstride, t.qmat.p, n, npad, cur);
+    for (size_t v = 0; v < count; v += 2) {
+        if (count - v >= 2) hipLaunchKernelGGL(k_interp_bottom<2>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, d_values, vstride, (int)v, t.qmat.p, n, npad, cur);
+        else hipLaunchKernelGGL(k_interp_bottom<1>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, d_values, vstride, (int)v, t.qmat.p, n, npad, cur);
+    }
     unsigned lg = 0;
     while ((1u << lg) < (unsigned)IB) ++lg;
     const unsigned levels = t.log_npad - lg;
@@ -315,7 +343,7 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
             hipLaunchKernelGGL(k_interp_pad, dim3(ceil_div(2 * npad * count, 256)), dim3(256), 0, st, cur, s, 2 * npad * count, tmp);
             ntt_dif(ctx, tmp, lg + l + 1, false, false, children * count);
             Fr* nxt = cur == d_out ? alt : d_out;
-            hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, nxt);
+            hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, nxt, false);
             ntt_dit(ctx, nxt, lg + l + 1, true, true, nullptr, parents * count);
             cur = nxt;
         }
@@ -329,8 +357,7 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
     }
     for (unsigned l = 0; l < levels; ++l) {
         const size_t s2 = (size_t)IB << (l + 1), parents = npad / s2, total = npad * count;
-        hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, alt);   // parents' images, 2s points
-        if (l + 1 < levels) hipLaunchKernelGGL(k_interp_half, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, s2, total, 0, tmp);
+        hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, alt, l + 1 < levels);   // parents' images, 2s points (+ the first half of their 4s-point images, in place)
         ntt_dit(ctx, alt, lg + l + 1, true, true, nullptr, parents * count);          // their coefficients
         if (l + 1 == levels) break;
         hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tw.p, s2, npad / s2, total);

@@ -205,6 +205,16 @@ struct FpR {
         return r;
 #endif
     }
+    // (a*b + c*d) * 2^-261 mod p with one reduction; bounds as mont_diff
+    ZK_HD static FpR mont_sum(const FpR& a, const FpR& b, const FpR& c, const FpR& d) {
+#if ZK_MONT_ASM_ON
+        FpR o;
+        mont_asm_sum<PR>(o.v, a.v, b.v, c.v, d.v);
+        return o;
+#else
+        return mont_diff(a, b, c.neg(), d);
+#endif
+    }
     ZK_HD FpR operator*(const FpR& b) const { return mont<false>(*this, b); }
     ZK_HD FpR sqr() const { return mont<true>(*this, *this); }
 
