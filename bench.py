@@ -311,6 +311,9 @@ def main():
     ap.add_argument("--latency", action="store_true",
                     help="one proof at a time (--depth 1), no per-kernel event timing (two extra API calls per launch, which small "
                          "circuits feel), no CPU baseline: ms_per_step is the latency of a lone zk_prove_dev call")
+    ap.add_argument("--lone-graph", action="store_true",
+                    help="with --latency: option lone_graph -- a lone proof replays one captured hipGraph (witness through the slot's buffer, "
+                         "(r, s) and blinding factors through a device-side parameter block)")
     ap.add_argument("--cpu-baseline", choices=["default", "full"], default="default",
                     help="full: also the same-algorithm CPU path at 2^20 on ONE thread (minutes)")
     args = ap.parse_args()
@@ -396,6 +399,8 @@ def main():
         return x
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
+    if args.lone_graph:
+        ctx.set_option("lone_graph", 1)
     if (args.serialize or args.opt) and ctx.get_option("measure_build") != 1:
         raise SystemExit("--serialize / --opt are measurement switches: load the ZK_MEASURE build (make -C zksnark_rs_amd/csrc measure; "
                          "ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so)")

@@ -725,3 +725,48 @@ def test_division_by_zero_polynomial(ctx):
     with pytest.raises(zk.ZkError) as e:
         ctx.setup(qap, ints_to_limbs([2, 3, 0, 5, 6]))           # gamma == 0: `/ gamma` panics (fr.rs:54)
     assert e.value.status == zk._lib.ZK_ERR_DIV_BY_ZERO
+
+
+@pytest.mark.parametrize("log_n,roots", [(4, "unity"), (10, "unity"), (16, "unity")])
+def test_lone_proofs_replayed_from_a_captured_graph(log_n, roots):
+    """Option lone_graph: a synchronous zk_prove_dev of a (CRS, QAP, witness length) seen before replays ONE captured hipGraph -- the
+    witness goes through the slot's own buffer, (r, s) and the blinding factors through a device-side parameter block.  Bytes equal
+    the eager path's for different witnesses and (r, s), for a truncated witness (another key: eager, then captured again), and an
+    out-of-range witness fails its own proof only."""
+    torch = pytest.importorskip("torch")
+    eager, ctx = zk.Context(0), zk.Context(0)
+    ctx.set_option("lone_graph", 1)
+    n = 1 << log_n
+    rng = SplitMix64(6100 + log_n)
+    if roots == "unity":
+        from zksnark_rs_amd.circuits import chain_rows, chain_weights
+        m, l, u, v, w = chain_rows(log_n)
+        mk = lambda c: c.qap_sparse(log_n, m, l, u, v, w)                           # noqa: E731
+        wit = lambda: chain_weights(log_n, rng.fr(), [rng.fr() for _ in range(n)])   # noqa: E731
+    else:
+        from test_integer_roots import chain_rows_integers, chain_weights_integers
+        m, l, u, v, w = chain_rows_integers(n)
+        mk = lambda c: c.qap_sparse_integers(n, m, l, u, v, w)                       # noqa: E731
+        wit = lambda: chain_weights_integers(n, rng.fr(), [rng.fr() for _ in range(n)])   # noqa: E731
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    q0, q1 = mk(eager), mk(ctx)
+    c0, c1 = eager.setup(q0, td), ctx.setup(q1, td)
+    jobs = [(wit(), rng.fr(), rng.fr()) for _ in range(5)]
+    devs = [torch.from_numpy(np.ascontiguousarray(wt).view(np.int64)).cuda() for wt, _, _ in jobs]
+    torch.cuda.synchronize()
+    want = [eager.prove(c0, q0, wt, r, s) for wt, r, s in jobs]
+    got = [ctx.prove_dev(c1, q1, d.data_ptr(), m, r, s) for d, (_, r, s) in zip(devs, jobs)]      # eager, captured, replayed x 3
+    assert got == want
+    bad = jobs[0][0].copy(); bad[3] = np.array([0xFFFFFFFFFFFFFFFF] * 4, dtype=np.uint64)
+    dbad = torch.from_numpy(np.ascontiguousarray(bad).view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    with pytest.raises(zk.ZkError) as e:
+        ctx.prove_dev(c1, q1, dbad.data_ptr(), m, jobs[0][1], jobs[0][2])
+    assert e.value.status == zk._lib.ZK_ERR_RANGE
+    assert ctx.prove_dev(c1, q1, devs[1].data_ptr(), m, jobs[1][1], jobs[1][2]) == want[1]
+    short = [eager.prove(c0, q0, jobs[k][0][:m - 3], jobs[k][1], jobs[k][2]) for k in range(3)]
+    assert [ctx.prove_dev(c1, q1, devs[k].data_ptr(), m - 3, jobs[k][1], jobs[k][2]) for k in range(3)] == short
+    # pipelined submissions beside it still take the eager path
+    t = [ctx.prove_submit(c1, q1, devs[k].data_ptr(), m, jobs[k][1], jobs[k][2]) for k in range(2)]
+    assert [ctx.prove_wait(x) for x in t] == want[:2]
+    assert ctx.prove_dev(c1, q1, devs[2].data_ptr(), m, jobs[2][1], jobs[2][2]) == want[2]

@@ -129,6 +129,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_quad_buckets")) return &ctx->opt_quad_buckets;
     if (!std::strcmp(key, "interp_large_log")) return &ctx->opt_interp_large_log;
     if (!std::strcmp(key, "comm_cu_reserve")) return &ctx->opt_comm_cu_reserve;
+    if (!std::strcmp(key, "lone_graph")) return &ctx->opt_lone_graph;
 #ifdef ZK_MEASURE
     // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;

@@ -110,6 +110,8 @@ struct zk_ctx {
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
     long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
+    long opt_lone_graph = 0;      // zk_prove / zk_prove_dev: a lone proof of a (CRS, QAP, witness length) seen before replays one captured hipGraph (prove.hip prove_graph)
+    bool graph_capture = false;   // prove_submit is being captured: per-proof factors come from the slot's parameter block, nothing outside the capture is waited for
     long opt_interp_large_log = 20; // interp.hip: trees of at least 2^this elements per level take the form that halves the upward transforms
     long opt_quad_buckets = 65536; // inner products of at most this many buckets run their reduction tail with four lanes per addition (msm_quad.hpp)
     std::map<std::string, zk::ProfEntry> prof;
