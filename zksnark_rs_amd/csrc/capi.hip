@@ -115,6 +115,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& pe : ctx->pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    (void)hipGetLastError();   // whatever the tear-down left in the thread's sticky error must not surface in another context's next call
     delete ctx;
 }
 

@@ -186,6 +186,7 @@ template <class Fn>
 int guarded(zk_ctx* ctx, Fn&& fn) {
     try {
         if (ctx) ZK_HIP(hipSetDevice(ctx->device));
+        (void)hipGetLastError();   // a call starts clean: the thread's sticky error may stem from another context's tear-down or a caller's own HIP use
         fn();
         return ZK_OK;
     } catch (const HipError& e) {
