@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4: why did -7 % instructions not move the rate?  same-box A/B against the round-3 build + counters + stand-alone kernel times
+# same-box A/B of two builds (default against libzkgpu_r3.so, built from an older commit) with issue / wait counters of the accumulations and
+# stand-alone kernel times: what round 4 used to see that -9 % instructions gave +4 % rate at an unchanged clock (profiles/r4_pmc_counters_*.txt)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
