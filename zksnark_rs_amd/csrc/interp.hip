@@ -360,8 +360,12 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
         hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, alt, l + 1 < levels);   // parents' images, 2s points (+ the first half of their 4s-point images, in place)
         ntt_dit(ctx, alt, lg + l + 1, true, true, nullptr, parents * count);          // their coefficients
         if (l + 1 == levels) break;
-        hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tw.p, s2, npad / s2, total);
-        ntt_dif(ctx, alt, lg + l + 1, false, false, parents * count);
+        if (lg + l + 1 <= 22) {
+            ntt_dif_pre(ctx, alt, lg + l + 1, t.tw.p, npad / s2, parents * count);   // the twist w_4s^j rides on the transform's first load
+        } else {
+            hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tw.p, s2, npad / s2, total);
+            ntt_dif(ctx, alt, lg + l + 1, false, false, parents * count);
+        }
         hipLaunchKernelGGL(k_interp_half, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, s2, total, 1, tmp);
     }
     if (levels) ZK_HIP(hipMemcpyAsync(d_out, alt, count * npad * sizeof(Fr), hipMemcpyDeviceToDevice, st));

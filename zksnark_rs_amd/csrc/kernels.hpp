@@ -42,6 +42,7 @@ void ntt_dif(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv
 // bit-reversed order in -> natural order out.  d_pre (optional): element-wise multiplier applied
 // to the input (in its bit-reversed order) as it is loaded.
 void ntt_dit(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, const Fr* d_pre, size_t batch = 1);
+void ntt_dif_pre(zk_ctx*, Fr* d_data, unsigned log_n, const Fr* table, size_t step, size_t batch);   // element i times table[i * step] on the first load
 void bitrev_permute(zk_ctx*, const Fr* d_in, Fr* d_out, unsigned log_n);
 // out[i] = a[i] * b[i]
 void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);

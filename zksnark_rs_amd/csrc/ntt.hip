@@ -187,6 +187,8 @@ struct NttPass {
     Fr post;
     int has_post;
     int contig;      // a tile = 2^log_cols WHOLE transforms of 2^log_rows contiguous elements each (batches of small transforms): element idx of the tile at base + idx
+    size_t pre_step; // > 0: `pre` is ONE table for every transform of the batch -- element i of a transform is multiplied by pre[(i & pre_mask) * pre_step]
+    size_t pre_mask; //      (interp.hip: the twist w_4s^i in front of the second half of a parent's image)
 };
 
 __device__ __forceinline__ FrL lds_get(const int32_t* lds, int e) {
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     const int elems = 1 << (log_rows + log_cols);
     const unsigned tile = blockIdx.x & ((1u << p.log_tiles) - 1);
     Fr* base = data + (size_t)(blockIdx.x >> p.log_tiles) * p.n + (size_t)tile * p.tile_stride;
-    const Fr* pre = p.pre ? p.pre + (size_t)tile * p.tile_stride : nullptr;
+    const Fr* pre = p.pre ? (p.pre_step ? p.pre : p.pre + (size_t)tile * p.tile_stride) : nullptr;
     const Fr* mid = p.mid ? p.mid + (size_t)tile * p.tile_stride : nullptr;
 
     // load: consecutive lanes walk the `cols` contiguous elements of a row, then the next row
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
         int at = (col << log_rows) + row;
         if (p.contig) { g = idx; at = idx; }
         FrL v = FrL::load(base[g]);
-        if (pre) v = v * FrL::load(pre[g]);
+        if (pre) v = v * FrL::load(pre[p.pre_step ? (((size_t)tile * p.tile_stride + g) & p.pre_mask) * p.pre_step : g]);
         lds_put(lds, at, v);
     }
     __syncthreads();
@@ -372,7 +374,7 @@ __global__ void k_mul_rows(Fr* __restrict__ d, const Fr* __restrict__ f, size_t 
 }
 
 // post: the factor applied with `scale` (null: 1 / 2^log_n) -- the blocks of a three-pass transform are scaled by 1 / n of the whole
-static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch, const Fr* post = nullptr) {
+static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch, const Fr* post = nullptr, size_t pre_step = 0) {
     static bool attr_set = false;
     if (!attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
@@ -412,13 +414,13 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     if (log_n <= NTT_MAX_LOCAL_LOG) {
         // batches of small transforms (the levels of interp.hip's tree): a tile takes as many whole transforms as fit its 2048 elements
         unsigned pack = 0;
-        while (!d_pre && log_n + pack < NTT_MAX_LOCAL_LOG && (batch >> (pack + 1)) << (pack + 1) == batch && (batch >> (pack + 1)) >= 256) ++pack;
+        while ((!d_pre || pre_step) && log_n + pack < NTT_MAX_LOCAL_LOG && (batch >> (pack + 1)) << (pack + 1) == batch && (batch >> (pack + 1)) >= 256) ++pack;
         if (pack) {
-            NttPass p{log_n, pack, 0, n << pack, 1, n << pack, tw, nullptr, nullptr, post_f, scale ? 1 : 0, 1};
+            NttPass p{log_n, pack, 0, n << pack, 1, n << pack, tw, nullptr, d_pre, post_f, scale ? 1 : 0, 1, pre_step, n - 1};
             launch_pass(ctx, dit, d, p, batch >> pack, "ntt_tile", pass_bytes);
             return;
         }
-        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, post_f, scale ? 1 : 0, 0};
+        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, d_pre, post_f, scale ? 1 : 0, 0, pre_step, n - 1};
         launch_pass(ctx, dit, d, p, batch, "ntt_tile", pass_bytes);
         return;
     }
@@ -432,6 +434,7 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
     if (!dit) {
         col.mid = mid;
         row.has_post = scale ? 1 : 0;
+        if (d_pre) { col.pre = d_pre; col.pre_step = pre_step; col.pre_mask = n - 1; }   // periodic table on the first load (ntt_dif_pre)
         launch_pass(ctx, false, d, col, col_tiles, "ntt_tile", pass_bytes);
         launch_pass(ctx, false, d, row, row_tiles, "ntt_tile", pass_bytes);
     } else {
@@ -445,6 +448,12 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
 
 void ntt_dif(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, size_t batch) { ntt_core(ctx, false, d, log_n, inverse, scale, nullptr, batch); }
 void ntt_dit(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch) { ntt_core(ctx, true, d, log_n, inverse, scale, d_pre, batch); }
+// forward DIF of `batch` transforms whose element i is first multiplied by table[i * step] (one table for the whole batch, fused into
+// the first tile load); log_n <= 22
+void ntt_dif_pre(zk_ctx* ctx, Fr* d, unsigned log_n, const Fr* table, size_t step, size_t batch) {
+    ZK_REQUIRE(log_n <= 2 * NTT_MAX_LOCAL_LOG && step >= 1, ZK_ERR_SIZE, "ntt_dif_pre: at most 2^22 points");
+    ntt_core(ctx, false, d, log_n, false, false, table, batch, nullptr, step);
+}
 
 __global__ void k_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, unsigned log_n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
