@@ -15,6 +15,7 @@ python bench.py --steps 100 --warmup 5 > $OUT/bench_100steps.json 2>> $OUT/bench
   python bench.py --log-n 16 --steps 320 --warmup 64 --batch 32 --no-cpu-baseline
   python bench.py --log-n 16 --latency --steps 40 --warmup 8
   python bench.py --log-n 4 --latency --steps 40 --warmup 8
+  python bench.py --log-n 16 --latency --steps 40 --warmup 8 --lone-graph
   python bench.py --log-n 4 --roots integers --steps 640 --warmup 64 --batch 32
   python bench.py --roots integers --steps 60 --warmup 5
   python bench.py --roots arbitrary --steps 30 --warmup 4
@@ -34,6 +35,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write16 -- $CMD3 --log-n 16 > $OUT/pmc_write16.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_acc -- $CMD3 > $OUT/pmc_acc.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_acc16 -- $CMD3 --log-n 16 > $OUT/pmc_acc16.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/pmc_ntt -- $CMD3 > $OUT/pmc_ntt.log 2>&1
+python $REPO/tools/pmc_counters.py $OUT/pmc_ntt k_ntt_tile > $OUT/pmc_ntt.txt; rm -rf $OUT/pmc_ntt
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $REPO/bench.py --steps 24 --warmup 4 --no-cpu-baseline > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace16 -- python $REPO/bench.py --latency --log-n 16 --steps 6 --warmup 3 > $OUT/trace16.log 2>&1
 cd $REPO
