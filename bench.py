@@ -336,7 +336,7 @@ def main():
     if args.transport == "zk" and args.backend == "gloo":
         args.transport = "zk-gloo"
     use_zk = world > 1 and args.transport in ("zk", "zk-gloo")
-    device = local_rank % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local_rank
+    device = local_rank % max(1, torch.cuda.device_count())   # one GPU per rank on a multi-GPU node; ranks share a GPU only in the functional runs of the tests
     torch.cuda.set_device(device)
     dist = None
     if world > 1 and args.transport != "zk":

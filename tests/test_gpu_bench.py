@@ -42,10 +42,10 @@ def test_bench_line_single_gpu():
         assert v["peak_measured_source"].startswith("profiles/")
 
 
-def run_two_ranks(extra, env=None, port_base=29600):
+def run_two_ranks(extra, env=None, port_base=29600, backend="gloo"):
     port = port_base + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo"] + extra
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", backend] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     return last_json_line(res.stdout)
@@ -88,3 +88,15 @@ def test_bench_survives_a_peer_that_never_arrives():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "replicas x2"
     assert "did not complete" in d["degraded"] or "timed out" in d["degraded"] or "another rank" in d["degraded"]
     assert d["replicas"]["bytes_equal_to_single_gpu_prove"]
+
+
+def test_bench_degrades_when_the_rccl_communicator_cannot_be_created():
+    """The driver's own command line (--transport zk over RCCL) with two ranks on ONE GPU: RCCL refuses a communicator whose ranks
+    share a device (or never completes it) -- the bootstrap's bounded wait ends in the degraded path, and the line still carries the
+    replicas' rate and their byte equality.  What a broken fabric or a missing peer looks like on a real node."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU (two ranks must collide on it)")
+    d = run_two_ranks(["--log-n", "10", "--timeout", "40"], port_base=30700, backend="nccl")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "degraded" in d and d["config"]["parallelism"] == "replicas x2"
+    assert d["rccl_ranks"] == 0 and d["replicas"]["bytes_equal_to_single_gpu_prove"]
