@@ -25,6 +25,7 @@
 #include "pipeline.hpp"
 #include "interp.hpp"
 #include "lazy29.cuh"
+#include "fr_tile.cuh"
 
 namespace zk {
 
@@ -184,7 +185,7 @@ __global__ void k_interp_mul_pairs(const Fr* __restrict__ node, size_t s2, size_
 // P of the bottom blocks: out[v][blk IB + i] = sum_k values[v][blk IB + k] q[blk][k][i]   (values beyond n are not read).
 // One lane per output coefficient serves all CNT vectors of the launch, so the matrix (64 x 32 B per coefficient: 2.1 GB at 2^20
 // leaves) is read once, coalesced; the sums run in the lazy radix-2^29 form of lazy29.cuh -- two products per Montgomery reduction
-// (mont_sum), limb-wise accumulation, one closing multiplication by 1 that contracts the sum before it is stored exactly.
+// (mont_sum), limb-wise accumulation, one closing reduction (fr_store_exact takes any |value| < 2^9 p: here <= 32 terms below 3p).
 // (Round 3: one launch row per vector, rows of q strided by 2 KB across the lanes, 8 x 32 multiplications: 2.3 ms per 2^20-gate proof.)
 template <int CNT>
 __global__ __launch_bounds__(256) void k_interp_bottom(const Fr* __restrict__ values, size_t vstride, int v0, const Fr* __restrict__ qmat, size_t n, size_t npad,
@@ -208,9 +209,8 @@ __global__ __launch_bounds__(256) void k_interp_bottom(const Fr* __restrict__ va
             acc[v] = (acc[v] + L::mont_sum(f0, q0, f1, q1)).norm();       // <= 32 terms of |value| < 3p: limbs stay in range
         }
     }
-    const L one = L::load(Fr::one());
 #pragma unroll
-    for (int v = 0; v < CNT; ++v) out[(size_t)(v0 + v) * npad + g] = (acc[v] * one).store_exact();
+    for (int v = 0; v < CNT; ++v) out[(size_t)(v0 + v) * npad + g] = fr_store_exact(acc[v]);
 }
 // children (size s, contiguous) -> zero padded to 2s
 __global__ void k_interp_pad(const Fr* __restrict__ cur, size_t s, size_t total2, Fr* __restrict__ tmp) {
@@ -228,7 +228,7 @@ __global__ void k_interp_combine(Fr* tmp, const Fr* __restrict__ nev, size_t s2,
     const size_t p = g / s2, j = g - p * s2;
     Fr* t = tmp + (size_t)blockIdx.y * parents * 2 * s2;
     const size_t l = (2 * p) * s2 + j, r = (2 * p + 1) * s2 + j;
-    const Fr v = t[l] * nev[r] + t[r] * nev[l];
+    const Fr v = fr_store_exact(FrL::mont_sum(FrL::load(t[l]), FrL::load(nev[r]), FrL::load(t[r]), FrL::load(nev[l])));   // one reduction for both products
     out[(size_t)blockIdx.y * parents * s2 + g] = v;
     if (keep) t[l] = v;
 }
@@ -243,7 +243,7 @@ __global__ void k_interp_half(const Fr* __restrict__ src, size_t s2, size_t tota
     const size_t p = g / s2, j = g - p * s2;
     next[p * 2 * s2 + (size_t)half * s2 + j] = src[g];
 }
-// coefficients times w_4s^j, w_4s^j = tw[j npad / 2s]  (tw[i] = w_(2 npad)^i)
+// coefficients times tw[(j mod 2s) step]  (interp_run: the level's table w_4s^j / 2s, step 1)
 __global__ void k_interp_twist(Fr* __restrict__ c, const Fr* __restrict__ tw, size_t s2, size_t step, size_t total) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -262,8 +262,6 @@ std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, si
     t->roots.alloc(n);
     ZK_HIP(hipMemcpyAsync(t->roots.p, d_roots_mont, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     t->w.alloc(n);
-    t->tw.alloc(npad);
-    fr_powers(ctx, host_root_of_unity(L + 1), Fr::one(), t->tw.p, npad);   // w_(2 npad)^i (interp_run: the twist of the doubled images)
     const size_t blocks = npad / IB;
     t->qmat.alloc(npad * IB);
     DevBuf<Fr> node(2 * npad), prod(npad), blk_poly(2 * npad);
@@ -275,6 +273,11 @@ std::shared_ptr<InterpTree> interp_build(zk_ctx* ctx, const Fr* d_roots_mont, si
     while ((1u << lg) < (unsigned)IB) ++lg;
     for (unsigned l = 0; lg + l < L; ++l) {
         const size_t s = (size_t)IB << l, s2 = 2 * s, children = npad / s, parents = children / 2;
+        if (lg + l + 1 < L) {   // interp_run: the twist w_4s^j of a parent's coefficients, with the 1 / 2s of the unscaled inverse transform before it
+            t->tws.emplace_back();
+            t->tws.back().alloc(s2);
+            fr_powers(ctx, host_root_of_unity(lg + l + 2), host_fr_pow(host_fr_from_u64(2), lg + l + 1).inv(), t->tws.back().p, s2);
+        }
         ntt_dif(ctx, node.p, lg + l + 1, false, false, children);
         t->nev.emplace_back();
         t->nev.back().alloc(2 * npad);
@@ -358,12 +361,12 @@ void interp_run(zk_ctx* ctx, const InterpTree& t, const Fr* d_values, size_t vst
     for (unsigned l = 0; l < levels; ++l) {
         const size_t s2 = (size_t)IB << (l + 1), parents = npad / s2, total = npad * count;
         hipLaunchKernelGGL(k_interp_combine, dim3(ceil_div(parents * s2, 256), count), dim3(256), 0, st, tmp, t.nev[l].p, s2, parents, alt, l + 1 < levels);   // parents' images, 2s points (+ the first half of their 4s-point images, in place)
-        ntt_dit(ctx, alt, lg + l + 1, true, true, nullptr, parents * count);          // their coefficients
+        ntt_dit(ctx, alt, lg + l + 1, true, l + 1 == levels, nullptr, parents * count);   // their coefficients -- times 2s below the root: the twist table divides
         if (l + 1 == levels) break;
         if (lg + l + 1 <= 22) {
-            ntt_dif_pre(ctx, alt, lg + l + 1, t.tw.p, npad / s2, parents * count);   // the twist w_4s^j rides on the transform's first load
+            ntt_dif_pre(ctx, alt, lg + l + 1, t.tws[l].p, 1, parents * count);   // the twist w_4s^j / 2s rides on the transform's first load
         } else {
-            hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tw.p, s2, npad / s2, total);
+            hipLaunchKernelGGL(k_interp_twist, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, t.tws[l].p, s2, (size_t)1, total);
             ntt_dif(ctx, alt, lg + l + 1, false, false, parents * count);
         }
         hipLaunchKernelGGL(k_interp_half, dim3(ceil_div(total, 256)), dim3(256), 0, st, alt, s2, total, 1, tmp);

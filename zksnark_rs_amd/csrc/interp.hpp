@@ -14,7 +14,8 @@ struct InterpTree {
     DevBuf<Fr> roots, w;              // the nodes and 1 / N'(r_k), Montgomery
     DevBuf<Fr> qmat;                  // bottom blocks: [block][i][k] = coefficient i of N_block / (x - r_k), times w_k
     std::vector<DevBuf<Fr>> nev;      // level l: DIF images of the children's N (children of 64 << l leaves, padded to twice that): 2 npad each
-    DevBuf<Fr> tw;                    // w_(2 npad)^i, i < npad
+    std::vector<DevBuf<Fr>> tws;      // level l: w_4s^j / 2s, j < 2s (s = 64 << l) -- the twist in front of the second half of a parent's doubled image,
+                                      // carrying the 1 / 2s of the inverse transform before it (which therefore runs unscaled)
     DevBuf<Fr> t;                     // N_root = prod (x - r_k): n + 1 coefficients
 };
 
