@@ -6,7 +6,10 @@
 
 namespace zk {
 
-constexpr int INTERP_BLOCK = 64;   // leaves per flat bottom block
+#ifndef ZK_INTERP_BLOCK
+#define ZK_INTERP_BLOCK 64
+#endif
+constexpr int INTERP_BLOCK = ZK_INTERP_BLOCK;   // leaves per flat bottom block
 
 struct InterpTree {
     size_t n = 0;
