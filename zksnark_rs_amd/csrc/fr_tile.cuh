@@ -1,5 +1,5 @@
-// fr_tile.cuh -- reductions of scalar-field values held in the multiplier's own radix (lazy29.cuh): shared by the transform tiles
-// (ntt.hip) and the interpolation tree (interp.hip).
+// fr_tile.cuh -- reductions of field values held in the multiplier's own radix (lazy29.cuh): shared by the transform tiles
+// (ntt.hip), the interpolation tree (interp.hip) and the affine pair sums of the G2 inner product (g2_affine.cuh).
 #pragma once
 #include "lazy29.cuh"
 
@@ -9,7 +9,10 @@ typedef FpR<FrParams> FrL;
 
 // value - q p with q ~ floor(value / p) estimated from the top limb: any limbs within int32 and
 // |value| < 2^9 p in, normal form with value in (-p - eps, 2p) out (eps = 2^-12 p: the low limbs of q p).
-__device__ __forceinline__ FrL fr_reduce(const FrL& a) {
+template <class PR>
+__device__ __forceinline__ FpR<PR> lazy_reduce(const FpR<PR>& a) {
+    typedef FpR<PR> FrL;
+    typedef PR FrParams;
     const int32_t q = (int32_t)floorf((float)a.v[8] * (1.0f / (float)FrParams::P29[8]));
     FrL r;
     int64_t c = 0;
@@ -22,9 +25,14 @@ __device__ __forceinline__ FrL fr_reduce(const FrL& a) {
     r.v[8] = a.v[8] - q * (int32_t)FrParams::P29[8] + (int32_t)c;
     return r;
 }
+__device__ __forceinline__ FrL fr_reduce(const FrL& a) { return lazy_reduce<FrParams>(a); }
 // canonical 8 x 32 form of any tile value
-__device__ __forceinline__ Fr fr_store_exact(const FrL& a) {
-    const FrL t = fr_reduce(a);   // (-p - eps, 2p): one of t + p, t, t - p is the residue
+template <class PR>
+__device__ __forceinline__ Fp<PR> lazy_store_exact(const FpR<PR>& a) {
+    typedef FpR<PR> FrL;
+    typedef PR FrParams;
+    typedef Fp<PR> Fr;
+    const FrL t = lazy_reduce<PR>(a);   // (-p - eps, 2p): one of t + p, t, t - p is the residue
     FrL d, s;
     int32_t bd = 0, cs = 0;
 #pragma unroll
@@ -46,5 +54,6 @@ __device__ __forceinline__ Fr fr_store_exact(const FrL& a) {
     Fr::from29(u, o.l);
     return o;
 }
+__device__ __forceinline__ Fr fr_store_exact(const FrL& a) { return lazy_store_exact<FrParams>(a); }
 
 }  // namespace zk

@@ -32,6 +32,7 @@
 #include "kernels.hpp"
 #include "lazy29.cuh"
 #include "quad29.cuh"
+#include "g2_affine.cuh"
 
 namespace zk {
 
@@ -467,8 +468,20 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
     if (entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill) T = RUN_MAX;
     else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
+    // G2 products whose buckets hold 16 .. run_whole entries each (the proofs' B product at 2^20 gates: 25): the first `aff_rounds`
+    // halvings of every bucket are pairwise AFFINE sums with shared inversions (g2_affine.cuh: ~4400 instructions per addition against
+    // ~5800 for the mixed XYZZ addition); the accumulation below then runs over the list that is left.  Every bucket's segment of the
+    // sorted list is padded to a multiple of 2^aff_rounds entries for this (k_msm_bin_offsets).
+    int aff_rounds = 0;
+    if constexpr (sizeof(F) > sizeof(Fq)) {
+        if (ctx->opt_g2_affine > 0 && T == RUN_MAX && entries / (size_t)buckets >= 16) aff_rounds = (int)std::min<long>(ctx->opt_g2_affine, 4);
+    }
+    const uint32_t aff_pad = (1u << aff_rounds) - 1;
+    const size_t entries_padded = entries + (size_t)buckets * aff_pad;         // upper bound of the padded list
+    const size_t entries_acc = aff_rounds ? entries_padded >> aff_rounds : entries;   // entries the accumulation walks
+    ZK_REQUIRE(entries_padded < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
     // upper bounds: a bucket of z entries has ceil(z / T) <= 1 + z / T runs, of which all but the first take an extra image slot
-    const size_t max_extra = entries / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries) + max_extra;
+    const size_t max_extra = entries_acc / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries_acc) + max_extra;
     // an accumulation that cannot fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
     if (std::min(max_runs, entries / std::min<size_t>(T, 32) + 1) < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
@@ -489,7 +502,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.bin_start.ensure(bins + 1);
     ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
-    ws.sorted.ensure(entries);
+    ws.sorted.ensure(entries_padded);
     if (!ws.runs_cnt.p) {   // cleared once; k_msm_runs_scan leaves it cleared
         ws.runs_cnt.alloc(2 * (RUN_MAX + 2) + 2);
         ZK_HIP(hipMemsetAsync(ws.runs_cnt.p, 0, ws.runs_cnt.bytes(), st));
@@ -550,9 +563,47 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             ws.part_start.ensure((size_t)bins + 1);
             hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
             hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
-            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
+            if (aff_rounds) {
+                ws.ptotal.ensure(bins);
+                ws.pbin_start.ensure(bins + 1);
+                hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p, aff_pad,
+                                   (const uint32_t*)nullptr, ws.ptotal.p);
+                hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.ptotal.p, ws.pbin_start.p, bins);
+                ZK_HIP(hipMemsetAsync(ws.sorted.p, 0xff, entries_padded * sizeof(uint32_t), st));   // AFF_PAD behind every bucket's entries
+            }
+            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p, aff_pad,
+                               aff_rounds ? (const uint32_t*)ws.pbin_start.p : (const uint32_t*)nullptr, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                                sub_bits, ws.bin_cnt.p, ws.sorted.p);
+        }
+        if (aff_rounds) {
+            // start[buckets] = length of the padded list (on the device); round r halves the list of round r - 1
+            if constexpr (sizeof(F) > sizeof(Fq)) {
+                ProfScope ps(ctx, "msm_affine_g2", 720.0 * (double)entries, st);
+                size_t list_elems = 0;
+                for (int r = 1; r <= aff_rounds; ++r) list_elems += entries_padded >> r;
+                ws.aff_list.ensure(list_elems * sizeof(Aff<Fq2>));
+                ws.aff_prefix.ensure(aff_prefix_words(entries_padded >> 1, ctx->cu_count));
+                if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
+                Aff<Fq2>* out = reinterpret_cast<Aff<Fq2>*>(ws.aff_list.p);
+                const Aff<Fq2>* in = nullptr;
+                for (int r = 1; r <= aff_rounds; ++r) {
+                    const size_t pairs = entries_padded >> r;
+                    const unsigned grid = aff_grid(pairs, ctx->cu_count);
+                    if (r == 1) hipLaunchKernelGGL(k_g2_pair_sums<PairTable>, dim3(grid), dim3(AFF_THREADS), 0, st, PairTable{tab.table.p + point_offset, ws.sorted.p}, (uint32_t)pairs,
+                                                   (const uint32_t*)(ws.start.p + buckets), r, ws.aff_prefix.p, out);
+                    else hipLaunchKernelGGL(k_g2_pair_sums<PairList>, dim3(grid), dim3(AFF_THREADS), 0, st, PairList{in}, (uint32_t)pairs, (const uint32_t*)(ws.start.p + buckets), r,
+                                            ws.aff_prefix.p, out);
+                    in = out;
+                    out += pairs;
+                }
+                if (ws.ident_filled < entries_acc) {
+                    ws.ident.ensure(entries_acc);
+                    hipLaunchKernelGGL(k_msm_identity_entries, dim3(ceil_div(entries_acc, 256)), dim3(256), 0, st, ws.ident.p, (uint32_t)entries_acc);
+                    ws.ident_filled = entries_acc;
+                }
+                hipLaunchKernelGGL(k_msm_shift_starts, dim3(ceil_div((size_t)buckets + 1, 256)), dim3(256), 0, st, ws.start.p, (uint32_t)buckets, aff_rounds);
+            }
         }
         {
             ProfScope ps(ctx, "msm_runs", 8.0 * buckets + 12.0 * max_runs, st);
@@ -566,12 +617,20 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         // pair -- 96 B in G1, 160 B in G2 -- whatever the window count.  (What this implementation actually gathers is W times
         // that: a 4-byte index and a 64 / 128-byte table entry per window and pair, plus one image per run; bench.py
         // reports that figure and the PMC-measured traffic beside the 8(d) number.)
-        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
+        if (acc_wait && !aff_rounds) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         {
             ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, st);
             // dynamic LDS nobody touches: an occupancy cap (ZK_ACC_G1_LDS bytes per workgroup; 160 KiB per compute unit) that is independent of
             // the register budget the kernel is compiled for
-            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), g2 ? 0 : ZK_ACC_G1_LDS, st, tab.table.p + point_offset, ws.sorted.p, d_runs, d_info, d_img);
+            const Aff<F>* acc_table = tab.table.p + point_offset;
+            const uint32_t* acc_sorted = ws.sorted.p;
+            if (aff_rounds) {   // the list the last round of pair sums left is its own table
+                size_t skip = 0;
+                for (int r = 1; r < aff_rounds; ++r) skip += entries_padded >> r;
+                acc_table = reinterpret_cast<const Aff<F>*>(ws.aff_list.p) + skip;
+                acc_sorted = ws.ident.p;
+            }
+            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), g2 ? 0 : ZK_ACC_G1_LDS, st, acc_table, acc_sorted, d_runs, d_info, d_img);
         }
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     }
