@@ -584,7 +584,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                 for (int r = 1; r <= aff_rounds; ++r) list_elems += entries_padded >> r;
                 ws.aff_list.ensure(list_elems * sizeof(Aff<Fq2>));
                 ws.aff_prefix.ensure(aff_prefix_words(entries_padded >> 1, ctx->cu_count));
-                if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
+                if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));   // the pair sums are the first part of this product's accumulation
+                acc_wait = nullptr;
                 Aff<Fq2>* out = reinterpret_cast<Aff<Fq2>*>(ws.aff_list.p);
                 const Aff<Fq2>* in = nullptr;
                 for (int r = 1; r <= aff_rounds; ++r) {
@@ -617,7 +618,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         // pair -- 96 B in G1, 160 B in G2 -- whatever the window count.  (What this implementation actually gathers is W times
         // that: a 4-byte index and a 64 / 128-byte table entry per window and pair, plus one image per run; bench.py
         // reports that figure and the PMC-measured traffic beside the 8(d) number.)
-        if (acc_wait && !aff_rounds) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
+        if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         {
             ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, st);
             // dynamic LDS nobody touches: an occupancy cap (ZK_ACC_G1_LDS bytes per workgroup; 160 KiB per compute unit) that is independent of
