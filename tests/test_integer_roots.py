@@ -262,6 +262,35 @@ def test_gpu_uploaded_crs_change_of_basis_at_size(ctx, orc, tmp_path, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 5, 64, 65, 200, 1000])
+def test_gpu_change_of_basis_by_the_transposed_tree(ctx, tmp_path, n):
+    """csrc/gbasis.hip: the Lagrange-basis points of an uploaded CRS as the TRANSPOSE of the interpolation tree run over curve points
+    (O(n log^2 n) point operations; the default from 512 gates on).  Forced at small sizes here -- one block, one level, ragged last
+    block, several levels --: the derived arrays equal the ones zk_setup wrote from the trapdoor, and the ones of the n^2 inner
+    products (the three CRS containers agree byte for byte)."""
+    rng = SplitMix64(8900 + n)
+    m, l, u, v, w = chain_rows_integers(n)
+    qap = ctx.qap_sparse_integers(n, m, l, u, v, w)
+    td = ints_to_limbs([rng.fr() for _ in range(5)])
+    crs = ctx.setup(qap, td)
+    weights = chain_weights_integers(n, rng.fr(), [rng.fr() for _ in range(n)])
+    r, s = rng.fr(), rng.fr()
+    good = ctx.prove(crs, qap, weights, r, s)
+    ctx.crs_save(crs, tmp_path / "setup.zkcrs")
+    want = (tmp_path / "setup.zkcrs").read_bytes()
+    old = ctx.get_option("basis_tree_min")
+    try:
+        for name, tree_min in (("tree", 1), ("squares", 1 << 30)):
+            ctx.set_option("basis_tree_min", tree_min)
+            up = ctx.crs_upload(n, m, l, ctx.crs_download(crs))
+            assert ctx.prove(up, qap, weights, r, s) == good, name
+            ctx.crs_save(up, tmp_path / (name + ".zkcrs"))
+            assert (tmp_path / (name + ".zkcrs")).read_bytes() == want, name
+    finally:
+        ctx.set_option("basis_tree_min", old)
+
+
+@pytest.mark.gpu
 def test_gpu_uploaded_crs_beyond_the_change_of_basis(ctx, orc):
     """Above 2^16 + 2^10 gates the O(n^2) change of basis is not attempted: an integer-roots QAP over a CRS that carries only the
     reference's arrays proves through the sub-product tree of the roots 1..n instead (csrc/arbroots.hip) -- the same bytes, which

@@ -134,6 +134,7 @@ static void basis_products(zk_ctx* ctx, const Aff<F>* d_bases, size_t D, const D
 void crs_lagrange_from_powers(zk_ctx* ctx, zk_crs& c, const zk_qap& q) {
     const size_t n = c.n;
     ZK_REQUIRE(q.roots && q.ap && q.n == n, ZK_ERR_ARG, "crs_lagrange_from_powers: not an integer-roots QAP of this CRS");
+    if (ctx->opt_basis_tree_min >= 0 && n >= (size_t)ctx->opt_basis_tree_min) { crs_lagrange_from_powers_tree(ctx, c, q); return; }
     ZK_REQUIRE(n <= BASIS_MAX_N, ZK_ERR_UNSUPPORTED,
                "prove: an integer-roots QAP of more than 2^16 + 2^10 gates needs the CRS zk_setup made for it (the change of basis of an uploaded CRS is O(n^2))");
     c.lag1.alloc(n); c.lag2.alloc(n); c.lagS_t1.alloc(std::max<size_t>(n - 1, 1));

@@ -132,6 +132,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "comm_cu_reserve")) return &ctx->opt_comm_cu_reserve;
     if (!std::strcmp(key, "lone_graph")) return &ctx->opt_lone_graph;
     if (!std::strcmp(key, "g2_affine")) return &ctx->opt_g2_affine;
+    if (!std::strcmp(key, "basis_tree_min")) return &ctx->opt_basis_tree_min;
 #ifdef ZK_MEASURE
     // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;

@@ -1,0 +1,197 @@
+// gbasis.hip -- the change of basis of an uploaded CRS in O(n log^2 n) group operations: the TRANSPOSE of interp.hip's interpolation,
+// run over curve points.
+//
+// groth16::prove takes any (&SigmaG1, &SigmaG2) setup emitted (/root/reference/src/groth16/mod.rs:172-194, 213-217), i.e. the powers
+// [x^i]; the integer-roots form (aproots.hip) multiplies with [L_k(x)] = sum_i c_{k,i} [x^i], where c_{k,.} are the coefficients of the
+// Lagrange polynomial of node k.  Interpolation IS the linear map M: values -> coefficients with M[i][k] = c_{k,i}, so the wanted points
+// are y = M^T G: the same straight-line program read backwards (Tellegen), with every scalar multiplication-by-a-constant turned into a
+// point multiplied by that constant.  interp.hip's program is: bottom blocks (a 64 x 64 matrix per 64 nodes), then per level
+//     parent = iDIT( DIF(pad(left)) . N_right + DIF(pad(right)) . N_left ),
+// and its transpose, level by level from the root down:
+//     u = DIF^-1(parent)            -- (F^-1 P)^T = P F^-1: decimation in frequency with the inverse twiddles, natural -> bit-reversed
+//     left' = N_right . u / 2s,  right' = N_left . u / 2s          (2s multiplications of a point by a stored scalar per node)
+//     left = first s of DIT(left'),  right = first s of DIT(right')   -- (P F)^T = F P, bit-reversed -> natural; pad^T = truncation
+// and at the bottom y_k = sum_i q[block][k][i] g_i.  Same per-root-set tables as the prover's interpolation (InterpTree), nothing new is
+// precomputed.  A butterfly is one point multiplied by a 254-bit twiddle: ~1.5 n log^2 n / 2 of them -- 3 x 10^8 at 2^20 gates, seconds
+// per array, against the n^2 = 10^12 terms of basis.hip's inner products (hours).
+#include <vector>
+#include "pipeline.hpp"
+#include "interp.hpp"
+
+namespace zk {
+
+constexpr int GB = INTERP_BLOCK;
+
+// data[i] = bases[i] for i < n, infinity beyond
+template <class F>
+__global__ void k_gb_load(const Aff<F>* __restrict__ bases, size_t n, size_t npad, Jac<F>* __restrict__ data) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) data[i] = i < n ? Jac<F>::from_affine(bases[i]) : Jac<F>::infinity();
+}
+
+template <class F>
+__device__ __forceinline__ Jac<F> gb_mul(const Jac<F>& p, const Fr& k_canonical) {
+    if (p.is_inf()) return p;
+    return jac_mul_words(p, k_canonical.l);
+}
+
+// One radix-2 stage over `total` points holding total >> log_size transforms of 2^log_size points each.  tw: canonical w_T^j, j < T / 2,
+// for the largest transform size T = 2^log_table of the tree (forward or inverse table).
+// DIF (natural -> bit-reversed), stage t = 0 .. L-1: half = N >> (t + 1); (x, y) -> (x + y, (x - y) w_N^(j 2^t))
+// DIT (bit-reversed -> natural), stage t = 0 .. L-1: half = 1 << t;       (x, y) -> (x + w y, x - w y), w = w_N^(j N / (2 half))
+template <class F, bool DIT>
+__global__ __launch_bounds__(64) void k_gb_stage(Jac<F>* __restrict__ data, size_t total, unsigned log_size, unsigned stage, const Fr* __restrict__ tw, unsigned log_table) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total / 2) return;
+    const unsigned log_half = DIT ? stage : log_size - 1 - stage;
+    const size_t half = (size_t)1 << log_half;
+    const size_t j = b & (half - 1), i0 = ((b >> log_half) << (log_half + 1)) | j, i1 = i0 + half;
+    // exponent of w_N, then of the table's w_T
+    const size_t e = DIT ? j << (log_size - 1 - log_half) : j << stage;
+    const size_t idx = e << (log_table - log_size);
+    Jac<F> x = data[i0], y = data[i1];
+    if (DIT) {
+        if (idx) y = gb_mul(y, tw[idx]);
+        data[i0] = jac_add_ni(x, y);
+        data[i1] = jac_add_ni(x, y.neg());
+    } else {
+        data[i0] = jac_add_ni(x, y);
+        Jac<F> d = jac_add_ni(x, y.neg());
+        if (idx) d = gb_mul(d, tw[idx]);
+        data[i1] = d;
+    }
+}
+
+// children' = N_sibling . u / 2s:  h[2p][j] = (nev[2p + 1][j] scale) u[p][j],  h[2p + 1][j] = (nev[2p][j] scale) u[p][j],  j < 2s
+template <class F>
+__global__ __launch_bounds__(64) void k_gb_spread(const Jac<F>* __restrict__ u, const Fr* __restrict__ nev, Fr scale, size_t s2, size_t parents, Jac<F>* __restrict__ h) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= parents * 2 * s2) return;
+    const size_t c = g / s2, j = g - c * s2, p = c >> 1;
+    const Fr k = (nev[(c ^ 1) * s2 + j] * scale).to_canonical();
+    h[g] = gb_mul(u[p * s2 + j], k);
+}
+// next[c s + j] = h[c 2s + j], j < s
+template <class F>
+__global__ void k_gb_truncate(const Jac<F>* __restrict__ h, size_t s, size_t total, Jac<F>* __restrict__ next) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t c = g / s, j = g - c * s;
+    next[g] = h[c * 2 * s + j];
+}
+template <class F>
+__global__ void k_gb_affine(const Jac<F>* __restrict__ in, size_t count, Aff<F>* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = jac_to_affine(in[i]);
+}
+
+// y[block GB + k] = sum_i q[block][k][i] g[block GB + i]: one wave per block, lane k; eight scalars at a time share their doublings
+template <class F>
+__global__ __launch_bounds__(GB) void k_gb_bottom(const Aff<F>* __restrict__ g, const Fr* __restrict__ qmat, size_t n, Jac<F>* __restrict__ y) {
+    const size_t blk = blockIdx.x, base = blk * GB;
+    const int k = threadIdx.x;
+    if (base + k >= n) return;
+    const int real = (int)(n - base < (size_t)GB ? n - base : GB);
+    const Fr* q = qmat + base * GB + (size_t)k * GB;
+    Jac<F> acc = Jac<F>::infinity();
+    for (int i0 = 0; i0 < real; i0 += 8) {
+        Fr sc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc[e] = i0 + e < real ? q[i0 + e].to_canonical() : Fr::zero();
+        Jac<F> part = Jac<F>::infinity();
+        bool started = false;
+        for (int bit = 255; bit >= 0; --bit) {
+            if (started) part = jac_dbl_ni(part);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if ((sc[e].l[bit >> 5] >> (bit & 31)) & 1) {
+                    part = jac_madd_ni(part, g[base + i0 + e]);
+                    started = true;
+                }
+            }
+        }
+        acc = jac_add_ni(acc, part);
+    }
+    y[base + k] = acc;
+}
+
+// out[k] = sum_i M[i][k] bases[i], k < t.n, for the interpolation map M of the tree's node set (bases: t.n affine points, Montgomery)
+template <class F>
+void group_interp_transpose(zk_ctx* ctx, const InterpTree& t, const Aff<F>* d_bases, Aff<F>* d_out) {
+    const size_t n = t.n, npad = (size_t)1 << t.log_npad;
+    hipStream_t st = ctx->stream;
+    unsigned lg = 0;
+    while ((1u << lg) < (unsigned)GB) ++lg;
+    const unsigned levels = t.log_npad - lg;
+    DevBuf<Jac<F>> cur(npad), h(levels ? 2 * npad : 1);
+    hipLaunchKernelGGL(k_gb_load<F>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, d_bases, n, npad, cur.p);
+    ZK_HIP(hipGetLastError());
+    DevBuf<Fr> tw_f, tw_i;
+    if (levels) {   // canonical w^j and w^-j, j < npad / 2, w of order npad (the largest transform: the root's 2s = npad points)
+        tw_f.alloc(npad / 2); tw_i.alloc(npad / 2);
+        const Fr w = host_root_of_unity(t.log_npad);
+        fr_powers(ctx, w, Fr::one(), tw_f.p, npad / 2);
+        fr_powers(ctx, w.inv(), Fr::one(), tw_i.p, npad / 2);
+        fr_from_mont(ctx, tw_f.p, tw_f.p, npad / 2);
+        fr_from_mont(ctx, tw_i.p, tw_i.p, npad / 2);
+    }
+    for (unsigned l = levels; l-- > 0;) {
+        const size_t s = (size_t)GB << l, s2 = 2 * s, parents = npad / s2;
+        const unsigned L = lg + l + 1;   // log2(2s)
+        for (unsigned stg = 0; stg < L; ++stg)
+            hipLaunchKernelGGL((k_gb_stage<F, false>), dim3(ceil_div(npad / 2, 64)), dim3(64), 0, st, cur.p, npad, L, stg, tw_i.p, t.log_npad);
+        const Fr scale = host_fr_pow(host_fr_from_u64(2), L).inv();
+        hipLaunchKernelGGL(k_gb_spread<F>, dim3(ceil_div(2 * npad, 64)), dim3(64), 0, st, cur.p, t.nev[l].p, scale, s2, parents, h.p);
+        for (unsigned stg = 0; stg < L; ++stg)
+            hipLaunchKernelGGL((k_gb_stage<F, true>), dim3(ceil_div(npad, 64)), dim3(64), 0, st, h.p, 2 * npad, L, stg, tw_f.p, t.log_npad);
+        hipLaunchKernelGGL(k_gb_truncate<F>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, h.p, s, npad, cur.p);
+        ZK_HIP(hipGetLastError());
+    }
+    DevBuf<Aff<F>> ga(npad);
+    hipLaunchKernelGGL(k_gb_affine<F>, dim3(ceil_div(npad, 64)), dim3(64), 0, st, cur.p, npad, ga.p);
+    DevBuf<Jac<F>> y(npad);
+    hipLaunchKernelGGL(k_gb_bottom<F>, dim3(npad / GB), dim3(GB), 0, st, ga.p, t.qmat.p, n, y.p);
+    hipLaunchKernelGGL(k_gb_affine<F>, dim3(ceil_div(n, 64)), dim3(64), 0, st, y.p, n, d_out);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(st));   // the temporaries go out of scope
+}
+template void group_interp_transpose<Fq>(zk_ctx*, const InterpTree&, const Aff<Fq>*, Aff<Fq>*);
+template void group_interp_transpose<Fq2>(zk_ctx*, const InterpTree&, const Aff<Fq2>*, Aff<Fq2>*);
+
+// nodes first .. first + count - 1 as Montgomery field elements
+__global__ void k_gb_integer_nodes(uint64_t first, size_t count, Fr* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    Fr v = Fr::zero();
+    v.l[0] = (uint32_t)(first + k); v.l[1] = (uint32_t)((first + k) >> 32);
+    out[k] = Fr::from_canonical(v);
+}
+
+// The three Lagrange-basis arrays of an integer-roots QAP from the powers of the CRS (basis.hip's header has the definitions)
+void crs_lagrange_from_powers_tree(zk_ctx* ctx, zk_crs& c, const zk_qap& q) {
+    const size_t n = c.n;
+    ZK_REQUIRE(q.roots && q.ap && q.n == n, ZK_ERR_ARG, "crs_lagrange_from_powers: not an integer-roots QAP of this CRS");
+    ZK_REQUIRE(n <= ((size_t)1 << (NTT_MAX_LOG - 2)), ZK_ERR_UNSUPPORTED, "prove: an integer-roots QAP of more than 2^22 gates needs the CRS zk_setup made for it");
+    c.lag1.alloc(n); c.lag2.alloc(n); c.lagS_t1.alloc(std::max<size_t>(n - 1, 1));
+    hipStream_t st = ctx->stream;
+    DevBuf<int> flag(1);
+    ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    {
+        DevBuf<Fr> nodes(n);
+        hipLaunchKernelGGL(k_gb_integer_nodes, dim3(ceil_div(n, 256)), dim3(256), 0, st, (uint64_t)1, n, nodes.p);
+        ZK_HIP(hipGetLastError());
+        auto tree = interp_build(ctx, nodes.p, n, flag.p);
+        group_interp_transpose<Fq>(ctx, *tree, c.xi1.p, c.lag1.p);
+        group_interp_transpose<Fq2>(ctx, *tree, c.xi2.p, c.lag2.p);
+    }
+    if (n >= 2) {
+        DevBuf<Fr> nodes(n - 1);
+        hipLaunchKernelGGL(k_gb_integer_nodes, dim3(ceil_div(n - 1, 256)), dim3(256), 0, st, (uint64_t)n + 1, n - 1, nodes.p);
+        ZK_HIP(hipGetLastError());
+        auto tree = interp_build(ctx, nodes.p, n - 1, flag.p);
+        group_interp_transpose<Fq>(ctx, *tree, c.xi_t1.p, c.lagS_t1.p);
+    }
+    c.ap = true;
+}
+
+}  // namespace zk

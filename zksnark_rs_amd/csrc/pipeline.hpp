@@ -126,6 +126,7 @@ void crs_attach_lagrange(zk_ctx*, zk_crs&, const uint64_t* lag1, const uint64_t*
 void crs_ensure_fixed_tables(zk_ctx*, zk_crs&);
 size_t basis_max_n();                                              // the largest n crs_lagrange_from_powers takes
 void arb_attach_integer_roots(zk_ctx*, zk_qap&);                    // arbroots.hip: the tree of the roots 1..n for an integer-roots QAP (see prove.hip)
+void crs_lagrange_from_powers_tree(zk_ctx*, zk_crs&, const zk_qap&);   // gbasis.hip: the same arrays by the transposed interpolation tree, O(n log^2 n) point operations
 void crs_lagrange_from_powers(zk_ctx*, zk_crs&, const zk_qap&);   // basis.hip: the Lagrange-basis points of an integer-roots QAP from the powers (once per CRS)
 
 void prove_host(zk_ctx*, const zk_crs&, const zk_qap&, const uint64_t* weights, size_t m, const uint64_t r[4], const uint64_t s[4], uint8_t* proof_out);
