@@ -17,6 +17,7 @@
 #include <vector>
 #include "pipeline.hpp"
 #include "interp.hpp"
+#include "lazy29.cuh"
 
 namespace zk {
 
@@ -29,10 +30,34 @@ __global__ void k_gb_load(const Aff<F>* __restrict__ bases, size_t n, size_t npa
     if (i < npad) data[i] = i < n ? Jac<F>::from_affine(bases[i]) : Jac<F>::infinity();
 }
 
+// k P for a canonical scalar k < r: the addition-subtraction chain of the non-adjacent form (digit i = bit i of 3k minus bit i of k,
+// read from the top: 255 doublings and ~85 additions of +-P), in the lazy radix of lazy29.cuh (dbl_lazy 2M + 5S, add_lazy 12M + 4S).
 template <class F>
-__device__ __forceinline__ Jac<F> gb_mul(const Jac<F>& p, const Fr& k_canonical) {
-    if (p.is_inf()) return p;
-    return jac_mul_words(p, k_canonical.l);
+__device__ __noinline__ JacR<F> gb_mul(const JacR<F>& p, const Fr& k) {
+    JacR<F> acc = p;
+    acc.inf = true;
+    if (p.inf) return acc;
+    uint32_t h[9];   // 3k
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c += 3ull * k.l[i]; h[i] = (uint32_t)c; c >>= 32; }
+        h[8] = (uint32_t)c;
+    }
+    JacR<F> m = p;
+    m.Y = p.Y.neg().norm();
+    for (int i = 256; i >= 1; --i) {
+        if (!acc.inf) acc = dbl_lazy(acc);
+        const uint32_t hb = (h[i >> 5] >> (i & 31)) & 1, kb = i < 256 ? (k.l[i >> 5] >> (i & 31)) & 1 : 0;
+        if (hb != kb) acc = add_lazy(acc, hb ? p : m);
+    }
+    return acc;
+}
+template <class F>
+__device__ __forceinline__ JacR<F> gb_neg(const JacR<F>& p) {
+    JacR<F> m = p;
+    m.Y = p.Y.neg().norm();
+    return m;
 }
 
 // One radix-2 stage over `total` points holding total >> log_size transforms of 2^log_size points each.  tw: canonical w_T^j, j < T / 2,
@@ -49,16 +74,17 @@ __global__ __launch_bounds__(64) void k_gb_stage(Jac<F>* __restrict__ data, size
     // exponent of w_N, then of the table's w_T
     const size_t e = DIT ? j << (log_size - 1 - log_half) : j << stage;
     const size_t idx = e << (log_table - log_size);
-    Jac<F> x = data[i0], y = data[i1];
+    const JacR<F> x = jacr_load(data[i0]);
+    JacR<F> y = jacr_load(data[i1]);
     if (DIT) {
         if (idx) y = gb_mul(y, tw[idx]);
-        data[i0] = jac_add_ni(x, y);
-        data[i1] = jac_add_ni(x, y.neg());
+        data[i0] = jacr_store(add_lazy(x, y));
+        data[i1] = jacr_store(add_lazy(x, gb_neg(y)));
     } else {
-        data[i0] = jac_add_ni(x, y);
-        Jac<F> d = jac_add_ni(x, y.neg());
+        data[i0] = jacr_store(add_lazy(x, y));
+        JacR<F> d = add_lazy(x, gb_neg(y));
         if (idx) d = gb_mul(d, tw[idx]);
-        data[i1] = d;
+        data[i1] = jacr_store(d);
     }
 }
 
@@ -69,7 +95,7 @@ __global__ __launch_bounds__(64) void k_gb_spread(const Jac<F>* __restrict__ u, 
     if (g >= parents * 2 * s2) return;
     const size_t c = g / s2, j = g - c * s2, p = c >> 1;
     const Fr k = (nev[(c ^ 1) * s2 + j] * scale).to_canonical();
-    h[g] = gb_mul(u[p * s2 + j], k);
+    h[g] = jacr_store(gb_mul(jacr_load(u[p * s2 + j]), k));
 }
 // next[c s + j] = h[c 2s + j], j < s
 template <class F>
@@ -93,26 +119,26 @@ __global__ __launch_bounds__(GB) void k_gb_bottom(const Aff<F>* __restrict__ g, 
     if (base + k >= n) return;
     const int real = (int)(n - base < (size_t)GB ? n - base : GB);
     const Fr* q = qmat + base * GB + (size_t)k * GB;
-    Jac<F> acc = Jac<F>::infinity();
+    JacR<F> acc = jacr_load(Jac<F>::infinity());
     for (int i0 = 0; i0 < real; i0 += 8) {
         Fr sc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) sc[e] = i0 + e < real ? q[i0 + e].to_canonical() : Fr::zero();
-        Jac<F> part = Jac<F>::infinity();
-        bool started = false;
+        typedef typename LazyOf<F>::type L;
+        JacR<F> part = jacr_load(Jac<F>::infinity());
         for (int bit = 255; bit >= 0; --bit) {
-            if (started) part = jac_dbl_ni(part);
-#pragma unroll
+            if (!part.inf) part = dbl_lazy(part);
             for (int e = 0; e < 8; ++e) {
                 if ((sc[e].l[bit >> 5] >> (bit & 31)) & 1) {
-                    part = jac_madd_ni(part, g[base + i0 + e]);
-                    started = true;
+                    const Aff<F> pt = g[base + i0 + e];
+                    if (pt.is_inf()) continue;
+                    if (!madd_lazy(part, L::load(pt.x), L::load(pt.y))) part = dbl_lazy(part);
                 }
             }
         }
-        acc = jac_add_ni(acc, part);
+        acc = add_lazy(acc, part);
     }
-    y[base + k] = acc;
+    y[base + k] = jacr_store(acc);
 }
 
 // out[k] = sum_i M[i][k] bases[i], k < t.n, for the interpolation map M of the tree's node set (bases: t.n affine points, Montgomery)

@@ -388,12 +388,14 @@ static void launch_pre(zk_ctx* ctx, const zk_crs& crs, hipStream_t st, const Fr&
 // inner products of the multi-GPU exchange -- ADVICE r3: they used to differ):
 //   0 roots of unity, 1 integer roots in the evaluation basis, 2 coefficients by the sub-product tree (arbroots.hip), 3 dense.
 // An integer-roots QAP over a CRS that carries only the powers (zk_crs_upload, ZKCRSv1) gets the Lagrange-basis points by the change
-// of basis, once per CRS, up to basis_max_n() gates; beyond, it proves in form 2 with the roots 1..n as caller data -- the same bytes
-// from ANY CRS.  One-off tables of forms 2 / 3 (the power-series inverse of rev(t)) are built here, before anything is enqueued.
+// of basis, once per CRS: the transposed interpolation tree (gbasis.hip, O(n log^2 n) point operations, to 2^22 gates) or, below
+// basis_tree_min gates, the n^2 inner products (basis.hip, to basis_max_n()); with the tree switched off it proves beyond that in
+// form 2 with the roots 1..n as caller data -- the same bytes from ANY CRS.  One-off tables of forms 2 / 3 (the power-series inverse of rev(t)) are built here, before anything is enqueued.
 static int prove_form(zk_ctx* ctx, zk_crs& crs, const zk_qap& q) {
     int form = q.dense ? 3 : q.roots;
     if (form == 1 && !crs.ap) {
-        if (q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
+        const bool tree = ctx->opt_basis_tree_min >= 0 && q.n >= (size_t)ctx->opt_basis_tree_min && q.n <= ((size_t)1 << (NTT_MAX_LOG - 2));
+        if (tree || q.n <= basis_max_n()) crs_lagrange_from_powers(ctx, crs, q);
         else { arb_attach_integer_roots(ctx, const_cast<zk_qap&>(q)); form = 2; }
     }
     if (form >= 2 && !q.t_is_zero && 2 * q.n - 1 > q.t_degree && 2 * q.n - 1 - q.t_degree >= 512 && !ctx->opt_long_division) {
