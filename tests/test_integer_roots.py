@@ -292,9 +292,27 @@ def test_gpu_change_of_basis_by_the_transposed_tree(ctx, tmp_path, n):
 
 @pytest.mark.gpu
 def test_gpu_uploaded_crs_beyond_the_change_of_basis(ctx, orc):
-    """Above 2^16 + 2^10 gates the O(n^2) change of basis is not attempted: an integer-roots QAP over a CRS that carries only the
-    reference's arrays proves through the sub-product tree of the roots 1..n instead (csrc/arbroots.hip) -- the same bytes, which
-    the closed form pins, from the uploaded CRS and again from the CRS zk_setup made (evaluation basis)."""
+    """Above 2^16 + 2^10 gates the O(n^2) change of basis is not attempted.  With the transposed tree switched off (option basis_tree_min
+    < 0: the round-3 behaviour) an integer-roots QAP over a CRS that carries only the reference's arrays proves through the sub-product
+    tree of the roots 1..n instead (csrc/arbroots.hip) -- the same bytes, which the closed form pins, from the uploaded CRS and again
+    from the CRS zk_setup made (evaluation basis).  The default (csrc/gbasis.hip) is covered by test_gpu_change_of_basis_at_2_17."""
+    ctx.set_option("basis_tree_min", -1)
+    try:
+        _beyond_the_n2_change_of_basis(ctx, orc, True)
+    finally:
+        ctx.set_option("basis_tree_min", 16384)
+
+
+@pytest.mark.gpu
+def test_gpu_change_of_basis_at_2_17(ctx, orc):
+    """The default above 16384 gates: the Lagrange-basis points by the transposed interpolation tree (csrc/gbasis.hip, seconds at this
+    size, O(n log^2 n)), after which the uploaded CRS proves in the evaluation basis like the one zk_setup wrote: closed-form bytes,
+    valid and invalid witness."""
+    assert ctx.get_option("basis_tree_min") == 16384
+    _beyond_the_n2_change_of_basis(ctx, orc, False)
+
+
+def _beyond_the_n2_change_of_basis(ctx, orc, others):
     n = (1 << 17) + 5
     m, l, u, v, w = chain_rows_integers(n)
     rng = SplitMix64(9650)
@@ -312,6 +330,8 @@ def test_gpu_uploaded_crs_beyond_the_change_of_basis(ctx, orc):
     bad = weights.copy(); bad[n // 3, 0] ^= np.uint64(1)
     want_bad = orc.trapdoor_proof_integers(desc, n, td, bad, r, s)
     assert ctx.prove(up, qap, bad, r, s) == want_bad
+    if not others:
+        return
     # round 4: every entry point decides the form in one place (prove_form) -- a batch and the multi-GPU pipeline over the uploaded CRS
     # take the same fall-back and give the same bytes (they used to answer ZK_ERR_UNSUPPORTED after the scalars had been exchanged)
     torch = pytest.importorskip("torch")

@@ -110,7 +110,7 @@ struct zk_ctx {
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
     long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
-    long opt_basis_tree_min = 512; // integer-roots QAP over a powers-only CRS: from this many gates on the Lagrange-basis points come from the transposed interpolation tree (gbasis.hip), below from the n^2 inner products (basis.hip)
+    long opt_basis_tree_min = 16384; // integer-roots QAP over a powers-only CRS: from this many gates on the Lagrange-basis points come from the transposed interpolation tree (gbasis.hip), below from the n^2 inner products (basis.hip)
     long opt_g2_affine = 0;       // G2 inner products: rounds of pairwise AFFINE sums with shared inversions in front of the XYZZ accumulation (g2_affine.cuh); zk_g2_add_batch takes the same kernel
     long opt_lone_graph = 0;      // zk_prove / zk_prove_dev: a lone proof of a (CRS, QAP, witness length) seen before replays one captured hipGraph (prove.hip prove_graph)
     bool graph_capture = false;   // prove_submit is being captured: per-proof factors come from the slot's parameter block, nothing outside the capture is waited for
