@@ -30,26 +30,126 @@ __global__ void k_gb_load(const Aff<F>* __restrict__ bases, size_t n, size_t npa
     if (i < npad) data[i] = i < n ? Jac<F>::from_affine(bases[i]) : Jac<F>::infinity();
 }
 
-// k P for a canonical scalar k < r: the addition-subtraction chain of the non-adjacent form (digit i = bit i of 3k minus bit i of k,
-// read from the top: 255 doublings and ~85 additions of +-P), in the lazy radix of lazy29.cuh (dbl_lazy 2M + 5S, add_lazy 12M + 4S).
+// ---- k P with the curve's endomorphism (GLV) ------------------------------------------------------------------------------------
+// phi(x, y) = (beta x, y) with beta^3 = 1 in Fq is multiplication by lambda (lambda^2 + lambda + 1 = 0 mod r) on G1, and -- with the other
+// cube root as beta -- on the order-r subgroup of the twist (both checked numerically against k P: tools/glv_constants.py).  A scalar
+// splits as k = k1 + k2 lambda with |k1|, |k2| < 2^128 (Babai rounding against the lattice basis (a1, b1), (a2, b2) of
+// {(x, y): x + y lambda = 0 mod r}; the roundings c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256) with g1 = floor(2^256 b2 / r),
+// g2 = floor(2^256 (-b1) / r) are off by at most one, which keeps the bound), so k P = k1 P + k2 phi(P) costs 129 doublings instead
+// of 255; the two halves run as interleaved non-adjacent forms (digit i = bit i of 3k minus bit i of k): ~86 additions.
+__device__ __constant__ const uint32_t GLV_G1[5] = {0x00ff6565u, 0x5398fd03u, 0xa773d2d2u, 0x4ccef014u, 0x00000002u};
+__device__ __constant__ const uint32_t GLV_G2[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};
+__device__ __constant__ const uint32_t GLV_A1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};
+__device__ __constant__ const uint32_t GLV_NB1[2] = {0x94d213e3u, 0x89d32568u};   // -b1 = a2
+__device__ __constant__ const uint32_t GLV_B2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+static const uint32_t GLV_BETA_G1[8] = {0x607cfd48u, 0xe4bd44e5u, 0xbb966e3du, 0xc28f069fu, 0xe0acccb0u, 0x5e6dd9e7u, 0xe131a029u, 0x30644e72u};
+static const uint32_t GLV_BETA_G2[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0x00000000u, 0x00000000u};
+template <class F> Fq glv_beta() {   // Montgomery form
+    Fq b;
+    for (int i = 0; i < 8; ++i) b.l[i] = sizeof(F) > sizeof(Fq) ? GLV_BETA_G2[i] : GLV_BETA_G1[i];
+    return Fq::from_canonical(b);
+}
+
+// out[0 .. NO) = low NO words of a[0 .. NA) * b[0 .. NB), starting at word `skip` of the product
+template <int NA, int NB, int NO>
+__device__ __forceinline__ void mp_mul(const uint32_t* a, const uint32_t* b, int skip, uint32_t* out) {
+    uint32_t prod[NA + NB];
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            c += (uint64_t)a[i] * b[j] + prod[i + j];
+            prod[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        prod[i + NB] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 0; i < NO; ++i) out[i] = skip + i < NA + NB ? prod[skip + i] : 0;
+}
+// |k1|, |k2| (5 words each, < 2^128) and their signs
+__device__ __forceinline__ void glv_split(const Fr& k, uint32_t* k1, bool& neg1, uint32_t* k2, bool& neg2) {
+    uint32_t kw[8], c1[5], c2[3], g1[5], g2[3], a1[4], nb1[2], b2[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kw[i] = k.l[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) g1[i] = GLV_G1[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g2[i] = GLV_G2[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] = GLV_A1[i]; b2[i] = GLV_B2[i]; }
+    nb1[0] = GLV_NB1[0]; nb1[1] = GLV_NB1[1];
+    mp_mul<8, 5, 5>(kw, g1, 8, c1);     // c1 = floor(k g1 / 2^256) < 2^128
+    mp_mul<8, 3, 3>(kw, g2, 8, c2);     // c2 < 2^65
+    // all in 6 words modulo 2^192 (the results fit 129 signed bits):  k1 = k - c1 a1 - c2 a2,  k2 = c1 (-b1) - c2 b2,  a2 = -b1
+    uint32_t t1[6], t2[6], t3[6], t4[6];
+    mp_mul<5, 4, 6>(c1, a1, 0, t1);
+    mp_mul<3, 2, 6>(c2, nb1, 0, t2);
+    mp_mul<5, 2, 6>(c1, nb1, 0, t3);
+    mp_mul<3, 4, 6>(c2, b2, 0, t4);
+    uint32_t r1[6], r2[6];
+    {
+        int64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const int64_t v = (int64_t)kw[i] - t1[i] - t2[i] + br; r1[i] = (uint32_t)v; br = v >> 32; }
+        br = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const int64_t v = (int64_t)t3[i] - t4[i] + br; r2[i] = (uint32_t)v; br = v >> 32; }
+    }
+    neg1 = (r1[5] >> 31) != 0; neg2 = (r2[5] >> 31) != 0;
+    {
+        uint64_t c = neg1 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { c += neg1 ? (uint32_t)~r1[i] : r1[i]; if (i < 5) k1[i] = (uint32_t)c; c >>= 32; }
+        c = neg2 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { c += neg2 ? (uint32_t)~r2[i] : r2[i]; if (i < 5) k2[i] = (uint32_t)c; c >>= 32; }
+    }
+}
+__device__ __forceinline__ uint32_t mp_bit(const uint32_t* w, int i) { return (w[i >> 5] >> (i & 31)) & 1; }
+
+template <class F> struct GlvPhi;
+template <> struct GlvPhi<Fq> { static __device__ __forceinline__ FpR<FqParams> mul(const FpR<FqParams>& x, const FpR<FqParams>& beta) { return x * beta; } };
+template <> struct GlvPhi<Fq2> { static __device__ __forceinline__ Fp2R<FqParams> mul(const Fp2R<FqParams>& x, const FpR<FqParams>& beta) { return Fp2R<FqParams>{x.c0 * beta, x.c1 * beta}; } };
+
+// k P for a canonical scalar k < r (P in the order-r subgroup)
 template <class F>
-__device__ __noinline__ JacR<F> gb_mul(const JacR<F>& p, const Fr& k) {
+__device__ __noinline__ JacR<F> gb_mul(const JacR<F>& p, const Fr& k, const Fq& beta) {
     JacR<F> acc = p;
     acc.inf = true;
     if (p.inf) return acc;
-    uint32_t h[9];   // 3k
+    uint32_t k1[6], k2[6], h1[6], h2[6];
+    bool neg1, neg2;
+    glv_split(k, k1, neg1, k2, neg2);
+    k1[5] = k2[5] = 0;
     {
         uint64_t c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { c += 3ull * k.l[i]; h[i] = (uint32_t)c; c >>= 32; }
-        h[8] = (uint32_t)c;
+        for (int i = 0; i < 6; ++i) { c += 3ull * k1[i]; h1[i] = (uint32_t)c; c >>= 32; }
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { c += 3ull * k2[i]; h2[i] = (uint32_t)c; c >>= 32; }
     }
-    JacR<F> m = p;
-    m.Y = p.Y.neg().norm();
-    for (int i = 256; i >= 1; --i) {
+    JacR<F> p1 = p, p2 = p;
+    p2.X = GlvPhi<F>::mul(p.X, FpR<FqParams>::load(beta));
+    if (neg1) p1.Y = p.Y.neg().norm();
+    if (neg2) p2.Y = p.Y.neg().norm();
+    for (int i = 130; i >= 1; --i) {
         if (!acc.inf) acc = dbl_lazy(acc);
-        const uint32_t hb = (h[i >> 5] >> (i & 31)) & 1, kb = i < 256 ? (k.l[i >> 5] >> (i & 31)) & 1 : 0;
-        if (hb != kb) acc = add_lazy(acc, hb ? p : m);
+        const uint32_t d1 = mp_bit(h1, i) - mp_bit(k1, i), d2 = mp_bit(h2, i) - mp_bit(k2, i);   // 0, 1 or 0xffffffff
+        if (d1) {
+            JacR<F> q = p1;
+            if (d1 != 1) q.Y = p1.Y.neg().norm();
+            acc = add_lazy(acc, q);
+        }
+        if (d2) {
+            JacR<F> q = p2;
+            if (d2 != 1) q.Y = p2.Y.neg().norm();
+            acc = add_lazy(acc, q);
+        }
     }
     return acc;
 }
@@ -65,7 +165,7 @@ __device__ __forceinline__ JacR<F> gb_neg(const JacR<F>& p) {
 // DIF (natural -> bit-reversed), stage t = 0 .. L-1: half = N >> (t + 1); (x, y) -> (x + y, (x - y) w_N^(j 2^t))
 // DIT (bit-reversed -> natural), stage t = 0 .. L-1: half = 1 << t;       (x, y) -> (x + w y, x - w y), w = w_N^(j N / (2 half))
 template <class F, bool DIT>
-__global__ __launch_bounds__(64) void k_gb_stage(Jac<F>* __restrict__ data, size_t total, unsigned log_size, unsigned stage, const Fr* __restrict__ tw, unsigned log_table) {
+__global__ __launch_bounds__(64) void k_gb_stage(Jac<F>* __restrict__ data, size_t total, unsigned log_size, unsigned stage, const Fr* __restrict__ tw, unsigned log_table, Fq beta) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= total / 2) return;
     const unsigned log_half = DIT ? stage : log_size - 1 - stage;
@@ -77,25 +177,25 @@ __global__ __launch_bounds__(64) void k_gb_stage(Jac<F>* __restrict__ data, size
     const JacR<F> x = jacr_load(data[i0]);
     JacR<F> y = jacr_load(data[i1]);
     if (DIT) {
-        if (idx) y = gb_mul(y, tw[idx]);
+        if (idx) y = gb_mul(y, tw[idx], beta);
         data[i0] = jacr_store(add_lazy(x, y));
         data[i1] = jacr_store(add_lazy(x, gb_neg(y)));
     } else {
         data[i0] = jacr_store(add_lazy(x, y));
         JacR<F> d = add_lazy(x, gb_neg(y));
-        if (idx) d = gb_mul(d, tw[idx]);
+        if (idx) d = gb_mul(d, tw[idx], beta);
         data[i1] = jacr_store(d);
     }
 }
 
 // children' = N_sibling . u / 2s:  h[2p][j] = (nev[2p + 1][j] scale) u[p][j],  h[2p + 1][j] = (nev[2p][j] scale) u[p][j],  j < 2s
 template <class F>
-__global__ __launch_bounds__(64) void k_gb_spread(const Jac<F>* __restrict__ u, const Fr* __restrict__ nev, Fr scale, size_t s2, size_t parents, Jac<F>* __restrict__ h) {
+__global__ __launch_bounds__(64) void k_gb_spread(const Jac<F>* __restrict__ u, const Fr* __restrict__ nev, Fr scale, size_t s2, size_t parents, Jac<F>* __restrict__ h, Fq beta) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= parents * 2 * s2) return;
     const size_t c = g / s2, j = g - c * s2, p = c >> 1;
     const Fr k = (nev[(c ^ 1) * s2 + j] * scale).to_canonical();
-    h[g] = jacr_store(gb_mul(jacr_load(u[p * s2 + j]), k));
+    h[g] = jacr_store(gb_mul(jacr_load(u[p * s2 + j]), k, beta));
 }
 // next[c s + j] = h[c 2s + j], j < s
 template <class F>
@@ -153,6 +253,7 @@ void group_interp_transpose(zk_ctx* ctx, const InterpTree& t, const Aff<F>* d_ba
     hipLaunchKernelGGL(k_gb_load<F>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, d_bases, n, npad, cur.p);
     ZK_HIP(hipGetLastError());
     DevBuf<Fr> tw_f, tw_i;
+    const Fq beta = glv_beta<F>();
     if (levels) {   // canonical w^j and w^-j, j < npad / 2, w of order npad (the largest transform: the root's 2s = npad points)
         tw_f.alloc(npad / 2); tw_i.alloc(npad / 2);
         const Fr w = host_root_of_unity(t.log_npad);
@@ -165,11 +266,11 @@ void group_interp_transpose(zk_ctx* ctx, const InterpTree& t, const Aff<F>* d_ba
         const size_t s = (size_t)GB << l, s2 = 2 * s, parents = npad / s2;
         const unsigned L = lg + l + 1;   // log2(2s)
         for (unsigned stg = 0; stg < L; ++stg)
-            hipLaunchKernelGGL((k_gb_stage<F, false>), dim3(ceil_div(npad / 2, 64)), dim3(64), 0, st, cur.p, npad, L, stg, tw_i.p, t.log_npad);
+            hipLaunchKernelGGL((k_gb_stage<F, false>), dim3(ceil_div(npad / 2, 64)), dim3(64), 0, st, cur.p, npad, L, stg, tw_i.p, t.log_npad, beta);
         const Fr scale = host_fr_pow(host_fr_from_u64(2), L).inv();
-        hipLaunchKernelGGL(k_gb_spread<F>, dim3(ceil_div(2 * npad, 64)), dim3(64), 0, st, cur.p, t.nev[l].p, scale, s2, parents, h.p);
+        hipLaunchKernelGGL(k_gb_spread<F>, dim3(ceil_div(2 * npad, 64)), dim3(64), 0, st, cur.p, t.nev[l].p, scale, s2, parents, h.p, beta);
         for (unsigned stg = 0; stg < L; ++stg)
-            hipLaunchKernelGGL((k_gb_stage<F, true>), dim3(ceil_div(npad, 64)), dim3(64), 0, st, h.p, 2 * npad, L, stg, tw_f.p, t.log_npad);
+            hipLaunchKernelGGL((k_gb_stage<F, true>), dim3(ceil_div(npad, 64)), dim3(64), 0, st, h.p, 2 * npad, L, stg, tw_f.p, t.log_npad, beta);
         hipLaunchKernelGGL(k_gb_truncate<F>, dim3(ceil_div(npad, 256)), dim3(256), 0, st, h.p, s, npad, cur.p);
         ZK_HIP(hipGetLastError());
     }
