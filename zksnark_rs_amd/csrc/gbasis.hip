@@ -112,8 +112,19 @@ __device__ __forceinline__ void glv_split(const Fr& k, uint32_t* k1, bool& neg1,
 __device__ __forceinline__ uint32_t mp_bit(const uint32_t* w, int i) { return (w[i >> 5] >> (i & 31)) & 1; }
 
 template <class F> struct GlvPhi;
-template <> struct GlvPhi<Fq> { static __device__ __forceinline__ FpR<FqParams> mul(const FpR<FqParams>& x, const FpR<FqParams>& beta) { return x * beta; } };
-template <> struct GlvPhi<Fq2> { static __device__ __forceinline__ Fp2R<FqParams> mul(const Fp2R<FqParams>& x, const FpR<FqParams>& beta) { return Fp2R<FqParams>{x.c0 * beta, x.c1 * beta}; } };
+template <> struct GlvPhi<Fq> {
+    typedef FpR<FqParams> L;
+    static __device__ __forceinline__ L mul(const L& x, const L& beta) { return x * beta; }
+    static __device__ __forceinline__ L inv(const L& z) { return L::load(z.store_exact().inv_vartime()); }
+};
+template <> struct GlvPhi<Fq2> {
+    typedef FpR<FqParams> L;
+    static __device__ __forceinline__ Fp2R<FqParams> mul(const Fp2R<FqParams>& x, const L& beta) { return Fp2R<FqParams>{x.c0 * beta, x.c1 * beta}; }
+    static __device__ __forceinline__ Fp2R<FqParams> inv(const Fp2R<FqParams>& z) {   // conj(z) / (z0^2 + z1^2)
+        const L ni = L::load(L::mont_sum(z.c0, z.c0, z.c1, z.c1).store_exact().inv_vartime());
+        return Fp2R<FqParams>{z.c0 * ni, (z.c1 * ni).neg().norm()};
+    }
+};
 
 // k P for a canonical scalar k < r (P in the order-r subgroup)
 template <class F>
@@ -133,23 +144,16 @@ __device__ __noinline__ JacR<F> gb_mul(const JacR<F>& p, const Fr& k, const Fq& 
 #pragma unroll
         for (int i = 0; i < 6; ++i) { c += 3ull * k2[i]; h2[i] = (uint32_t)c; c >>= 32; }
     }
-    JacR<F> p1 = p, p2 = p;
-    p2.X = GlvPhi<F>::mul(p.X, FpR<FqParams>::load(beta));
-    if (neg1) p1.Y = p.Y.neg().norm();
-    if (neg2) p2.Y = p.Y.neg().norm();
+    // P in affine coordinates (one variable-time inversion: the points are public), so that the ~86 additions are mixed ones
+    typedef typename LazyOf<F>::type L;
+    const L zi = GlvPhi<F>::inv(p.Z), zi2 = zi.sqr();
+    const L x1 = p.X * zi2, x2 = GlvPhi<F>::mul(x1, FpR<FqParams>::load(beta));
+    const L yp = (p.Y * zi2) * zi, yn = yp.neg().norm();
     for (int i = 130; i >= 1; --i) {
         if (!acc.inf) acc = dbl_lazy(acc);
         const uint32_t d1 = mp_bit(h1, i) - mp_bit(k1, i), d2 = mp_bit(h2, i) - mp_bit(k2, i);   // 0, 1 or 0xffffffff
-        if (d1) {
-            JacR<F> q = p1;
-            if (d1 != 1) q.Y = p1.Y.neg().norm();
-            acc = add_lazy(acc, q);
-        }
-        if (d2) {
-            JacR<F> q = p2;
-            if (d2 != 1) q.Y = p2.Y.neg().norm();
-            acc = add_lazy(acc, q);
-        }
+        if (d1 && !madd_lazy(acc, x1, ((d1 == 1) != neg1) ? yp : yn)) acc = dbl_lazy(acc);
+        if (d2 && !madd_lazy(acc, x2, ((d2 == 1) != neg2) ? yp : yn)) acc = dbl_lazy(acc);
     }
     return acc;
 }
