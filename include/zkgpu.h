@@ -169,8 +169,8 @@ int zk_qap_upload_sparse(zk_ctx* ctx, const zk_qap_sparse_desc* desc, zk_qap** o
  * products with the CRS in those Lagrange bases, which zk_setup emits next to the reference's [x^i] arrays.  Costs
  * O(nnz + n log n) per proof where the dense form is O(m n); SURVEY.md 8-f4.  With a CRS that carries only the reference's arrays
  * (zk_crs_upload, a ZKCRSv1 file) the first proof derives the Lagrange-basis points from [x^i], once per CRS: from 16384 gates on
- * (option "basis_tree_min") by the transpose of the interpolation tree run over curve points, O(n log^2 n) point operations (3 s at
- * 2^16 gates, 62 s at 2^20, n <= 2^22; csrc/gbasis.hip), below by n^2 inner products (csrc/basis.hip).  With basis_tree_min < 0 a
+ * (option "basis_tree_min") by the transpose of the interpolation tree run over curve points, O(n log^2 n) point operations (2.2 s at
+ * 2^16 gates, 40 s at 2^20, n <= 2^22; csrc/gbasis.hip), below by n^2 inner products (csrc/basis.hip).  With basis_tree_min < 0 a
  * CRS of more than 2^16 + 2^10 gates is served through the form of zk_qap_upload_sparse_roots with the roots 1..n instead (same
  * bytes, 0.6 x the rate).
  * Batches and the multi-GPU entry points take both sparse forms. */
