@@ -56,7 +56,7 @@ python tools/trace_kernels.py "$(find $OUT/prof_stats_ser -name '*kernel_trace.c
   for n in 16 14 12 4 20; do python tools/lone_breakdown.py --log-n $n; done
   [ -x tools/_bin/ubench_assemble ] && timeout 60 tools/_bin/ubench_assemble
   python tools/time_root_tables.py 16 18 20 22
-  python tools/time_change_of_basis.py 12 14
+  python tools/time_change_of_basis.py 12 14 16
 } > $OUT/lone.txt 2>/dev/null
 for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --steps 20 --warmup 4 2>/dev/null | tail -1; done > $OUT/emul.txt
 ZK_COMM_FORCE_RCCL=1 python tools/rccl_starvation.py > $OUT/rccl_starvation.txt 2>&1
