@@ -54,6 +54,21 @@ def test_interpolation_matches_lagrange_sums(ctx, n):
     assert [limbs_to_int(x) for x in got] == lagrange_coeffs(roots, values)
 
 
+def test_interp_single_block(ctx):
+    """The layout of InterpTree::qmat ([block][node k][coefficient i], csrc/interp.hpp) pinned through ONE bottom block of known nodes:
+    with the unit vector e_k as values the interpolant IS row k of the block's matrix -- the Lagrange polynomial of node k -- so a
+    transposed read (node and coefficient swapped) shows up as the wrong polynomial for every k except on the diagonal."""
+    n = 64
+    roots = [(7 * k * k + 3 * k + 11) % R for k in range(n)]
+    assert len(set(roots)) == n
+    for k in (0, 1, 31, 62, 63):
+        values = [1 if j == k else 0 for j in range(n)]
+        got = ctx.interpolate_fr(ints_to_limbs(roots).reshape(n, 4), ints_to_limbs(values).reshape(n, 4))
+        want = lagrange_coeffs(roots, values)
+        assert [limbs_to_int(x) for x in got] == want
+        assert want[n - 1] != 0 and want != lagrange_coeffs(roots, [1 if j == (k + 1) % n else 0 for j in range(n)])
+
+
 @pytest.mark.parametrize("log_n", [10, 14, 17, 20])
 def test_interpolation_on_permuted_roots_of_unity(ctx, log_n):
     """Size-independent check: when the nodes are the 2^k-th roots of unity in a scrambled order the interpolant is the inverse

@@ -14,10 +14,16 @@ namespace zk {
 // mid-priority streams of zk_ctx_create).  Used by the multi-GPU exchange (zk_mgpu_create, option comm_cu_reserve): RCCL's send /
 // receive kernels run on the collectives' stream, which is not masked, and always find those units free instead of waiting ~2 ms
 // (p90 5 ms) for an accumulation wave to retire (profiles/r3_rccl_starvation.txt, r4_rccl_starvation.txt).  Mask layout measured
-// with tools/ubench_cumask.hip: clearing bits 0 .. 8 R - 1 takes R units from each of the 8 XCDs.
+// with tools/ubench_cumask.hip: clearing bits 0 .. 8 R - 1 takes R units from each of the 8 XCDs -- on the part it was measured on
+// (256 compute units in 8 XCDs); on anything else the option is refused rather than applied to a layout nobody measured.
+// The masked streams come from hipExtStreamCreateWithCUMask, which takes neither flags nor a priority: they are BLOCKING streams of
+// the default priority, i.e. they synchronise implicitly with the legacy NULL stream (a caller that uses it -- torch does -- gets its
+// NULL-stream work serialised against the inner products) and they no longer sit between the main streams and the tails in
+// priority.  Default off (profiles/r4_rccl_starvation.txt); the plain mid-priority non-blocking streams come back with per_xcd = 0.
 void ctx_reserve_cus(zk_ctx* ctx, int per_xcd) {
     per_xcd = std::max(0, std::min(per_xcd, 8));
     if (per_xcd == ctx->msm_cu_reserved) return;
+    ZK_REQUIRE(per_xcd == 0 || ctx->cu_count == 256, ZK_ERR_UNSUPPORTED, "comm_cu_reserve: the compute-unit mask layout is only known for 256 units in 8 XCDs");
     ZK_HIP(hipSetDevice(ctx->device));
     ZK_HIP(hipDeviceSynchronize());
     int prio_least = 0, prio_greatest = 0;

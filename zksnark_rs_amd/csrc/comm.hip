@@ -14,7 +14,12 @@
 // (zk_prove_scalars_submit / zk_prove_msm_submit / zk_prove_wait / zk_prove_combine); tests may substitute CPU stand-ins
 // so that the pipeline logic and the collectives' order run under world-size-2 gloo without a GPU.
 #include <rccl/rccl.h>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -30,12 +35,14 @@ struct zk_comm {
     int rank = 0, world = 1;
     bool custom = false;
     zk_comm_ops ops{};
-    ncclComm_t nccl = nullptr;
+    // The handle and the flag are touched by two threads (zk_comm_abort is documented as callable while another thread waits for a
+    // collective): whoever exchanges the handle out owns the ONE ncclCommAbort / ncclCommDestroy of it.
+    std::atomic<ncclComm_t> nccl{nullptr};
     bool loopback = false;          // TIMING ONLY (ZK_COMM_LOOPBACK=1): several ranks played by device-to-device copies on this stream
     hipStream_t stream = nullptr;   // collectives run here, never on the compute streams
     int* d_flag = nullptr;          // barrier / max-reduce scratch (device)
     long timeout_ms = 120000;       // every host wait for a collective is bounded by this (zk_comm_set_timeout; ZK_COMM_TIMEOUT_MS)
-    bool aborted = false;           // a wait timed out or the caller gave up: the RCCL communicator is gone, every later call is refused
+    std::atomic<bool> aborted{false};   // a wait timed out or the caller gave up: the RCCL communicator is gone, every later call is refused
 };
 
 struct zk_mgpu {
@@ -81,7 +88,8 @@ static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
         return;
     }
-    if (!c->nccl) {   // one rank, no communicator (loopback: the copies a `world`-rank exchange would receive, same sizes)
+    ncclComm_t nc = c->nccl.load();
+    if (!nc) {   // one rank, no communicator (loopback: the copies a `world`-rank exchange would receive, same sizes)
         ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank * (c->loopback ? (size_t)c->world : 1), hipMemcpyDeviceToDevice, c->stream));
         return;
     }
@@ -89,8 +97,8 @@ static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t
     // grouped send / recv pairs run on all links at once, which is what an equal-split exchange wants.
     ZK_NCCL(ncclGroupStart());
     for (int peer = 0; peer < c->world; ++peer) {
-        ZK_NCCL(ncclSend((const uint8_t*)d_send + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, c->nccl, c->stream));
-        ZK_NCCL(ncclRecv((uint8_t*)d_recv + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, c->nccl, c->stream));
+        ZK_NCCL(ncclSend((const uint8_t*)d_send + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, nc, c->stream));
+        ZK_NCCL(ncclRecv((uint8_t*)d_recv + (size_t)peer * bytes_per_rank, bytes_per_rank, ncclUint8, peer, nc, c->stream));
     }
     ZK_NCCL(ncclGroupEnd());
 }
@@ -100,28 +108,36 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
         return;
     }
-    if (!c->nccl) {
+    ncclComm_t nc = c->nccl.load();
+    if (!nc) {
         for (int g = 0; g < (c->loopback ? c->world : 1); ++g)
             ZK_HIP(hipMemcpyAsync((uint8_t*)d_recv + (size_t)g * bytes_per_rank, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
         return;
     }
-    ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->nccl, c->stream));
+    ZK_NCCL(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, nc, c->stream));
 }
 // Tears the RCCL communicator down without waiting for its peers (ncclCommAbort makes the collectives' kernels exit), so that a
 // rank whose peer died or never arrived gets its stream back instead of hanging in a device synchronisation for ever.
 static void comm_abort(zk_comm* c) {
-    c->aborted = true;
-    if (c->nccl) { (void)ncclCommAbort(c->nccl); c->nccl = nullptr; }
+    c->aborted.store(true);
+    ncclComm_t nc = c->nccl.exchange(nullptr);   // a time-out's abort racing the caller's: one of them gets the handle
+    if (nc) (void)ncclCommAbort(nc);
 }
 // Host wait for everything enqueued on the collectives' stream, BOUNDED: polls the stream (a spin for the first 2 ms -- the normal
 // case is a few hundred microseconds --, then 50 us sleeps) and, when timeout_ms pass, aborts the communicator and reports
 // ZK_ERR_COMM.  A custom transport completes inside the caller's callback.
+// A drained stream is not proof of a completed collective: ncclCommAbort (zk_comm_abort from another thread, or this function's own
+// time-out) makes RCCL's kernels LEAVE, and the stream completes over partial or untouched receive buffers.  So the flag is read
+// again after the stream reports success, and an aborted wait answers ZK_ERR_COMM whatever the stream says.
 static void comm_sync(zk_comm* c) {
     if (c->custom) return;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(c->stream);
-        if (q == hipSuccess) return;
+        if (q == hipSuccess) {
+            if (c->aborted.load()) throw StatusError{ZK_ERR_COMM, "zk_comm: the communicator was aborted while a collective was waited for; what it received is not valid"};
+            return;
+        }
         if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery (collectives' stream)"};
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (c->timeout_ms > 0 && ms > (double)c->timeout_ms) {
@@ -133,7 +149,7 @@ static void comm_sync(zk_comm* c) {
     }
 }
 static void comm_live(const zk_comm* c) {
-    ZK_REQUIRE(!c->aborted, ZK_ERR_COMM, "zk_comm: the communicator was aborted (an earlier collective timed out); create a new one");
+    ZK_REQUIRE(!c->aborted.load(), ZK_ERR_COMM, "zk_comm: the communicator was aborted (an earlier collective timed out); create a new one");
 }
 
 // ---- the default backend: this library's GPU stages -----------------------------------------------
@@ -272,7 +288,14 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
         ZK_HIP(hipMalloc((void**)&c->d_flag, 64));
         // ZK_COMM_FORCE_RCCL=1: a one-rank communicator too goes through RCCL (self send / recv, all-gather, all-reduce) -- the
         // only way to execute this file's RCCL calls on a one-GPU box (tests/test_gpu_bench.py)
-        if (const char* tmo = std::getenv("ZK_COMM_TIMEOUT_MS")) c->timeout_ms = std::atol(tmo);
+        if (const char* tmo = std::getenv("ZK_COMM_TIMEOUT_MS")) {
+            // a malformed value must not silently become 0 = "wait for ever"
+            char* end = nullptr;
+            errno = 0;
+            const long v = std::strtol(tmo, &end, 10);
+            ZK_REQUIRE(end != tmo && *end == '\0' && errno == 0 && v >= 0, ZK_ERR_ARG, "zk_comm_init: ZK_COMM_TIMEOUT_MS must be a non-negative integer (milliseconds; 0 = unbounded)");
+            c->timeout_ms = v;
+        }
         const char* force = std::getenv("ZK_COMM_FORCE_RCCL");
         // ZK_COMM_LOOPBACK=1 (bench.py --emulate-world): rank 0 of `world` ranks with copies in place of the collectives -- one rank's
         // work of a `world`-GPU run through the same code path (stream-ordered hand-overs included).  The sums it forms are NOT
@@ -289,7 +312,34 @@ int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int 
             ZK_HIP(hipSetDevice(ctx->device));
             ncclUniqueId nid;
             std::memcpy(nid.internal, id, ZK_COMM_ID_BYTES);
-            ZK_NCCL(ncclCommInitRank(&c->nccl, world, nid, rank));
+            // ncclCommInitRank blocks until every rank has joined: bounded like the collectives (timeout_ms).  The call runs on
+            // a helper thread; when the bound passes this rank gives up, and the helper -- which cannot be cancelled inside RCCL's
+            // bootstrap -- aborts whatever communicator it may still get and ends on its own.
+            struct InitJob { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+            auto job = std::make_shared<InitJob>();
+            const int device = ctx->device;
+            std::thread([job, world, nid, rank, device] {
+                (void)hipSetDevice(device);
+                ncclComm_t nc = nullptr;
+                const ncclResult_t r = ncclCommInitRank(&nc, world, nid, rank);
+                std::lock_guard<std::mutex> lk(job->m);
+                job->res = r; job->comm = nc; job->done = true;
+                if (job->abandoned && nc) (void)ncclCommAbort(nc);
+                job->cv.notify_all();
+            }).detach();
+            {
+                std::unique_lock<std::mutex> lk(job->m);
+                if (c->timeout_ms > 0) {
+                    if (!job->cv.wait_for(lk, std::chrono::milliseconds(c->timeout_ms), [&] { return job->done; })) {
+                        job->abandoned = true;
+                        throw StatusError{ZK_ERR_COMM, "zk_comm_init: ncclCommInitRank did not return within " + std::to_string(c->timeout_ms) + " ms (a rank is missing)"};
+                    }
+                } else {
+                    job->cv.wait(lk, [&] { return job->done; });
+                }
+                if (job->res != ncclSuccess) throw StatusError{ZK_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(job->res)};
+                c->nccl.store(job->comm);
+            }
         }
     });
     if (rc != ZK_OK) { zk_comm_destroy(c); return rc; }
@@ -309,7 +359,7 @@ int zk_comm_init_custom(zk_ctx* ctx, const zk_comm_ops* ops, int rank, int world
 void zk_comm_destroy(zk_comm* c) {
     if (!c) return;
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (ncclComm_t nc = c->nccl.exchange(nullptr)) (void)ncclCommDestroy(nc);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -319,9 +369,10 @@ int zk_comm_world(const zk_comm* c) { return c ? c->world : 0; }
 /* ranks of the RCCL communicator behind this zk_comm as RCCL itself counts them (ncclCommCount); 0 = no RCCL communicator
  * (one rank without ZK_COMM_FORCE_RCCL, a caller's transport, the loop-back of the measurement build, or aborted) */
 int zk_comm_rccl_ranks(const zk_comm* c) {
-    if (!c || !c->nccl) return 0;
+    ncclComm_t nc = c ? c->nccl.load() : nullptr;
+    if (!nc) return 0;
     int n = 0;
-    return ncclCommCount(c->nccl, &n) == ncclSuccess ? n : 0;
+    return ncclCommCount(nc, &n) == ncclSuccess ? n : 0;
 }
 /* bound (ms) of every host wait for a collective of this communicator: barrier, max, all-to-all, all-gather, zk_mgpu_pop.
  * 0 = wait for ever.  Default 120000, or the environment variable ZK_COMM_TIMEOUT_MS at zk_comm_init. */
@@ -345,7 +396,7 @@ int zk_comm_barrier(zk_comm* c) {
     if (c->custom) return c->ops.barrier ? c->ops.barrier(c->ops.user) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
         comm_live(c);
-        if (c->nccl) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, c->nccl, c->stream));
+        if (ncclComm_t nc = c->nccl.load()) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, nc, c->stream));
         comm_sync(c);
     });
 }
@@ -355,10 +406,11 @@ int zk_comm_max_f64(zk_comm* c, double* value) {
     if (c->custom) return c->ops.max_f64 ? c->ops.max_f64(c->ops.user, value) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
         comm_live(c);
-        if (!c->nccl) return;
+        ncclComm_t nc = c->nccl.load();
+        if (!nc) return;
         double* d = reinterpret_cast<double*>(c->d_flag) + 2;
         ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, c->nccl, c->stream));
+        ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, nc, c->stream));
         ZK_HIP(hipMemcpyAsync(value, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         comm_sync(c);
     });
@@ -438,7 +490,7 @@ int zk_mgpu_create(zk_ctx* ctx, zk_comm* c, const zk_crs* crs, const zk_qap* qap
     zk_mgpu_backend be{gpu, gpu_elems, gpu_alloc, gpu_free, gpu_scalars, gpu_msm, gpu_wait, gpu_combine};
     // over RCCL the inner-product streams leave comm_cu_reserve units per XCD to the collectives' kernels (a straggling exchange on
     // one rank stalls every peer); a lone rank or a caller's transport keeps the whole chip
-    const bool reserve = c->nccl && ctx->opt_comm_cu_reserve > 0;   // an RCCL communicator (several ranks, or one with ZK_COMM_FORCE_RCCL)
+    const bool reserve = c->nccl.load() && ctx->opt_comm_cu_reserve > 0;   // an RCCL communicator (several ranks, or one with ZK_COMM_FORCE_RCCL)
     if (reserve) {
         const int rc = comm_guard(c, nullptr, [&] { ctx_reserve_cus(ctx, (int)ctx->opt_comm_cu_reserve); });
         if (rc != ZK_OK) { delete gpu; return rc; }
@@ -456,6 +508,11 @@ void zk_mgpu_destroy(zk_mgpu* g) {
     if (!g) return;
     if (g->gpu) {   // whatever is still enqueued (released tickets, collectives) must end before the buffers go
         (void)hipSetDevice(g->gpu->ctx->device);
+        // ... but a collective whose peer hangs never ends: the bounded wait first (it aborts the communicator when the time-out
+        // passes, after which the device synchronisation below returns), as zkgpu.h promises for every host wait of a collective
+        if (g->comm && !g->comm->custom && g->comm->stream) {
+            try { comm_sync(g->comm); } catch (...) {}
+        }
         (void)hipDeviceSynchronize();
     }
     if (g->gpu && g->cu_reserved) {

@@ -1,6 +1,7 @@
 // common.hpp -- context, error plumbing, device buffers and HIP-event profiling shared by the
 // translation units of libzkgpu.so.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +36,14 @@ struct StatusError {
     } while (0)
 
 // RAII device allocation
+// Counts every device (re)allocation and release made through DevBuf, process wide.  A captured graph (prove.hip, option lone_graph)
+// bakes raw device pointers in: it is replayed only while this counter still has the value it had when the capture ended, so a slot,
+// workspace or table buffer that was regrown or freed in between -- or a new CRS / QAP at a recycled address -- can never be read
+// through a stale graph.
+inline std::atomic<uint64_t>& devbuf_generation() {
+    static std::atomic<uint64_t> g{0};
+    return g;
+}
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -52,14 +61,14 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        if (count) ZK_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        if (count) { ZK_HIP(hipMalloc((void**)&p, count * sizeof(T))); devbuf_generation().fetch_add(1, std::memory_order_relaxed); }
     }
     // grow-only: keeps the allocation when it is already large enough
     void ensure(size_t count) {
         if (count > n) alloc(count);
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { (void)hipFree(p); devbuf_generation().fetch_add(1, std::memory_order_relaxed); }
         p = nullptr;
         n = 0;
     }

@@ -58,10 +58,26 @@ __global__ void k_fr_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, si
     if (!x.raw_in_range()) { atomicOr(flag, 2); return; }
     out[i] = Fr::from_canonical(x);
 }
+// *flag |= 2 when an element is not below r (the range check of k_fr_to_mont without the conversion: the sparse prover multiplies its
+// witness in canonical form, qap.hip k_spmv)
+__global__ void k_fr_check_range(const Fr* __restrict__ in, size_t n, int* flag) {
+    ZK_LATENCY_KERNEL();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !in[i].raw_in_range()) atomicOr(flag, 2);
+}
+void fr_check_range(zk_ctx* ctx, const Fr* in, size_t n, int* d_flag) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fr_check_range, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, n, d_flag);
+    ZK_HIP(hipGetLastError());
+}
 __global__ void k_fr_from_mont(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i].to_canonical();
+    if (i < n) {   // one multiplication by the plain integer 1 in the lazy radix (the asm multiplier), closed by the exact reduction
+        Fr one = Fr::zero();
+        one.l[0] = 1;
+        out[i] = fr_store_exact(FrL::load(in[i]) * FrL::load(one));
+    }
 }
 template <class A>
 __global__ void k_pts_to_mont(const A* __restrict__ in, A* __restrict__ out, size_t n, int* flag) {

@@ -15,7 +15,9 @@ struct InterpTree {
     size_t n = 0;
     unsigned log_npad = 0;            // npad = 2^log_npad >= max(n, INTERP_BLOCK)
     DevBuf<Fr> roots, w;              // the nodes and 1 / N'(r_k), Montgomery
-    DevBuf<Fr> qmat;                  // bottom blocks: [block][i][k] = coefficient i of N_block / (x - r_k), times w_k
+    DevBuf<Fr> qmat;                  // bottom blocks: [block][k][i] = coefficient i of N_block / (x - r_k), times w_k (node k outer, coefficient i inner:
+                                      // k_interp_blocks, k_interp_scale_q, k_interp_bottom and gbasis.hip's k_gb_bottom all read this order; tests/test_arbitrary_roots.py
+                                      // test_interp_single_block pins it through one block of known nodes)
     std::vector<DevBuf<Fr>> nev;      // level l: DIF images of the children's N (children of 64 << l leaves, padded to twice that): 2 npad each
     std::vector<DevBuf<Fr>> tws;      // level l: w_4s^j / 2s, j < 2s (s = 64 << l) -- the twist in front of the second half of a parent's doubled image,
                                       // carrying the 1 / 2s of the inverse transform before it (which therefore runs unscaled)

@@ -8,6 +8,7 @@ namespace zk {
 template <class F> void field_batch(zk_ctx*, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 void fr_to_mont(zk_ctx*, const Fr* in, Fr* out, size_t n, int* d_flag);
 void fr_from_mont(zk_ctx*, const Fr* in, Fr* out, size_t n);
+void fr_check_range(zk_ctx*, const Fr* in, size_t n, int* d_flag);   // *d_flag |= 2 when an element is >= r
 template <class A> void pts_to_mont(zk_ctx*, const A* in, A* out, size_t n, int* d_flag);
 template <class A> void pts_from_mont(zk_ctx*, const A* in, A* out, size_t n);
 // *d_flag |= 4 when a finite point (Montgomery form) is not on its curve (G1: y^2 = x^3 + 3; G2: the twist)
@@ -30,7 +31,7 @@ struct NttTables {
     DevBuf<int32_t> tw29_fwd, tw29_inv;   // the same in the tiles' lazy radix, 12 words per twiddle (ntt.hip k_tw29)
     DevBuf<Fr> mid_fwd, mid_inv;     // inter-pass twiddles, n entries each (log_n > 11)
     DevBuf<Fr> coset_fwd_brev;       // g^brev(pos) / n                 (prove pipeline, DIT input order; n: of the unscaled inverse transform before it)
-    DevBuf<Fr> coset_inv_brev_half;  // g^-brev(pos) / (2 n)            (prove pipeline, h combine)
+    DevBuf<Fr> coset_inv_brev_half;  // g^-brev(pos) / (2 n) as PLAIN integers (prove pipeline, h combine: the product with a Montgomery-form value is canonical)
     Fr n_inv;                        // 1/n
 };
 std::shared_ptr<NttTables> ntt_get_tables(zk_ctx*, unsigned log_n);

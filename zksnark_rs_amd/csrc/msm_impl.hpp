@@ -133,6 +133,42 @@ __device__ __forceinline__ void for_each_digit(const Fr& k, int c, int windows, 
     }
 }
 
+// The same with the window size known at compile time: digit w is bits [C w, C w + C) of the scalar, ONE v_alignbit of two limbs whose
+// numbers are constants (the recursion below is the unrolled window loop), instead of the 8 v_alignbit that move the whole value:
+// 7 instead of 14 instructions per digit in both level-1 passes of the sort.  C = 20 and 17 (the windows of every product of 2^20
+// points and more) are instantiated; other sizes take the generic form.
+template <int C, int w, class Fn>
+__device__ __forceinline__ void digit_step_c(const Fr& k, uint32_t& carry, int& next_owned, int step, Fn& f) {
+    if constexpr (w < 254 / C + 1) {
+        constexpr int bit = C * w, lw = bit >> 5, s = bit & 31;
+        constexpr uint32_t mask = (1u << C) - 1, half = 1u << (C - 1);
+        uint32_t bits = k.l[lw];
+        if constexpr (s != 0) bits = lw + 1 < 8 ? __builtin_amdgcn_alignbit(k.l[lw + 1 < 8 ? lw + 1 : 7], bits, s) : bits >> s;
+        const uint32_t raw = (bits & mask) + carry;
+        const uint32_t neg = raw > half;
+        const uint32_t mag = neg ? (1u << C) - raw : raw;
+        carry = neg;
+        if (w == next_owned) {
+            if (mag) f(w, mag, neg);
+            next_owned += step;
+        }
+        digit_step_c<C, w + 1>(k, carry, next_owned, step, f);
+    }
+}
+template <int C, class Fn>
+__device__ __forceinline__ void for_each_digit_c(const Fr& k, int first, int step, Fn&& f) {
+    uint32_t carry = 0;
+    int next_owned = first;
+    digit_step_c<C, 0>(k, carry, next_owned, step, f);
+}
+// dispatch on the run-time window size (uniform over the launch)
+template <class Fn>
+__device__ __forceinline__ void for_each_digit_auto(const Fr& k, int c, int windows, int first, int step, Fn&& f) {
+    if (c == 20) for_each_digit_c<20>(k, first, step, f);
+    else if (c == 17) for_each_digit_c<17>(k, first, step, f);
+    else for_each_digit(k, c, windows, first, step, f);
+}
+
 #include "msm_sort.hpp"   // the counting sort and the runs (shared, field-independent kernels)
 
 // ---- bucket accumulation: one run per lane -------------------------------------------------------

@@ -20,6 +20,13 @@
 // atomics serialise).  Groups are peeled while they are large; evenly spread indices fall through to the
 // plain atomic after one round.
 __device__ __forceinline__ uint32_t lds_inc(uint32_t* ctr, uint32_t idx) {
+    // Evenly spread indices (every product of random scalars) take the plain atomic after ONE wave-uniform test -- how many active
+    // lanes share the first active lane's counter? -- instead of a round of the peeling below: the peeling's bookkeeping was ~10 of the
+    // ~35 VALU instructions a digit costs in each of the four kernels that count (round 5: profiles/r5_experiments.txt).
+    {
+        const uint32_t v0 = __builtin_amdgcn_readfirstlane(idx);
+        if (__popcll(__ballot(idx == v0)) < 8) return atomicAdd(&ctr[idx], 1u);
+    }
     uint32_t res = 0;
     bool pending = true;
     for (int round = 0; round < 6; ++round) {
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
         if (il >= gvalid) continue;
         Fr k = scalars[i];
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
-        for_each_digit(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
+        for_each_digit_auto(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
     }
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * bins;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
         if (il >= gvalid) continue;
         Fr k = scalars[i];
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
-        for_each_digit(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
+        for_each_digit_auto(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
             uint32_t pos = lds_inc(lds, bin0 + (b >> sub_bits));
             records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + il) << 1) | neg);

@@ -139,7 +139,8 @@ void ntt_ensure_coset_tables(zk_ctx* ctx, NttTables& t) {
     t.coset_inv_brev_half.alloc(n);
     // both tables carry the 1 / n of the inverse transform in front of them (prove.hip runs those transforms unscaled)
     hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g, t.n_inv, t.coset_fwd_brev.p, t.log_n);
-    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g.inv(), host_inv_pow2(1) * t.n_inv, t.coset_inv_brev_half.p, t.log_n);
+    // ... the second as plain integers (scale / R as a Montgomery-form factor): k_h_combine's product with a Montgomery-form value is canonical
+    hipLaunchKernelGGL(k_powers_brev, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, g.inv(), (host_inv_pow2(1) * t.n_inv).to_canonical(), t.coset_inv_brev_half.p, t.log_n);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(ctx->stream));
 }

@@ -318,6 +318,7 @@ struct ProveState {
         const void *crs = nullptr, *qap = nullptr;
         size_t m_in = 0;
         long window = 0;
+        uint64_t generation = 0;      // devbuf_generation() when the capture ended: any allocation or release since then invalidates the graph
         int seen = 0;                 // proofs of this key so far: the first runs eagerly (allocations), the second is captured
         bool disabled = false;        // capture failed once: eager from then on
         hipGraphExec_t exec = nullptr;
@@ -410,7 +411,7 @@ static int prove_form(zk_ctx* ctx, zk_crs& crs, const zk_qap& q) {
 // coefficients, h is the quotient of U V by t.  vc_can / uc_can: n canonical scalars each; hb_can: h (n - 1) | r v + s u (n).
 // `uv_ready` is called when uc_can and vc_can exist (their inner products can start while the quotient is computed).
 template <class Ready>
-static void arb_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, const Fr* a_mont, size_t a_len, const Fr& r_mont, const Fr& s_mont,
+static void arb_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, const Fr* a_can, size_t a_len, const Fr& r_mont, const Fr& s_mont,
                              Fr* vc_can, Fr* uc_can, Fr* hb_can, Ready&& uv_ready) {
     const size_t n = q.n;
     hipStream_t st = ctx->stream;
@@ -420,8 +421,8 @@ static void arb_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, const F
     S.ue.ensure(n); S.ve.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
     S.arb_vals.ensure(2 * n); S.arb_work.ensure(arb_work_elems(q));
     // W is not needed: U V = h t + E with E = the interpolant of U_k V_k (degree < n), so the quotient of U V alone is h.
-    spmv(ctx, q.u_gate, a_mont, a_len, S.arb_vals.p);
-    spmv(ctx, q.v_gate, a_mont, a_len, S.arb_vals.p + n);
+    spmv(ctx, q.u_gate, a_can, a_len, S.arb_vals.p);         // the witness as given (canonical: k_spmv)
+    spmv(ctx, q.v_gate, a_can, a_len, S.arb_vals.p + n);
     arb_coefficients(ctx, q, S.arb_vals.p, S.arb_work.p, S.ue.p, S.ve.p);
     fr_from_mont(ctx, S.ue.p, uc_can, n);
     fr_from_mont(ctx, S.ve.p, vc_can, n);
@@ -449,7 +450,7 @@ static void arb_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, const F
 }
 
 // SpMV / NTT stage of one proof in the roots-of-unity form: the scalars of the inner products B2 (vc), A (uc) and
-// H + r B1 + s A (hb: h | r v + s u) from the Montgomery-form witness in S.a_mont.  `launch(k, after, scalars, count)`
+// H + r B1 + s A (hb: h | r v + s u) from the witness as the caller gave it (canonical; range-checked by the caller).  `launch(k, after, scalars, count)`
 // is called as soon as the scalars of product k exist (k = MSM stream: 1 L, 0 B2, 2 A, 4 HB).
 // accumulation chain L -> B2 -> A -> H+rB1+sA: L needs only the witness, so the chip is busy
 // ~0.6 ms after the call starts; the long G2 reduction tail hides behind A and the H product
@@ -461,8 +462,8 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     hipStream_t st = ctx->stream;
     Fr *ve = S.uv.p, *ue = S.uv.p + n, *x0 = S.xy.p, *y0 = S.xy.p + n, *vg = S.uvg.p, *ug = S.uvg.p + n;
     launch(1, -1, d_weights + l + 1, n_l);
-    spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
-    spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
+    spmv(ctx, q.u_gate, d_weights, a_len, ue);
+    spmv(ctx, q.v_gate, d_weights, a_len, ve);
     fr_pointwise_mul(ctx, ue, ve, x0, n);                             // U.V on <w>
     // The inverse transforms run WITHOUT their 1 / n (a multiplication per element in the last pass): the factor rides in the
     // kernels that consume their outputs anyway -- the conversions to canonical scalars, r v + s u, the coset table, the h combine.
@@ -525,8 +526,14 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
 
     if (ctx->submit_wait_evt) { ZK_HIP(hipStreamWaitEvent(st, ctx->submit_wait_evt, 0)); ctx->submit_wait_evt = nullptr; }
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
-    S.a_mont.ensure(std::max<size_t>(a_len, 1));
-    fr_to_mont(ctx, d_weights, S.a_mont.p, a_len, S.flag.p);
+    // Sparse forms multiply the witness as the caller gave it (canonical integers; the by-gate coefficients carry the extra R, qap.hip
+    // k_spmv): only its range is checked.  The dense form still converts.
+    if (qap_c.dense) {
+        S.a_mont.ensure(std::max<size_t>(a_len, 1));
+        fr_to_mont(ctx, d_weights, S.a_mont.p, a_len, S.flag.p);
+    } else {
+        fr_check_range(ctx, d_weights, a_len, S.flag.p);
+    }
 
     // the r/s-only fixed-base multiplications run on the side stream beside everything below
     if (ctx->graph_capture) {
@@ -607,8 +614,8 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         }
         Fr *ve = S.uv.p, *ue = S.uv.p + n;
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        spmv(ctx, q.u_gate, S.a_mont.p, a_len, ue);
-        spmv(ctx, q.v_gate, S.a_mont.p, a_len, ve);
+        spmv(ctx, q.u_gate, d_weights, a_len, ue);
+        spmv(ctx, q.v_gate, d_weights, a_len, ve);
         fr_from_mont(ctx, ve, vc_can, n);
         launch(0, 1, crs.t_xi2, vc_can, n, &ms->b2);                     // B = sum V_k [L_k(x)]_2
         fr_from_mont(ctx, ue, uc_can, n);
@@ -663,7 +670,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
         }
         launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
-        arb_scalar_stage(ctx, S, q, S.a_mont.p, a_len, r_mont, s_mont, vc_can, uc_can, hb_can, [&] {
+        arb_scalar_stage(ctx, S, q, d_weights, a_len, r_mont, s_mont, vc_can, uc_can, hb_can, [&] {
             launch(2, 1, crs.t_xi1, uc_can, n, &ms->a);
             launch(0, 2, crs.t_xi2, vc_can, n, &ms->b2);
         });
@@ -768,6 +775,10 @@ static bool prove_graph(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, const
         G.reset();
         G.crs = &crs_c; G.qap = &q; G.m_in = m_in; G.window = ctx->opt_window_bits;
     }
+    // The graph holds raw pointers into slot 0, the MSM workspaces and the CRS tables.  Other entry points (submit, batch, the multi-GPU
+    // paths, a destroyed and re-created CRS / QAP at the same address) may have regrown or freed any of them: replay only if nothing was
+    // allocated or released through DevBuf since the capture ended, otherwise start over (eager proof, then a new capture).
+    if (G.exec && G.generation != devbuf_generation().load()) { const bool was_disabled = G.disabled; G.reset(); G.disabled = was_disabled; }
     if (G.disabled) return false;
     if (G.seen++ == 0) return false;                // first proof of this key: eager (tables, slot buffers)
     Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
@@ -784,7 +795,7 @@ static bool prove_graph(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, const
     const Fr r_mont = Fr::from_canonical(rc), s_mont = Fr::from_canonical(sc);
     const Fr f = q.roots == 0 ? ntt_get_tables(ctx, q.log_n)->n_inv : Fr::one();   // the inverse transforms run without their 1 / n
     S.h_lp->rs_can[0] = rc; S.h_lp->rs_can[1] = sc;
-    S.h_lp->rs_lin[0] = r_mont * f; S.h_lp->rs_lin[1] = s_mont * f;
+    S.h_lp->rs_lin[0] = (r_mont * f).to_canonical(); S.h_lp->rs_lin[1] = (s_mont * f).to_canonical();   // plain integers (k_lincomb_to_canonical_p)
     S.h_lp->blind = ps.draw_blind();
     hipStream_t st = ctx->stream;
     if (mm) ZK_HIP(hipMemcpyAsync(S.d_wit.p, d_weights, mm * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -815,6 +826,7 @@ static bool prove_graph(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, const
         ps.next = 0;
         ctx->cur_slot = -1;
         if (G.disabled) { ZK_HIP(hipStreamSynchronize(st)); return false; }
+        G.generation = devbuf_generation().load();
     }
     ZK_HIP(hipGraphLaunch(G.exec, st));
     ZK_HIP(hipStreamSynchronize(st));
@@ -972,12 +984,11 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         // arbitrary roots (arbroots.hip): every proof interpolates its own U, V (the tree's transforms are per proof); the inner products
         // of the batch run grouped like those of the other forms
         const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
-        S.a_mont.ensure(amax * cnt);
+        (void)amax;
         ZK_HIP(hipMemsetAsync(S.bx_h.p, 0, 2 * n * cnt * sizeof(Fr), st));
         for (size_t j = 0; j < cnt; ++j) {
-            Fr* a_mont = S.a_mont.p + j * amax;
-            fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
-            arb_scalar_stage(ctx, S, q, a_mont, a_len[j], Fr::from_canonical(S.h_b_rs[2 * j]), Fr::from_canonical(S.h_b_rs[2 * j + 1]),
+            fr_check_range(ctx, (const Fr*)d_weights[j], a_len[j], S.flag.p);
+            arb_scalar_stage(ctx, S, q, (const Fr*)d_weights[j], a_len[j], Fr::from_canonical(S.h_b_rs[2 * j]), Fr::from_canonical(S.h_b_rs[2 * j + 1]),
                              S.bx_v.p + j * n, S.bx_u.p + j * n, S.bx_h.p + j * 2 * n, [] {});
         }
         launch(2, 1, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
@@ -986,13 +997,13 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     } else if (form == 1) {
         // integer roots (aproots.hip): evaluation values as scalars of A and B, h on {n+1..2n-1} by one batched convolution
         const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1), M = (size_t)1 << q.ap->log_m;
-        S.uv.ensure(2 * n * cnt); S.xy.ensure(3 * M * cnt); S.a_mont.ensure(amax * cnt);
+        S.uv.ensure(2 * n * cnt); S.xy.ensure(3 * M * cnt);
+        (void)amax;
         Fr *ve = S.uv.p, *ue = S.uv.p + n * cnt;
         for (size_t j = 0; j < cnt; ++j) {
-            Fr* a_mont = S.a_mont.p + j * amax;
-            fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
-            spmv(ctx, q.u_gate, a_mont, a_len[j], ue + j * n);
-            spmv(ctx, q.v_gate, a_mont, a_len[j], ve + j * n);
+            fr_check_range(ctx, (const Fr*)d_weights[j], a_len[j], S.flag.p);
+            spmv(ctx, q.u_gate, (const Fr*)d_weights[j], a_len[j], ue + j * n);
+            spmv(ctx, q.v_gate, (const Fr*)d_weights[j], a_len[j], ve + j * n);
         }
         fr_from_mont(ctx, ve, S.bx_v.p, n * cnt);
         launch(0, 1, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
@@ -1011,13 +1022,12 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     // SpMV, r v + s u, h) is launched per proof: 5 count + 13 launches instead of 17 count
     const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
     S.uv.ensure(2 * n * cnt); S.uvg.ensure(2 * n * cnt); S.xy.ensure(2 * n * cnt);
-    S.a_mont.ensure(amax * cnt);
+    (void)amax;
     Fr *ve = S.uv.p, *ue = S.uv.p + n * cnt, *x0 = S.xy.p, *y0 = S.xy.p + n * cnt, *vg = S.uvg.p, *ug = S.uvg.p + n * cnt;
     for (size_t j = 0; j < cnt; ++j) {
-        Fr* a_mont = S.a_mont.p + j * amax;
-        fr_to_mont(ctx, (const Fr*)d_weights[j], a_mont, a_len[j], S.flag.p);
-        spmv(ctx, q.u_gate, a_mont, a_len[j], ue + j * n);
-        spmv(ctx, q.v_gate, a_mont, a_len[j], ve + j * n);
+        fr_check_range(ctx, (const Fr*)d_weights[j], a_len[j], S.flag.p);
+        spmv(ctx, q.u_gate, (const Fr*)d_weights[j], a_len[j], ue + j * n);
+        spmv(ctx, q.v_gate, (const Fr*)d_weights[j], a_len[j], ve + j * n);
     }
     fr_pointwise_mul(ctx, ue, ve, x0, n * cnt);                             // U.V on <w>
     const Fr n_inv = tabs->n_inv;                                           // the inverse transforms run without their 1 / n (see sparse_scalar_stage)

@@ -14,12 +14,15 @@
 #include <numeric>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
+#include "fr_tile.cuh"
 
 namespace zk {
 
 // ---- sparse upload -------------------------------------------------------------------------
+// `twice`: the values are stored as val R (the Montgomery form of the Montgomery form): k_spmv multiplies them with the CANONICAL
+// witness and gets Montgomery-form sums, so that a proof never converts its witness (one multiplication per wire and a pass over it)
 static void upload_csr(zk_ctx* ctx, DevCsr& d, const std::vector<uint32_t>& ptr, const std::vector<uint32_t>& idx,
-                       const std::vector<uint64_t>& val_words, int* d_flag) {
+                       const std::vector<uint64_t>& val_words, int* d_flag, bool twice = false) {
     d.rows = ptr.size() - 1;
     d.nnz = idx.size();
     d.ptr.alloc(ptr.size());
@@ -30,6 +33,7 @@ static void upload_csr(zk_ctx* ctx, DevCsr& d, const std::vector<uint32_t>& ptr,
         ZK_HIP(hipMemcpyAsync(d.idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(hipMemcpyAsync(d.val.p, val_words.data(), d.nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         fr_to_mont(ctx, d.val.p, d.val.p, d.nnz, d_flag);
+        if (twice) fr_to_mont(ctx, d.val.p, d.val.p, d.nnz, d_flag);
     }
     ZK_HIP(hipStreamSynchronize(ctx->stream));  // host vectors may go out of scope
 }
@@ -61,7 +65,7 @@ static void upload_rows(zk_ctx* ctx, const zk_sparse_rows& rows, size_t m, size_
                 gidx[pos] = (uint32_t)i;
                 std::copy(val.begin() + 4 * k, val.begin() + 4 * k + 4, gval.begin() + 4 * (size_t)pos);
             }
-        upload_csr(ctx, *by_gate, gptr, gidx, gval, d_flag);
+        upload_csr(ctx, *by_gate, gptr, gidx, gval, d_flag, true);
     }
 }
 
@@ -147,18 +151,25 @@ void qap_free(zk_qap* q) {
 }
 
 // ---- kernels -------------------------------------------------------------------------------
-// out[row] = sum_k a[idx[k]] * val[k]   (one lane per row; rows of the chain circuit have 1-2 entries)
+// out[row] = sum_k a[idx[k]] * val[k]   (one lane per row; rows of the chain circuit have 1-2 entries).  `a` = the witness as the caller
+// gave it (CANONICAL integers), val = the coefficients times R (upload_csr, twice): the products are the Montgomery forms, so the proof
+// never converts its witness.  Sums stay in the multiplier's lazy radix (9 limb-wise adds + a carry pass instead of a carry chain with a
+// conditional correction) and leave through one exact reduction.
 __global__ void k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const Fr* __restrict__ val,
                        const Fr* __restrict__ a, size_t a_len, Fr* __restrict__ out, size_t rows) {
     ZK_LATENCY_KERNEL();
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= rows) return;
-    Fr acc = Fr::zero();
+    FrL acc = FrL::load(Fr::zero());
+    uint32_t cnt = 0;
     for (uint32_t k = ptr[j]; k < ptr[j + 1]; ++k) {
         uint32_t i = idx[k];
-        if (i < a_len) acc = acc + a[i] * val[k];   // zip(weights) truncates (mod.rs:233-253)
+        if (i < a_len) {   // zip(weights) truncates (mod.rs:233-253)
+            acc = (acc + FrL::load(a[i]) * FrL::load(val[k])).norm();
+            if ((++cnt & 63u) == 0) acc = fr_reduce(acc);   // |value| stays below 2^7 p whatever the row length
+        }
     }
-    out[j] = acc;
+    out[j] = fr_store_exact(acc);
 }
 void spmv(zk_ctx* ctx, const DevCsr& m, const Fr* a, size_t a_len, Fr* out) {
     if (!m.rows) return;
@@ -181,42 +192,46 @@ void dense_matvec(zk_ctx* ctx, const Fr* M, const Fr* a, size_t rows, size_t n, 
     ZK_HIP(hipGetLastError());
 }
 
-// h[pos] = canonical( x[pos] * 1/2  -  tab[pos] * y[pos] ),  tab = g^-brev(pos) / 2
-__global__ void k_h_combine(const Fr* __restrict__ x, const Fr* __restrict__ y, const Fr* __restrict__ tab, Fr half, Fr* __restrict__ out, size_t n) {
+// The element-wise kernels that END in canonical integers (the scalars of the inner products) take their constant factors as PLAIN
+// integers: mont(x R, k) = x k is already the canonical value, so "multiply, then leave the Montgomery form" is one multiplication
+// instead of two, and a r + b s is one reduction (FpR::mont_sum) instead of three.  The launchers keep their Montgomery-form arguments
+// and convert on the host.  All in the multiplier's own radix (lazy29.cuh); the exact reduction closes them.
+// h[pos] = canonical( x[pos] * 1/2  -  tab[pos] * y[pos] ),  tab = g^-brev(pos) / 2 as plain integers (ntt_ensure_coset_tables)
+__global__ void k_h_combine(const Fr* __restrict__ x, const Fr* __restrict__ y, const Fr* __restrict__ tab, Fr half_c, Fr* __restrict__ out, size_t n) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (x[i] * half - tab[i] * y[i]).to_canonical();
+    if (i < n) out[i] = fr_store_exact(FrL::mont_diff(FrL::load(x[i]), FrL::load(half_c), FrL::load(tab[i]), FrL::load(y[i])));
 }
 void h_combine(zk_ctx* ctx, const Fr* x, const Fr* y, const Fr* tab, Fr half, Fr* out, size_t n) {
     ProfScope ps(ctx, "qap_h_combine", 128.0 * n);
-    hipLaunchKernelGGL(k_h_combine, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, x, y, tab, half, out, n);
+    hipLaunchKernelGGL(k_h_combine, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, x, y, tab, half.to_canonical(), out, n);
     ZK_HIP(hipGetLastError());
 }
 
-// out[i] = canonical(in[i] * k)   (in Montgomery form, k Montgomery)
-__global__ void k_scale_to_canonical(const Fr* __restrict__ in, Fr k, Fr* __restrict__ out, size_t n) {
+// out[i] = canonical(in[i] * k)   (in Montgomery form, kc = k as a plain integer)
+__global__ void k_scale_to_canonical(const Fr* __restrict__ in, Fr kc, Fr* __restrict__ out, size_t n) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (in[i] * k).to_canonical();
+    if (i < n) out[i] = fr_store_exact(FrL::load(in[i]) * FrL::load(kc));
 }
 void fr_scale_to_canonical(zk_ctx* ctx, const Fr* in, Fr k, Fr* out, size_t n) {
     if (!n) return;
     ProfScope ps(ctx, "fr_scale_to_canonical", 64.0 * n);
-    hipLaunchKernelGGL(k_scale_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, k, out, n);
+    hipLaunchKernelGGL(k_scale_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, in, k.to_canonical(), out, n);
     ZK_HIP(hipGetLastError());
 }
 
-// out[i] = canonical(a[i] * ka + b[i] * kb)
-__global__ void k_lincomb_to_canonical(const Fr* __restrict__ a, Fr ka, const Fr* __restrict__ b, Fr kb, Fr* __restrict__ out, size_t n) {
+// out[i] = canonical(a[i] * ka + b[i] * kb), ka / kb as plain integers
+__global__ void k_lincomb_to_canonical(const Fr* __restrict__ a, Fr kac, const Fr* __restrict__ b, Fr kbc, Fr* __restrict__ out, size_t n) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (a[i] * ka + b[i] * kb).to_canonical();
+    if (i < n) out[i] = fr_store_exact(FrL::mont_sum(FrL::load(a[i]), FrL::load(kac), FrL::load(b[i]), FrL::load(kbc)));
 }
-// the same with the two factors in DEVICE memory (k[0], k[1]): a captured graph replays with other factors (prove.hip, lone proofs)
+// the same with the two factors in DEVICE memory (k[0], k[1], plain integers): a captured graph replays with other factors (prove.hip, lone proofs)
 __global__ void k_lincomb_to_canonical_p(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ k, Fr* __restrict__ out, size_t n) {
     ZK_LATENCY_KERNEL();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (a[i] * k[0] + b[i] * k[1]).to_canonical();
+    if (i < n) out[i] = fr_store_exact(FrL::mont_sum(FrL::load(a[i]), FrL::load(k[0]), FrL::load(b[i]), FrL::load(k[1])));
 }
 void fr_lincomb_to_canonical_p(zk_ctx* ctx, const Fr* a, const Fr* b, const Fr* d_k, Fr* out, size_t n) {
     if (!n) return;
@@ -226,7 +241,7 @@ void fr_lincomb_to_canonical_p(zk_ctx* ctx, const Fr* a, const Fr* b, const Fr* 
 void fr_lincomb_to_canonical(zk_ctx* ctx, const Fr* a, Fr ka, const Fr* b, Fr kb, Fr* out, size_t n) {
     if (!n) return;
     ProfScope ps(ctx, "fr_lincomb_to_canonical", 96.0 * n);
-    hipLaunchKernelGGL(k_lincomb_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, a, ka, b, kb, out, n);
+    hipLaunchKernelGGL(k_lincomb_to_canonical, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, a, ka.to_canonical(), b, kb.to_canonical(), out, n);
     ZK_HIP(hipGetLastError());
 }
 
@@ -357,9 +372,13 @@ void qap_weighted_sum(zk_ctx* ctx, const zk_qap& q, const uint64_t* weights, siz
     hipStream_t st = ctx->stream;
     ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
     if (a_len) ZK_HIP(hipMemcpyAsync(a.p, weights, a_len * sizeof(Fr), hipMemcpyHostToDevice, st));
-    fr_to_mont(ctx, a.p, a.p, a_len, flag.p);
-    if (q.dense) dense_matvec(ctx, which == 0 ? q.du.p : which == 1 ? q.dv.p : q.dw.p, a.p, a_len, q.n, res.p);
-    else spmv(ctx, which == 0 ? q.u_gate : q.v_gate, a.p, a_len, res.p);
+    if (q.dense) {
+        fr_to_mont(ctx, a.p, a.p, a_len, flag.p);
+        dense_matvec(ctx, which == 0 ? q.du.p : which == 1 ? q.dv.p : q.dw.p, a.p, a_len, q.n, res.p);
+    } else {
+        fr_check_range(ctx, a.p, a_len, flag.p);
+        spmv(ctx, which == 0 ? q.u_gate : q.v_gate, a.p, a_len, res.p);   // the witness as given (k_spmv)
+    }
     fr_from_mont(ctx, res.p, res.p, q.n);
     int h = 0;
     ZK_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
