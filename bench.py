@@ -537,10 +537,12 @@ def main():
         if depth == 1 and host_ws is None:
             return [(j, ctx.prove_dev(inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"])) for j in idx]
         out, inflight = [], []
+        stamps = state.setdefault("stamps", [])
         for j in idx:
             if len(inflight) == depth:
                 jj, t = inflight.pop(0)
                 out.append((jj, ctx.prove_wait(t)))
+                stamps.append(time.perf_counter())          # completion of one proof while the next ones are in flight
             t_s = time.perf_counter()
             if host_ws is not None:
                 t = ctx.prove_submit_host(inst["crs"], inst["qap"], host_ws[j].ctypes.data, m, sets[j]["r"], sets[j]["s"])
@@ -549,10 +551,21 @@ def main():
             state["submit_s"] += time.perf_counter() - t_s
             state["submits"] += 1
             inflight.append((j, t))
+        stamps.append(None)                                  # what follows is the drain of this call: not steady state
         while inflight:
             jj, t = inflight.pop(0)
             out.append((jj, ctx.prove_wait(t)))
         return out
+
+    def steady_state_ms():
+        """median time between the completions of consecutive proofs of the timed region, pipeline fill (the first `depth` completions) and
+        drain (completions with nothing submitted behind them) excluded; None when too few proofs were timed"""
+        st = state.get("stamps", [])
+        gaps = [b - a for a, b in zip(st[depth:], st[depth + 1:]) if a is not None and b is not None]
+        if len(gaps) < 4:
+            return None
+        gaps.sort()
+        return round(1e3 * gaps[len(gaps) // 2], 4)
 
     # ---- untimed: one-off set-up and the expected bytes --------------------------------------------------------------------
     # Every set's proof by ONE synchronous single-GPU zk_prove_dev: the bytes every leg of the run (pipelined, batched, from host memory,
@@ -561,6 +574,9 @@ def main():
     PRIME = 4
     expected = [ctx.prove_dev(inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"]) for j in range(len(sets))]
     sha = lambda b: __import__("hashlib").sha256(b).hexdigest()[:16]   # noqa: E731
+    # groth16::verify (mod.rs:299-320) of set 0's proof: the pairing check shares no code with the prover or with the closed form the
+    # tests use, and it is the only reader of sum_gamma / [gamma]_2 of this CRS (untimed; 36 ms on the host)
+    verified = bool(ctx.verify(inst["crs"], sets[0]["weights"][1:1 + inst["l"]], expected[0]))
     for j, pr in run(args.warmup + PRIME, "single"):
         assert pr == expected[j], "pipelined proof differs from the synchronous one"
     torch.cuda.synchronize()
@@ -618,6 +634,7 @@ def main():
             state["submit_s"], state["submits"] = 0.0, 0
             ctx.profile_reset()
         leg_barrier(tag + "_b0", collective)
+        state["stamps"] = []
         t0 = time.perf_counter()
         outs = run(args.steps, mode)
         torch.cuda.synchronize()
@@ -663,6 +680,8 @@ def main():
                 res = bounded(lambda: timed_leg(mode, "leg_" + mode, profile=(mode == primary)), max(TMO, 4 * TMO if args.steps > 200 else TMO), "the %s leg" % mode, device)
             else:
                 res = timed_leg(mode, "leg_" + mode, profile=(mode == primary))
+            if mode == primary:
+                state["ss_ms"] = steady_state_ms()
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             if not collective:
                 raise
@@ -762,7 +781,11 @@ def main():
             # additions per launch = pairs x windows, windows averaged over the launches of this kernel in a proof (their point counts
             # differ: L has m - l - 1 points, A n, H + r B1 + s A 2n; the window follows the count; at N > 1 a rank holds 1 / N of each)
             div = world if (world > 1 and not shard) else 1
-            counts = [n] if g2 else [inst["m"] - inst["l"] - 1, n, 2 * n - (0 if args.roots == "unity" else 1)]
+            n_l, n_hb = inst["m"] - inst["l"] - 1, 2 * n - (0 if args.roots == "unity" else 1)
+            # round 5: L and H + r B1 + s A are ONE product over xi_t | xi | sum_delta in a whole proof (option merge_lh; the scalar
+            # exchange and point-range shards keep them apart)
+            merged = ctx.get_option("merge_lh") == 1 and not exchange and not (primary == "shard" and args.shard == "points")
+            counts = [n] if g2 else ([n, n_l + n_hb] if merged else [n_l, n, n_hb])
             wins = [254 // msm_window(max(cnt // div, 1), args.window_bits, g2) + 1 for cnt in counts]
             windows = sum(cnt * w_ for cnt, w_ in zip(counts, wins)) / float(sum(counts))
             gathered = pairs * windows * (4.0 + (128.0 if g2 else 64.0)) + pairs * windows / 32.0 * (304.0 if g2 else 160.0)
@@ -819,6 +842,9 @@ def main():
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            # median time between consecutive proof completions of the timed region, pipeline fill and drain excluded (what
+            # profiles/r5_timeline_pipelined_2p20.txt shows as the period); ms_per_step includes both
+            "steady_state_ms_per_proof": state.get("ss_ms"),
             "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
             "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d; %d distinct (witness, r, s) cycled through the timed region)" % (args.witness, args.seed, len(sets)),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM%s"
@@ -834,7 +860,7 @@ def main():
                                                 "`window_shard` object of the same line",
                        "setup_steps_before_warmup": PRIME + len(sets), "witness_from": args.witness_from, "witness_sets": len(sets),
                        "proofs_in_flight": depth if args.batch <= 1 else "2 batches of %d" % args.batch, "msm_window_bits": args.window_bits or "auto",
-                       "proof_sha": sha(expected[0]), "proof_shas": [sha(e_) for e_ in expected],
+                       "proof_sha": sha(expected[0]), "proof_shas": [sha(e_) for e_ in expected], "verified": verified,
                        "expected_bytes_from": "one synchronous single-GPU zk_prove_dev per set in the untimed set-up; every timed proof is compared with it"},
             "roofline": roofline,
             **({k_: v_ for k_, v_ in (("exchange", legs.get("exchange")), ("window_shard", legs.get("window_shard") or (legs.get("shard") if args.shard == "windows" else None)),

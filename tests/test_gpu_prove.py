@@ -39,9 +39,10 @@ def assert_crs_equal(a, b):
         assert np.array_equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("log_n,faithful", [(1, True), (3, True), (5, True), (8, False)])
+@pytest.mark.parametrize("log_n,faithful", [(1, True), (3, True), (5, True), (8, False), (12, False), (14, False)])
 def test_setup_sparse_matches_oracle(ctx, orc, log_n, faithful):
-    """CRS structure given the trapdoor (cf. single_mult_honest, groth16/mod.rs:398-416)."""
+    """CRS structure given the trapdoor (cf. single_mult_honest, groth16/mod.rs:398-416): all eleven arrays, array for array -- also
+    sum_gamma and [gamma]_2, which no proof ever reads (only verify does), up to 2^14 gates."""
     inst = chain_instance(ctx, log_n, 40 + log_n)
     crs = ctx.setup(inst["qap"], inst["td"])
     got = ctx.crs_download(crs)
@@ -83,6 +84,27 @@ def test_prove_sparse_matches_fast_oracle(ctx, orc, log_n):
     got = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
     assert got == orc.prove_sparse(inst["desc"], cdesc, inst["weights"], inst["r"], inst["s"], False)
     assert got == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
+
+
+@pytest.mark.parametrize("log_n", [12, 14])
+def test_prove_over_oracle_made_crs(ctx, orc, log_n):
+    """A roots-of-unity proof over a CRS the ORACLE made (fast setup on the CPU, uploaded through zk_crs_upload) equals the oracle's fast
+    twin byte for byte: at these sizes every other check either uses a CRS zk_setup made on the GPU or the trapdoor closed form, so this
+    is the one that is independent of zk_setup.  The proof also verifies (pairing check: shares no code with
+    either prover), and the GPU-made CRS gives the same bytes."""
+    inst = chain_instance(ctx, log_n, 90 + log_n)
+    arrs = orc.setup_sparse(inst["desc"], inst["td"], inst["n"], inst["m"], inst["l"], False)
+    crs = ctx.crs_upload(inst["n"], inst["m"], inst["l"], arrs)
+    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], arrs)
+    got = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
+    assert got == orc.prove_sparse(inst["desc"], cdesc, inst["weights"], inst["r"], inst["s"], False)
+    assert ctx.verify(crs, inst["weights"][1:1 + inst["l"]], got)
+    assert got == ctx.prove(ctx.setup(inst["qap"], inst["td"]), inst["qap"], inst["weights"], inst["r"], inst["s"])
+    bad = inst["weights"].copy()
+    bad[9, 0] ^= np.uint64(1)
+    got_bad = ctx.prove(crs, inst["qap"], bad, inst["r"], inst["s"])
+    assert got_bad == orc.prove_sparse(inst["desc"], cdesc, bad, inst["r"], inst["s"], False)
+    assert not ctx.verify(crs, bad[1:1 + inst["l"]], got_bad)
 
 
 @pytest.mark.parametrize("log_n", [12, 16])
@@ -152,11 +174,24 @@ def test_random_sparse_qap_setup_and_prove(ctx, orc, log_n, m, l, faithful):
 
 
 def test_prove_full_size_2_20(ctx, orc):
-    """BASELINE configs 4/5 size: 2^20 constraints, proof bytes == trapdoor closed form."""
+    """BASELINE configs 4/5 size: 2^20 constraints, proof bytes == trapdoor closed form; the proof passes the pairing check of
+    groth16::verify (mod.rs:299-320) -- the one validity oracle that shares no code with the prover or the closed form, and the only
+    reader of sum_gamma / [gamma]_2 of a 2^20 CRS -- and a proof of an unsatisfying witness does not."""
     inst = chain_instance(ctx, 20, 2020)
     crs = ctx.setup(inst["qap"], inst["td"])
     got = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
     assert got == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], inst["weights"], inst["r"], inst["s"])
+    assert ctx.verify(crs, inst["weights"][1:1 + inst["l"]], got)
+    ctx.set_option("merge_lh", 0)              # L and H + r B1 + s A as two inner products (the round-4 form): the same group element
+    try:
+        assert ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"]) == got
+    finally:
+        ctx.set_option("merge_lh", 1)
+    bad = inst["weights"].copy()
+    bad[12345, 1] ^= np.uint64(1)
+    got_bad = ctx.prove(crs, inst["qap"], bad, inst["r"], inst["s"])
+    assert got_bad == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], bad, inst["r"], inst["s"])
+    assert not ctx.verify(crs, bad[1:1 + inst["l"]], got_bad)
 
 
 def test_prove_full_size_2_20_skewed_witnesses(ctx, orc):

@@ -29,7 +29,9 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
     rows.sort()
     acc = [r for r in rows if r[2].startswith("k_msm_accumulate")]
-    per = 4
+    # accumulation launches per proof: one of them is the G2 product (round 5: 3 -- B in G2, A, L + H merged; before: 4)
+    g2n = sum(1 for r in acc if "G2" in r[2])
+    per = max(1, round(len(acc) / g2n)) if g2n else 4
     nproofs = len(acc) // per
     lo = int(nums[0]) if nums else nproofs // 2
     cnt = int(nums[1]) if len(nums) > 1 else 8

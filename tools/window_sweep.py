@@ -93,8 +93,12 @@ def main():
         rng = zk.SplitMix64(99)
         sc = zk.ints_to_limbs([rng.fr() for _ in range(n)]).reshape(n, 4)
         want = None
-        for form, c in [("shipped", 0), ("shipped", 17), ("shipped", 20)] + [("lds_buckets", -c) for c in (6, 7, 8, 9)]:
-            ctx.msm_g1(pts, sc, c)                   # warm-up (allocations)
+        for form, c in [("shipped", 0), ("shipped", 17), ("shipped", 20)] + [("lds_buckets", -c) for c in (6, 7, 8, 9, 10)]:
+            try:
+                ctx.msm_g1(pts, sc, c)               # warm-up (allocations)
+            except zk.ZkError as e:                  # a window whose buckets do not fit LDS
+                print(json.dumps({"part": "lds", "form": form, "window_bits": abs(c), "refused": str(e)[:160]}), flush=True)
+                continue
             ctx.set_option("profile", 2)
             ctx.profile_reset()
             got = ctx.msm_g1(pts, sc, c)

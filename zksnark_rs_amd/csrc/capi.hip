@@ -147,6 +147,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
     if (!std::strcmp(key, "msm_unchain_lanes")) return &ctx->opt_unchain_lanes;
     if (!std::strcmp(key, "chain_order")) return &ctx->opt_chain_order;
+    if (!std::strcmp(key, "merge_lh")) return &ctx->opt_merge_lh;
     if (!std::strcmp(key, "msm_run_entries")) return &ctx->opt_run_entries;
     if (!std::strcmp(key, "msm_run_whole")) return &ctx->opt_run_whole;
 #endif

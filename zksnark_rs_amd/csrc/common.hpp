@@ -115,10 +115,11 @@ struct zk_ctx {
     long opt_ablate = 0;          // bit 0: reuse the previous sorted list of a workspace (repeated inputs only; prices the sort)
     long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take shorter runs (msm_impl.hpp)
     long opt_unchain_lanes = 140000; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation (2^16 gates: lone proof 2.83 -> 2.55 ms, two in flight level)
+    long opt_merge_lh = 1;        // prove: L (witness over sum_delta) and H + r B1 + s A as ONE inner product over the table xi_t | xi | sum_delta (one bucket set, one tail); 0 = two products
     long opt_chain_order = 0;     // order of the accumulation chain of a proof: 0 = L, B2, A, HB; 1 = L, A, B2, HB
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
-    long opt_run_whole = 64;      // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
+    long opt_run_whole = 128;     // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
     long opt_basis_tree_min = 16384; // integer-roots QAP over a powers-only CRS: from this many gates on the Lagrange-basis points come from the transposed interpolation tree (gbasis.hip), below from the n^2 inner products (basis.hip)
     long opt_g2_affine = 0;       // G2 inner products: rounds of pairwise AFFINE sums with shared inversions in front of the XYZZ accumulation (g2_affine.cuh); zk_g2_add_batch takes the same kernel
     long opt_lone_graph = 0;      // zk_prove / zk_prove_dev: a lone proof of a (CRS, QAP, witness length) seen before replays one captured hipGraph (prove.hip prove_graph)

@@ -216,15 +216,18 @@ void crs_ensure_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, bool l
     const G2A* b_xi2 = lagrange ? c.lag2.p : (brev ? c.xi2_br.p : c.xi2.p);
     // xi_t has n-1 points; the bit-reversed copy is padded with infinity to n entries
     msm_build_table<Fq>(ctx, b_xi1, n, pick(n), c.t_xi1);
-    {   // bases of the merged product H + r*B1: xi_t | xi
+    {   // bases of the merged product H + r*B1 + s*A + L: xi_t | xi | sum_delta.  Everything the proof element c takes from the witness
+        // and from h is ONE inner product over this table (prove.hip): one set of buckets, one reduction tail.  An entry point that
+        // needs L on its own (the scalar exchange without per-rank tables, batches) multiplies the points from off_l on.
         const size_t nt = brev ? n : n - 1;
-        DevBuf<G1A> cat(nt + n);
+        DevBuf<G1A> cat(nt + n + nl);
         if (nt) ZK_HIP(hipMemcpyAsync(cat.p, b_xit, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
         ZK_HIP(hipMemcpyAsync(cat.p + nt, b_xi1, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
-        msm_build_table<Fq>(ctx, cat.p, nt + n, pick(nt + n), c.t_hb1);
+        if (nl) ZK_HIP(hipMemcpyAsync(cat.p + nt + n, c.sum_delta1.p, nl * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        msm_build_table<Fq>(ctx, cat.p, nt + n + nl, pick(nt + n + nl), c.t_hb1);
+        c.off_l = nt + n;
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    msm_build_table<Fq>(ctx, c.sum_delta1.p, nl, pick(nl), c.t_sum_delta1);
     msm_build_table<Fq2>(ctx, b_xi2, n, o_g2 > 0 ? (int)o_g2 : (o_all % 10000 > 0 ? pick(n) : msm_auto_window_g2(n)), c.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));
     if (brev) {   // the tables now hold the permuted points

@@ -95,11 +95,19 @@ struct MsmGroups {
     int groups = 1;
     size_t glen = 0, valid = 0, out_stride = 0;
 };
+// Two scalar arrays, one product (groups == 1 only): the scalars of the points [0, split) come from d_scalars, those of the points
+// [split, split + n2) from scalars2 -- n_used is then split + n2.  How prove() multiplies its witness (the caller's array) and its
+// quotient / r v + s u scalars (the slot's) over ONE table sum_delta-behind-xi_t-and-xi with one set of buckets: both sums only ever
+// occur added together in the proof element c (prove.hip).
+struct MsmSplit {
+    const Fr* scalars2 = nullptr;
+    size_t split = ~(size_t)0, n2 = 0;
+};
 // Returns the stream the result lands on (st).
 template <class F>
 hipStream_t msm_run(zk_ctx*, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
              int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait = nullptr, hipEvent_t acc_done = nullptr, size_t point_offset = 0,
-             const MsmGroups& grp = MsmGroups());
+             const MsmGroups& grp = MsmGroups(), const MsmSplit& sp = MsmSplit());
 template <class F>
 void msm_host(zk_ctx*, const uint64_t* points, const uint64_t* scalars, size_t n, int window_bits, uint64_t* out_affine);
 

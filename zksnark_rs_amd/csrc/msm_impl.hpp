@@ -72,7 +72,7 @@ constexpr int SORT2_THREADS = 256;   // level-2 histogram / offsets workgroups (
 constexpr int BINS_THREADS = 512;    // level-2 scatter workgroups
 constexpr int BIN_STAGE = 8192;      // ... and the records they stage in LDS at a time
 constexpr int BIN_PER_LANE = BIN_STAGE / BINS_THREADS;
-constexpr int RUN_MAX = 128;         // longest run of the accumulation (length classes 1..RUN_MAX)
+constexpr int RUN_MAX = 256;         // longest run of the accumulation (length classes 1..RUN_MAX)
 
 // one run of the accumulation: entries [k0, k0 + len) of the bucket-sorted list, all of one bucket; the image of their sum goes to
 // slot `dest` (the bucket's own slot for its first run, a slot behind the buckets' for the others)
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, TailWaves<F>::value) void k_msm_sum_points(con
 
 template <class F>
 hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
-                    int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp) {
+                    int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp, const MsmSplit& sp) {
     const bool g2 = sizeof(F) > sizeof(Fq);
     const int c = tab.c, windows = tab.windows, bpg = 1 << (c - 1);
     const size_t n = tab.n;
@@ -471,6 +471,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t glen = groups > 1 ? grp.glen : std::max<size_t>(n_used, 1), gvalid = groups > 1 ? grp.valid : n_used;
     if (groups > 1) n_used = (size_t)groups * glen;
     ZK_REQUIRE(groups >= 1 && (groups == 1 || gvalid <= glen), ZK_ERR_ARG, "msm: bad grouping");
+    ZK_REQUIRE(!sp.scalars2 || (groups == 1 && sp.split <= n_used && n_used - sp.split == sp.n2), ZK_ERR_ARG, "msm: bad scalar split");
+    const size_t split = sp.scalars2 ? sp.split : ~(size_t)0;
     ZK_REQUIRE(point_offset <= n && gvalid <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
     ZK_REQUIRE(n_used < ((size_t)1 << 32) && (size_t)groups * bpg <= ((size_t)1 << 24), ZK_ERR_SIZE, "msm: too many scalars or buckets");
     const int buckets = bpg * groups;
@@ -502,7 +504,10 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // chip -- 32 additions over Fq2 are 0.6 ms whether 16 or 2^16 scalars are multiplied -- so its runs are shorter, down to 4.
     uint32_t T = (uint32_t)std::max<long>(4, std::min<long>(ctx->opt_run_entries, RUN_MAX) & ~3L);
     const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
-    if (entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill) T = RUN_MAX;
+    // (one run of at most 128 entries up to 64 entries per bucket on average -- the separate products of 2^20 .. 2^21 points --, of at
+    // most RUN_MAX = 256 beyond: the merged L + H product of a proof holds 104 per bucket, and 128 would cut one bucket in a hundred)
+    const bool whole = entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill;
+    if (whole) T = entries / (size_t)buckets <= 64 ? 128 : RUN_MAX;
     else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
     // G2 products whose buckets hold 16 .. run_whole entries each (the proofs' B product at 2^20 gates: 25): the first `aff_rounds`
     // halvings of every bucket are pairwise AFFINE sums with shared inversions (g2_affine.cuh: ~4400 instructions per addition against
@@ -510,7 +515,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // sorted list is padded to a multiple of 2^aff_rounds entries for this (k_msm_bin_offsets).
     int aff_rounds = 0;
     if constexpr (sizeof(F) > sizeof(Fq)) {
-        if (ctx->opt_g2_affine > 0 && T == RUN_MAX && entries / (size_t)buckets >= 16) aff_rounds = (int)std::min<long>(ctx->opt_g2_affine, 4);
+        if (ctx->opt_g2_affine > 0 && whole && entries / (size_t)buckets >= 16) aff_rounds = (int)std::min<long>(ctx->opt_g2_affine, 4);
     }
     const uint32_t aff_pad = (1u << aff_rounds) - 1;
     const size_t entries_padded = entries + (size_t)buckets * aff_pad;         // upper bound of the padded list
@@ -575,7 +580,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     if (!reuse_sort) {
         {
             ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
-            hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, chunk_len, c, windows, rank, world, sub_bits,
+            hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, sp.scalars2, split, n_used, chunk_len, c, windows, rank, world, sub_bits,
                                (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p);
         }
         {
@@ -586,7 +591,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         }
         {
             ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
-            hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, n_used, n, chunk_len, c, windows, rank, world,
+            hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, sp.scalars2, split, n_used, n, chunk_len, c, windows, rank, world,
                                sub_bits, (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p, ws.records.p);
         }
         {
@@ -739,7 +744,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ZK_HIP(hipGetLastError());
     return st;
 }
-template hipStream_t msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&);
+template hipStream_t msm_run<ZK_MSM_FIELD>(zk_ctx*, MsmWorkspace&, hipStream_t, const MsmTable<ZK_MSM_FIELD>&, const Fr*, size_t, int, int, Jac<ZK_MSM_FIELD>*, hipEvent_t, hipEvent_t, size_t, const MsmGroups&, const MsmSplit&);
 
 
 #ifdef ZK_MSM_COMMON

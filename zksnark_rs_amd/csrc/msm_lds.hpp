@@ -13,7 +13,7 @@
 // (Included by msm_impl.hpp inside namespace zk, behind k_msm_sum_points, in the translation unit that holds the shared kernels.)
 #pragma once
 
-constexpr int LDS_MSM_MAX_C = 9;
+constexpr int LDS_MSM_MAX_C = 10;   // 2^9 XYZZ buckets + locks = 76 KB of the 160 KB per compute unit: two waves per unit (c = 9: four)
 
 __global__ __launch_bounds__(64) void k_msm_lds_g1(const Aff<Fq>* __restrict__ table, size_t n, const Fr* __restrict__ scalars, size_t n_used, int c, int windows,
                                                    size_t chunk_len, Jac<Fq>* __restrict__ out) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_msm_lds_g1(const Aff<Fq>* __restrict__ t
 
 // sum_i scalars[i] P_i by the kernel above; table = T[w][i] with c <= 9 bits (msm_build_table); result in d_out (Jacobian)
 inline void msm_lds_run_g1(zk_ctx* ctx, hipStream_t st, const MsmTable<Fq>& tab, const Fr* d_scalars, size_t n_used, DevBuf<Jac<Fq>>& parts, Jac<Fq>* d_out) {
-    ZK_REQUIRE(tab.c >= 2 && tab.c <= LDS_MSM_MAX_C, ZK_ERR_ARG, "msm (LDS buckets): window_bits must be in [2, 9]");
+    ZK_REQUIRE(tab.c >= 2 && tab.c <= LDS_MSM_MAX_C, ZK_ERR_ARG, "msm (LDS buckets): window_bits must be in [2, 10]");
     const int buckets = 1 << (tab.c - 1);
     // one wave per (window, chunk): ~4 waves per compute unit fit (LDS), one round of them fills the chip
     int chunks = std::max(1, std::min<int>((int)((n_used + 63) / 64), std::max(1, 4 * ctx->cu_count / tab.windows)));
@@ -80,6 +80,10 @@ inline void msm_lds_run_g1(zk_ctx* ctx, hipStream_t st, const MsmTable<Fq>& tab,
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
     parts.ensure((size_t)chunks * tab.windows);
     const size_t lds = (size_t)buckets * (sizeof(XyzzR<FpR<FqParams>>) + 4) + 64 * sizeof(Jac<Fq>);
+    if (lds > 65536) {   // c = 10: beyond the default dynamic LDS limit
+        static bool attr = false;
+        if (!attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_lds_g1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+    }
     {
         ProfScope ps(ctx, "msm_lds_buckets_g1", 96.0 * n_used, st);
         hipLaunchKernelGGL(k_msm_lds_g1, dim3(chunks, tab.windows), dim3(64), lds, st, tab.table.p, tab.n, d_scalars, n_used, tab.c, tab.windows, chunk_len, parts.p);

@@ -80,7 +80,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uin
 // hist[chunk][bin] = number of digits of the chunk whose bucket falls into the bin
 // Grouped form (several independent products over the same bases in one pass): scalar i belongs to group i / glen and
 // multiplies point i % glen (scalars at or behind gvalid are ignored); group g owns the bins [g bins_pg, (g+1) bins_pg).
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, size_t n, size_t chunk_len, int c, int windows,
+// Split form (MsmSplit): scalar i comes from scalars2[i - split] for i >= split.
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, const Fr* __restrict__ scalars2, size_t split, size_t n, size_t chunk_len, int c, int windows,
                                                            int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups, uint32_t* __restrict__ hist) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
         if (il >= gvalid) continue;
-        Fr k = scalars[i];
+        Fr k = i < split ? scalars[i] : scalars2[i - split];
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit_auto(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
     }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 // level 1: records[pos] = (sub-bucket << 32) | ((w*n + i) << 1 | neg), grouped by bin: one 8-byte store per digit at the
 // position taken from the bin's LDS counter.  (An LDS-staged form that writes the records in runs, like level 2 below,
 // was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, size_t n, size_t stride, size_t chunk_len, int c, int windows,
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, const Fr* __restrict__ scalars2, size_t split, size_t n, size_t stride, size_t chunk_len, int c, int windows,
                                                                      int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups,
                                                                      const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
     ZK_LATENCY_KERNEL();
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
         const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
         if (il >= gvalid) continue;
-        Fr k = scalars[i];
+        Fr k = i < split ? scalars[i] : scalars2[i - split];
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit_auto(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
@@ -495,11 +496,11 @@ __global__ __launch_bounds__(256) void k_msm_runs_emit(const uint32_t* __restric
 }
 
 #else
-__global__ void k_msm_hist(const Fr*, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, uint32_t*);
+__global__ void k_msm_hist(const Fr*, const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, uint32_t*);
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
+__global__ void k_msm_scatter(const Fr*, const Fr*, size_t, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*, uint32_t, const uint32_t*, uint32_t*);

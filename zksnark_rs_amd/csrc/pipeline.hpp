@@ -70,7 +70,8 @@ struct zk_crs {
     bool has_br = false;
     // fixed-base window tables T[w][i] = 2^(c w) P_i for the four base sets prove() uses
     // (built on first use for the order -- natural or bit-reversed -- the QAP kind needs)
-    zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;   // t_hb1: bases xi_t | xi (H and r*B1 in one product)
+    zk::MsmTable<zk::Fq> t_xi1, t_hb1;   // t_hb1: bases xi_t | xi | sum_delta (H, r*B1, s*A and L in one product); sum_delta starts at point off_l
+    size_t off_l = 0;
     zk::MsmTable<zk::Fq2> t_xi2;
     // per-rank tables of the multi-GPU scalar exchange: only the points [g c, (g+1) c) of every product that rank g of `world`
     // multiplies (1 / world of the table memory and of the time to build them); one (rank, world) at a time

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <random>
+#include <type_traits>
 #include <vector>
 #include "pipeline.hpp"
 #include "qap_kernels.hpp"
@@ -558,20 +559,30 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // instead of thrashing each other; sorting phases and reduction tails overlap freely.
     MsmResults* ms = S.ms.p;
     const size_t n_l = a_len > l + 1 ? std::min(a_len - l - 1, m - l - 1) : 0;
-    auto launch_now = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out, hipStream_t ms_st) {
+    // `off`: first point of the table the scalars multiply (L on its own sits behind xi_t | xi in t_hb1); `sp`: the merged product's
+    // second scalar array (MsmSplit).
+    auto launch_now = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out, hipStream_t ms_st, size_t off, MsmSplit sp) {
         ZK_HIP(hipStreamWaitEvent(ms_st, S.scal_evt[k], 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : (ctx->graph_capture ? nullptr : ps.last_acc);   // nothing outside a capture is waited for
         hipStream_t end_st;
         if (world > 1 && ctx->opt_shard_points) {
             // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
             const size_t lo = count * (size_t)rank / (size_t)world, hi = count * ((size_t)rank + 1) / (size_t)world;
-            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], lo);
+            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], off + lo);
         } else {
-            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k]);
+            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k], off, MsmGroups(), sp);
         }
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
+    // L and H + r B1 + s A only ever occur ADDED in the proof element c (assemble_body), so they are one inner product over the table
+    // xi_t | xi | sum_delta with the scalars h | r v + s u (the slot's array) and the witness (the caller's): one set of 2^(c-1)
+    // buckets instead of two, i.e. one reduction tail (2 additions per bucket), one sort, ~25 launches less per proof (option merge_lh;
+    // round 5: profiles/r5_experiments.txt).  ms->l stays infinity.  Not with partial sums by point ranges (they slice ONE scalar array).
+    const bool merge_lh = ctx->opt_merge_lh && !xout && !(world > 1 && ctx->opt_shard_points);
+    const Fr* l_scalars = nullptr;
+    size_t l_count = 0;
+    bool l_pending = false;
     // The ~30 launches of an inner product are enqueued AFTER the whole SpMV / NTT stage (an event marks the point of the main
     // stream where its scalars exist): a lone proof of a small circuit is bound by the host's enqueue rate, and with the
     // products enqueued in between the stage's own 25 short kernels sat 2 ms apart on the timeline of a 2^16 proof.
@@ -579,10 +590,23 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     std::vector<std::pair<int, std::function<void(int)>>> deferred;
     auto launch = [&](int k, int, auto& table, const Fr* scalars, size_t count, auto* out) {
         if (xout) return;
+        size_t off = 0;
+        MsmSplit sp;
+        if constexpr (std::is_same<std::remove_reference_t<decltype(table)>, MsmTable<Fq>>::value) {
+            if (k == 1) {
+                if (merge_lh) { l_scalars = scalars; l_count = count; l_pending = true; return; }   // joins product 4
+                off = crs.off_l;
+            } else if (k == 4 && l_pending && count == crs.off_l) {
+                sp.scalars2 = l_scalars; sp.split = crs.off_l; sp.n2 = l_count;
+                count += l_count;
+                l_pending = false;
+                ZK_HIP(hipMemsetAsync(&ms->l, 0, sizeof(G1J), st));   // infinity: everything is in hb
+            }
+        }
         hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.scal_evt[k], st));
         auto* tab = &table;
-        deferred.emplace_back(k, [&, k, tab, scalars, count, out, ms_st](int after) { launch_now(k, after, *tab, scalars, count, out, ms_st); });
+        deferred.emplace_back(k, [&, k, tab, scalars, count, out, ms_st, off, sp](int after) { launch_now(k, after, *tab, scalars, count, out, ms_st, off, sp); });
     };
     auto run_deferred = [&] {
         static const int orders[3][4] = {{1, 0, 2, 4}, {1, 2, 0, 4}, {0, 1, 4, 2}};   // MSM slots: 1 = L, 0 = B in G2, 2 = A, 4 = H + r B1 + s A
@@ -613,7 +637,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
         }
         Fr *ve = S.uv.p, *ue = S.uv.p + n;
-        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        launch(1, -1, crs.t_hb1, d_weights + l + 1, n_l, &ms->l);
         spmv(ctx, q.u_gate, d_weights, a_len, ue);
         spmv(ctx, q.v_gate, d_weights, a_len, ve);
         fr_from_mont(ctx, ve, vc_can, n);
@@ -646,7 +670,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         }
         sparse_scalar_stage(ctx, S, q, *tabs, d_weights, a_len, n_l, r_mont, s_mont, vc_can, uc_can, hb_can,
                             [&](int k, int after, const Fr* scalars, size_t count) {
-                                if (k == 1) launch(1, after, crs.t_sum_delta1, scalars, count, &ms->l);    // L: sum a_i * sum_delta_i
+                                if (k == 1) launch(1, after, crs.t_hb1, scalars, count, &ms->l);           // L: sum a_i * sum_delta_i (merged into HB: launch)
                                 else if (k == 0) launch(0, after, crs.t_xi2, scalars, count, &ms->b2);     // B in G2
                                 else if (k == 2) launch(2, after, crs.t_xi1, scalars, count, &ms->a);      // A
                                 else launch(4, after, crs.t_hb1, scalars, count, &ms->hb);                // H + r B1 + s A: last in the chain
@@ -669,7 +693,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
             vc_can = S.vc_can.p; uc_can = S.uc_can.p; hb_can = S.hb_can.p;
         }
-        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        launch(1, -1, crs.t_hb1, d_weights + l + 1, n_l, &ms->l);
         arb_scalar_stage(ctx, S, q, d_weights, a_len, r_mont, s_mont, vc_can, uc_can, hb_can, [&] {
             launch(2, 1, crs.t_xi1, uc_can, n, &ms->a);
             launch(0, 2, crs.t_xi2, vc_can, n, &ms->b2);
@@ -682,7 +706,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         size_t nc = (size_t)1 << lc;
         S.ue.ensure(n); S.ve.ensure(n); S.wc.ensure(n); S.prod_a.ensure(nc); S.prod_b.ensure(nc);
         S.uc_can.ensure(n); S.vc_can.ensure(n); S.hb_can.ensure(2 * n);
-        launch(1, -1, crs.t_sum_delta1, d_weights + l + 1, n_l, &ms->l);
+        launch(1, -1, crs.t_hb1, d_weights + l + 1, n_l, &ms->l);
         dense_matvec(ctx, q.du.p, S.a_mont.p, a_len, n, S.ue.p);
         dense_matvec(ctx, q.dv.p, S.a_mont.p, a_len, n, S.ve.p);
         dense_matvec(ctx, q.dw.p, S.a_mont.p, a_len, n, S.wc.p);
@@ -716,6 +740,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         launch(4, 0, crs.t_hb1, S.hb_can.p, 2 * n - 1, &ms->hb);
     }
 
+    ZK_REQUIRE(!l_pending, ZK_ERR_ARG, "prove: internal -- the witness product was not merged");
     run_deferred();
     // join + assembly + copy-out on the finish stream, so that the main stream is free for the next proof.  A
     // scalars-only ticket completes on its own main stream: the finish stream may hold the join of an earlier ticket's
@@ -873,7 +898,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     ZK_HIP(hipMemsetAsync(d_partials_out, 0, (size_t)sets * ZK_PARTIAL_BYTES, st));
     // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
     // reduction tails (group j = proof j with its own 2^(c-1) buckets); chain L -> B2 -> A -> H as in a whole proof
-    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out) {
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out, size_t base_off = 0) {
         hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
@@ -883,6 +908,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         MsmGroups grp;
         grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
         if (rt) lo = 0;   // the rank's table starts at its first point
+        else lo += base_off;
         hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
@@ -890,7 +916,7 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     };
     if (sets > 0) {
         MsmResults* ms = reinterpret_cast<MsmResults*>(d_partials_out);
-        launch(1, -1, rt ? crs.rank_tabs.t_sum_delta1 : crs.t_sum_delta1, d_l, xd.cl, nl, &ms->l);
+        launch(1, -1, rt ? crs.rank_tabs.t_sum_delta1 : crs.t_hb1, d_l, xd.cl, nl, &ms->l, crs.off_l);   // whole tables: sum_delta sits behind xi_t | xi
         launch(0, 1, rt ? crs.rank_tabs.t_xi2 : crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
         launch(2, 0, rt ? crs.rank_tabs.t_xi1 : crs.t_xi1, d_uc, xd.cn, n, &ms->a);
         launch(4, 2, rt ? crs.rank_tabs.t_hb1 : crs.t_hb1, d_hb, xd.ch, q.roots ? 2 * n - 1 : 2 * n, &ms->hb);   // integer roots: L^S t/delta (n-1) | L (n)
@@ -959,15 +985,15 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
     }
     MsmResults* ms = reinterpret_cast<MsmResults*>(S.b_partials.p);
-    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t glen, size_t valid, auto* out) {
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t glen, size_t valid, auto* out, size_t off = 0) {
         hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         MsmGroups grp;
         grp.groups = count; grp.glen = glen; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        hipStream_t end_st = count == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k])
-                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], 0, grp);
+        hipStream_t end_st = count == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], off)
+                                        : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], off, grp);
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
@@ -979,7 +1005,7 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         n_l[j] = a_len[j] > l + 1 ? std::min(a_len[j] - l - 1, m - l - 1) : 0;
         if (n_l[j]) ZK_HIP(hipMemcpyAsync(S.bx_l.p + (size_t)j * cl, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     }
-    launch(1, -1, crs.t_sum_delta1, S.bx_l.p, cl, nl, &ms->l);
+    launch(1, -1, crs.t_hb1, S.bx_l.p, cl, nl, &ms->l, crs.off_l);   // sum_delta sits behind xi_t | xi in the table
     if (form == 2) {
         // arbitrary roots (arbroots.hip): every proof interpolates its own U, V (the tree's transforms are per proof); the inner products
         // of the batch run grouped like those of the other forms
