@@ -77,7 +77,10 @@ const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last fai
  * path at every size -- 2^16 gates 2.17 against 1.59 ms, profiles/r4_lone_graph.txt -- hence default 0), "g2_affine" (1..4: G2 inner
  * products whose buckets hold 16..64 entries sum the first `value` halvings of every bucket as affine pairs with one inversion per
  * workgroup before the accumulation, and zk_g2_add_batch takes the same kernel; same points; measured SLOWER inside a proof --
- * 102.5 against 94..98 proofs/s, profiles/r4_experiments.txt item 12 -- hence default 0).  Each is exercised by a -m gpu test.
+ * 102.5 against 94..98 proofs/s, profiles/r4_experiments.txt item 12 -- hence default 0), "merge_lh" (default 1: the witness product
+ * L = sum a_i sum_delta_i and H + r B1 + s A, which only occur added together in the proof element c, are ONE inner product over the
+ * table xi_t | xi | sum_delta with one set of buckets and one reduction tail; 0 = two products as in round 4; same proof bytes, +1.3 %
+ * proofs/s at 2^20 gates, profiles/r5_experiments.txt item 2).  Each is exercised by a -m gpu test.
  * A library built with -DZK_MEASURE (make -C zksnark_rs_amd/csrc measure; zk_get_option(ctx, "measure_build") == 1) also accepts the
  * measurement switches of bench.py --opt / --serialize ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole",
  * "msm_small_lanes", "msm_unchain_lanes", "chain_order"); the product build answers ZK_ERR_UNSUPPORTED to them and to unknown keys. */

@@ -206,7 +206,7 @@ def test_msm_matches_reference_sum(ctx, orc, n, c):
     assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
 
 
-@pytest.mark.parametrize("n,c", [(1, 2), (17, 3), (300, 5), (1000, 8), (3000, 9), (70000, 9)])
+@pytest.mark.parametrize("n,c", [(1, 2), (17, 3), (300, 5), (1000, 8), (3000, 9), (70000, 9), (5000, 10)])
 def test_msm_lds_bucket_form(ctx, orc, n, c):
     """The Pippenger form BASELINE.json's north_star words (one wavefront per (window, chunk), buckets in LDS under per-bucket locks,
     wave-level fold; csrc/msm_lds.hpp: zk_msm_g1 with window_bits = -c) gives the same point as the folded double-and-add --
@@ -221,7 +221,7 @@ def test_msm_lds_bucket_form(ctx, orc, n, c):
     assert np.array_equal(ctx.msm_g1(p1, k, -c), orc.msm_g1(p1, k, 0))
     if n == 17:
         with pytest.raises(zk.ZkError):
-            ctx.msm_g1(p1, k, -10)        # the buckets of a wider window do not fit LDS
+            ctx.msm_g1(p1, k, -11)        # the buckets of a wider window do not fit LDS (c = 10: 76 KB, two waves per compute unit)
         with pytest.raises(zk.ZkError):
             ctx.msm_g2(g2_points(orc, rng, n), k, -5)   # G1 only
 

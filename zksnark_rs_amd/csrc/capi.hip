@@ -139,6 +139,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "lone_graph")) return &ctx->opt_lone_graph;
     if (!std::strcmp(key, "g2_affine")) return &ctx->opt_g2_affine;
     if (!std::strcmp(key, "basis_tree_min")) return &ctx->opt_basis_tree_min;
+    if (!std::strcmp(key, "merge_lh")) return &ctx->opt_merge_lh;
 #ifdef ZK_MEASURE
     // measurement switches (tools/ab_*.sh, bench.py --opt / --serialize): not part of the product build
     if (!std::strcmp(key, "serialize")) return &ctx->opt_serialize;
@@ -147,9 +148,9 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_small_lanes")) return &ctx->opt_small_lanes;
     if (!std::strcmp(key, "msm_unchain_lanes")) return &ctx->opt_unchain_lanes;
     if (!std::strcmp(key, "chain_order")) return &ctx->opt_chain_order;
-    if (!std::strcmp(key, "merge_lh")) return &ctx->opt_merge_lh;
     if (!std::strcmp(key, "msm_run_entries")) return &ctx->opt_run_entries;
     if (!std::strcmp(key, "msm_run_whole")) return &ctx->opt_run_whole;
+    if (!std::strcmp(key, "msm_run_fill")) return &ctx->opt_run_fill;
 #endif
     return nullptr;
 }

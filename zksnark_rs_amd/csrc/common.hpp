@@ -119,6 +119,7 @@ struct zk_ctx {
     long opt_chain_order = 0;     // order of the accumulation chain of a proof: 0 = L, B2, A, HB; 1 = L, A, B2, HB
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail
     long opt_run_entries = 32;    // longest run of the bucket accumulation when buckets are cut into several runs (multiple of 4)
+    long opt_run_fill = 1;        // products cut into several runs per bucket: runs as long as one round of accumulation lanes allows (fewer merges)
     long opt_run_whole = 128;     // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
     long opt_basis_tree_min = 16384; // integer-roots QAP over a powers-only CRS: from this many gates on the Lagrange-basis points come from the transposed interpolation tree (gbasis.hip), below from the n^2 inner products (basis.hip)
     long opt_g2_affine = 0;       // G2 inner products: rounds of pairwise AFFINE sums with shared inversions in front of the XYZZ accumulation (g2_affine.cuh); zk_g2_add_batch takes the same kernel

@@ -208,6 +208,67 @@ struct alignas(16) AccSlot {
     typename AccOf<F>::type a;
 };
 
+// G2: ZZ and ZZZ of the accumulator parked in LDS between their uses (option at build time, ZK_G2_PARK).  The Fq2 kernel holds 72
+// accumulator limbs, the prefetched point and a multiplier that needs 63 registers at once: at 256 registers it spills ~47 of them to
+// scratch (160 B per lane, 1.2 GB of scratch writes per launch).  ZZ / ZZZ are read twice and written once per
+// addition and idle in between: 2 x 20 dwords per lane as five 16-byte rows, lane-contiguous (conflict-free ds_read_b128).
+#ifndef ZK_G2_PARK
+#define ZK_G2_PARK 0
+#endif
+template <class F> struct ParkAcc { static constexpr bool on = false; };
+template <> struct ParkAcc<Fq2> { static constexpr bool on = ZK_G2_PARK != 0; };
+struct ParkRows { int4 r[2][5][256]; };   // [ZZ | ZZZ][row][lane]
+__device__ __forceinline__ void park_put(ParkRows* pk, int which, const Fp2R<FqParams>& v) {
+    int4* row = &pk->r[which][0][threadIdx.x];
+    row[0 * 256] = make_int4(v.c0.v[0], v.c0.v[1], v.c0.v[2], v.c0.v[3]);
+    row[1 * 256] = make_int4(v.c0.v[4], v.c0.v[5], v.c0.v[6], v.c0.v[7]);
+    row[2 * 256] = make_int4(v.c0.v[8], v.c1.v[0], v.c1.v[1], v.c1.v[2]);
+    row[3 * 256] = make_int4(v.c1.v[3], v.c1.v[4], v.c1.v[5], v.c1.v[6]);
+    row[4 * 256] = make_int4(v.c1.v[7], v.c1.v[8], 0, 0);
+}
+__device__ __forceinline__ Fp2R<FqParams> park_get(const ParkRows* pk, int which) {
+    asm volatile("" ::: "memory");   // a fresh read every time: the point is NOT to keep the value in registers
+    const int4* row = &pk->r[which][0][threadIdx.x];
+    const int4 a = row[0 * 256], b = row[1 * 256], c = row[2 * 256], d = row[3 * 256], e = row[4 * 256];
+    Fp2R<FqParams> v;
+    v.c0.v[0] = a.x; v.c0.v[1] = a.y; v.c0.v[2] = a.z; v.c0.v[3] = a.w; v.c0.v[4] = b.x; v.c0.v[5] = b.y; v.c0.v[6] = b.z; v.c0.v[7] = b.w;
+    v.c0.v[8] = c.x; v.c1.v[0] = c.y; v.c1.v[1] = c.z; v.c1.v[2] = c.w; v.c1.v[3] = d.x; v.c1.v[4] = d.y; v.c1.v[5] = d.z; v.c1.v[6] = d.w;
+    v.c1.v[7] = e.x; v.c1.v[8] = e.y;
+    return v;
+}
+// madd_xyzz_nz (lazy29.cuh) with ZZ / ZZZ in LDS: same formulas, same bounds, same return codes
+__device__ __forceinline__ int madd_xyzz_nz_parked(Fp2R<FqParams>& X, Fp2R<FqParams>& Y, ParkRows* pk, const Fp2R<FqParams>& qx, const Fp2R<FqParams>& qy) {
+    typedef Fp2R<FqParams> L;
+    L U2 = qx * park_get(pk, 0);
+    L S2 = qy * park_get(pk, 1);
+    L P = U2 - X;
+    L R = S2 - Y;
+    L PP = P.sqr();
+    if (PP.is_zero_mod_p()) return R.sqr().is_zero_mod_p() ? 1 : 2;
+    L PPP = P * PP;
+    L Q = X * PP;
+    L X3 = (R.sqr() - PPP - (Q + Q)).norm();
+    Y = xyzz_ydiff(R, Q - X3, Y, PPP);
+    X = X3;
+    park_put(pk, 0, park_get(pk, 0) * PP);
+    park_put(pk, 1, park_get(pk, 1) * PPP);
+    return 0;
+}
+
+// The next point's gather straight into LDS (global_load_lds_dwordx4: no destination registers), build-time options ZK_ACC_PF_G1 /
+// ZK_ACC_PF_G2.  The shipped loops hold the prefetched point in 16 (G1) / 32 (G2) registers across a whole addition -- a seventh of
+// the G1 kernel's 137, and the reason the G2 kernel spills.  Here lane t's point lands in rows [j][t] of a per-workgroup stage
+// (16 B per row and lane: what the instruction writes for a wave is 64 consecutive 16-byte slots from the address in M0), is read back
+// at the top of the next trip and converted at once.  One loop shape for both fields: the accumulator's emptiness is tested per trip.
+#ifndef ZK_ACC_PF_G1
+#define ZK_ACC_PF_G1 0
+#endif
+#ifndef ZK_ACC_PF_G2
+#define ZK_ACC_PF_G2 1
+#endif
+template <class F> struct AccPrefetchLds { static constexpr bool on = ZK_ACC_PF_G1 != 0; };
+template <> struct AccPrefetchLds<Fq2> { static constexpr bool on = ZK_ACC_PF_G2 != 0; };
+
 // Lane t adds the entries of run t (k_msm_runs_emit) and stores the image of their sum in the run's slot.  info[0] = number of runs.
 template <class F>
 __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
@@ -220,6 +281,8 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     typedef AccShape<F> Shape;
     typename AccOf<F>::type acc;
     acc_clear(acc);
+    __shared__ __attribute__((aligned(16))) uint8_t park_mem[ParkAcc<F>::on ? sizeof(ParkRows) : 16];
+    [[maybe_unused]] ParkRows* const pk = reinterpret_cast<ParkRows*>(park_mem);
     // software pipeline: the next point's gather (a random line of a multi-GiB table) is in flight
     // while the current addition executes
     uint32_t k = run.k0;
@@ -227,7 +290,49 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     uint32_t e_next = k + 1 < k1 ? sorted[k + 1] : 0;
     Aff<F> p = table[e >> 1];
     uint32_t bend = run.end;      // == k1, but loaded: the compiler cannot fold the (dead) block below away (see AccShape)
-    if constexpr (Shape::NZ) {
+    if constexpr (AccPrefetchLds<F>::on) {
+        (void)p; (void)bend;
+        constexpr int ROWS = (int)(sizeof(Aff<F>) / 16);
+        __shared__ int4 stage[ROWS][256];
+        int4* const wave_rows = &stage[0][threadIdx.x & ~63u];
+        auto issue = [&](uint32_t entry) {
+            const int4* src = reinterpret_cast<const int4*>(table + (entry >> 1));
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + j),
+                                                 (void __attribute__((address_space(3)))*)(wave_rows + j * 256), 16, 0, 0);
+        };
+        // the point of entry k (its transfer was issued a trip earlier); then the transfer of entry k + 1 into the same rows
+        auto fetch = [&](uint32_t& ce) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            union { Aff<F> pt; int4 q[ROWS]; } u;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) u.q[j] = stage[j][threadIdx.x];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are read before the next transfer may overwrite them
+            ce = e;
+            const uint32_t kn = k + 1;
+            if (kn < k1) issue(e_next);
+            e = e_next;
+            e_next = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            k = kn;
+            return u.pt;
+        };
+        issue(e);
+        while (k < k1) {
+            uint32_t ce;
+            const Aff<F> pt = fetch(ce);
+            if (pt.is_inf()) continue;                      // padding entries of a table
+            L qx = L::load(pt.x), qy = L::load(pt.y);
+            if (ce & 1) qy = qy.neg();
+            if (acc.inf) {                                  // first finite point of the run, or the one behind a P + (-P)
+                acc.X = qx; acc.Y = qy.norm(); acc.ZZ = acc.ZZZ = L::load(F::one()); acc.inf = false;
+                continue;
+            }
+            const int st = madd_xyzz_nz(acc, qx, qy);
+            if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
+            else if (st == 2) acc_clear(acc);
+        }
+    } else if constexpr (Shape::NZ) {
         auto advance = [&] {
             const uint32_t kn = k + 1;
             const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
@@ -243,6 +348,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             acc.Y = L::load(p.y);
             if (e & 1) acc.Y = acc.Y.neg().norm();
             acc.ZZ = acc.ZZZ = L::load(F::one());
+            if constexpr (ParkAcc<F>::on) { park_put(pk, 0, acc.ZZ); park_put(pk, 1, acc.ZZZ); }
             acc.inf = false;
             advance();
             bool emptied = false;
@@ -257,8 +363,18 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
                 if (!p.is_inf()) {
                     L qx = L::load(p.x), qy = L::load(p.y);
                     if (e & 1) qy = qy.neg();
-                    const int st = madd_xyzz_nz(acc, qx, qy);
-                    if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
+                    int st;
+                    if constexpr (ParkAcc<F>::on) {
+                        st = madd_xyzz_nz_parked(acc.X, acc.Y, pk, qx, qy);
+                        if (st == 1) {   // same point twice in one bucket: doubling through the generic formulas (rare)
+                            acc.ZZ = park_get(pk, 0); acc.ZZZ = park_get(pk, 1);
+                            acc_load(acc, jac_dbl(acc_store(acc)));
+                            park_put(pk, 0, acc.ZZ); park_put(pk, 1, acc.ZZZ);
+                        }
+                    } else {
+                        st = madd_xyzz_nz(acc, qx, qy);
+                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
+                    }
                     emptied = st == 2;
                 }
                 p = p_next;
@@ -269,6 +385,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             }
             if (!emptied) break;
             acc_clear(acc);
+        }
+        if constexpr (ParkAcc<F>::on) {
+            if (!acc.inf) { acc.ZZ = park_get(pk, 0); acc.ZZZ = park_get(pk, 1); }
         }
     } else {
         // one entry: the next point's gather is issued before the addition.  (Written out instead of #pragma unroll: the unroller
@@ -508,6 +627,13 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // most RUN_MAX = 256 beyond: the merged L + H product of a proof holds 104 per bucket, and 128 would cut one bucket in a hundred)
     const bool whole = entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill;
     if (whole) T = entries / (size_t)buckets <= 64 ? 128 : RUN_MAX;
+    else if (ctx->opt_run_fill && entries / T > (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count) {
+        // More runs than the chip holds lanes (3 waves per SIMD in G1, 2 in G2): every run beyond a bucket's first costs a full
+        // XYZZ + XYZZ addition in the merge, so the runs are made as long as one round of lanes allows.  The A product of a 2^20-gate
+        // proof (c = 17: 240 entries per bucket): T = 80 instead of 32, 2 merges per bucket instead of 7 (round 5).
+        const size_t lanes = (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count;
+        T = (uint32_t)std::min<size_t>(RUN_MAX, (entries / lanes + 3) & ~(size_t)3);
+    }
     else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
     // G2 products whose buckets hold 16 .. run_whole entries each (the proofs' B product at 2^20 gates: 25): the first `aff_rounds`
     // halvings of every bucket are pairwise AFFINE sums with shared inversions (g2_affine.cuh: ~4400 instructions per addition against
