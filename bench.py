@@ -194,7 +194,7 @@ def msm_window(count, opt=0, g2=False):
         return o
     if o >= 100:
         return o // 100 if count >= (1 << 21) - 8 else o % 100
-    if count + 8 >= (1 << 21) or (g2 and count + 8 >= (1 << 20)):
+    if count + 8 >= (1 << 20):
         return 20
     lg = max(count, 1).bit_length() - 1
     return 17 if lg >= 17 else 16 if lg >= 16 else 15 if lg >= 14 else 13 if lg >= 11 else 8

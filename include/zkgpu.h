@@ -402,7 +402,7 @@ int zk_comm_all_to_all(zk_comm* comm, const void* d_send, void* d_recv, size_t b
 int zk_comm_all_gather(zk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 /* Latency form -- ONE groth16::prove over all ranks: every rank holds the same witness, recomputes the SpMV / NTT stage,
- * accumulates its share of the four inner products (zk_prove_partial: Pippenger windows w = rank (mod world), or point
+ * accumulates its share of the inner products (three with merge_lh; zk_prove_partial: Pippenger windows w = rank (mod world), or point
  * ranges with the option msm_shard_points), one 768-byte all-gather, and every rank assembles the same 259 bytes. */
 int zk_mgpu_prove_sharded(zk_ctx* ctx, zk_comm* comm, const zk_crs* crs, const zk_qap* qap, const void* d_weights, size_t m,
                           const uint64_t r[4], const uint64_t s[4], uint8_t proof_out[ZK_PROOF_BYTES]);

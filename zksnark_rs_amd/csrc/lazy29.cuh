@@ -463,6 +463,28 @@ ZK_HD int madd_xyzz_nz(XyzzR<L>& p, const L& qx, const L& qy) {
     return 0;
 }
 
+// The SECOND point of a run: the accumulator still is its first point (ZZ = ZZZ = 1), so the sum is an affine + affine addition --
+// U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP: four multiplications of ten less, once per bucket (26 entries per bucket in the A and B
+// products of a 2^20-gate proof).  Called from the PEELED second trip of k_msm_accumulate only: as a branch inside the hot loop the
+// same saving was paid back in register moves at the joins (profiles/r5_experiments.txt item 7).
+// Returns 0 when the sum was formed, 1 when P == Q (the caller doubles), 2 when P == -Q (the sum is infinity; coordinates untouched).
+// qy may be a negated point (limbs <= 0): normalised before R = y2 - Y1 (|limb| < 2^29 is what the squaring and mont_diff need).
+template <class L>
+ZK_HD int madd_xyzz_second(XyzzR<L>& p, const L& qx, const L& qy) {
+    L P = qx - p.X;
+    L R = qy.norm() - p.Y;
+    L PP = P.sqr();
+    if (PP.is_zero_mod_p()) return R.sqr().is_zero_mod_p() ? 1 : 2;
+    L PPP = P * PP;
+    L Q = p.X * PP;
+    L X3 = (R.sqr() - PPP - (Q + Q)).norm();
+    p.Y = xyzz_ydiff(R, Q - X3, p.Y, PPP);
+    p.X = X3;
+    p.ZZ = PP;
+    p.ZZZ = PPP;
+    return 0;
+}
+
 // Jacobian point with the same affine image: (X ZZ^2, Y ZZZ^2, ZZZ)
 template <class L>
 ZK_HD Jac<typename L::Elem> xyzz_store(const XyzzR<L>& p) {

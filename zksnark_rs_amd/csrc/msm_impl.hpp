@@ -29,6 +29,7 @@
 // Multi-GPU partial sums: rank g of a job owns windows w = g (mod world) (the digit
 // loop skips other windows), or a range of the points with every window (point_offset).
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 #include "lazy29.cuh"
 #include "quad29.cuh"
@@ -48,7 +49,10 @@ int msm_auto_window(size_t n) {
     // c = 20 -- 13 windows -- wins for the products of 2^21 points and more (L and H + r B1 + s A at 2^20 gates): +1.3 .. 2.5 % on
     // the pipelined prover against 17 on two boxes; 19 is level, 21 / 22 lose 4 / 6 %, and a wider window for the 2^20-point
     // products (A; B in G2: 18 / 19 / 20 measured -7 / -8 / -3 %) does not pay (tools/ab_g2_window.sh).
-    if (n + 8 >= ((size_t)1 << 21)) return 20;
+    // Round 5: c = 20 from 2^20 points on -- the A product of a 2^20-gate proof.  With L merged into the H product the proof folds one
+    // set of 2^19 buckets less, and 13 instead of 15 windows for A now pay: 100.8 against 99.5 and 102.0 against 101.5 proofs/s on two
+    // boxes (profiles/r5_experiments.txt items 5, 6); c = 19 loses 7 %.
+    if (n + 8 >= ((size_t)1 << 20)) return 20;
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
     if (lg >= 17) return 17;
@@ -266,6 +270,10 @@ __device__ __forceinline__ int madd_xyzz_nz_parked(Fp2R<FqParams>& X, Fp2R<FqPar
 #ifndef ZK_ACC_PF_G2
 #define ZK_ACC_PF_G2 1
 #endif
+// the second point of a run as an affine + affine addition (madd_xyzz_unit, lazy29.cuh); build-time switch for A/B
+#ifndef ZK_ACC_UNIT
+#define ZK_ACC_UNIT 1
+#endif
 template <class F> struct AccPrefetchLds { static constexpr bool on = ZK_ACC_PF_G1 != 0; };
 template <> struct AccPrefetchLds<Fq2> { static constexpr bool on = ZK_ACC_PF_G2 != 0; };
 
@@ -318,16 +326,38 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             return u.pt;
         };
         issue(e);
+        auto start = [&](const L& qx, const L& qy) { acc.X = qx; acc.Y = qy.norm(); acc.ZZ = acc.ZZZ = L::load(F::one()); acc.inf = false; };
+        // Trips 1 and 2 peeled: the run's first point starts the accumulator, the second joins it as an affine + affine addition
+        // (madd_xyzz_second: 6 of 10 multiplications).  A padding entry in front falls through to the loop.  (Its own scope and its
+        // own temporaries: written with shared ones, the hot loop below went back to spilling.)
+        if (ZK_ACC_UNIT != 0) {
+            uint32_t ce;
+            const Aff<F> p1 = fetch(ce);
+            if (!p1.is_inf()) {
+                {
+                    L qx = L::load(p1.x), qy = L::load(p1.y);
+                    if (ce & 1) qy = qy.neg();
+                    start(qx, qy);
+                }
+                if (k < k1) {
+                    const Aff<F> p2 = fetch(ce);
+                    if (!p2.is_inf()) {
+                        L qx = L::load(p2.x), qy = L::load(p2.y);
+                        if (ce & 1) qy = qy.neg();
+                        const int st = madd_xyzz_second(acc, qx, qy);
+                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));
+                        else if (st == 2) acc_clear(acc);
+                    }
+                }
+            }
+        }
         while (k < k1) {
             uint32_t ce;
             const Aff<F> pt = fetch(ce);
             if (pt.is_inf()) continue;                      // padding entries of a table
             L qx = L::load(pt.x), qy = L::load(pt.y);
             if (ce & 1) qy = qy.neg();
-            if (acc.inf) {                                  // first finite point of the run, or the one behind a P + (-P)
-                acc.X = qx; acc.Y = qy.norm(); acc.ZZ = acc.ZZZ = L::load(F::one()); acc.inf = false;
-                continue;
-            }
+            if (acc.inf) { start(qx, qy); continue; }       // first finite point of the run, or the one behind a P + (-P)
             const int st = madd_xyzz_nz(acc, qx, qy);
             if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
             else if (st == 2) acc_clear(acc);
@@ -392,7 +422,10 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     } else {
         // one entry: the next point's gather is issued before the addition.  (Written out instead of #pragma unroll: the unroller
         // declines loops that contain the inline-asm multipliers of mont_asm.inc.)
-        auto step = [&] {
+        // `second`: the peeled second trip of the run -- when the first one started the accumulator from a finite point (`fresh`), the
+        // sum is an affine + affine addition (madd_xyzz_second)
+        bool fresh = false;
+        auto step = [&](auto second) {
             if constexpr (Shape::DEAD) {
                 if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
             }
@@ -402,7 +435,16 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             if (!p.is_inf()) {
                 L qx = L::load(p.x), qy = L::load(p.y);
                 if (e & 1) qy = qy.neg();
-                if (!acc_madd(acc, qx, qy)) {
+                bool done = false;
+                if constexpr (decltype(second)::value) {
+                    if (fresh && !acc.inf) {
+                        const int st = madd_xyzz_second(acc, qx, qy);
+                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));
+                        else if (st == 2) acc.inf = true;   // P + (-P): the sum is infinity (the coordinates stay, as madd_xyzz leaves them)
+                        done = true;
+                    }
+                }
+                if (!done && !acc_madd(acc, qx, qy)) {
                     // same point twice in one bucket: doubling through the generic formulas (rare)
                     acc_load(acc, jac_dbl(acc_store(acc)));
                 }
@@ -412,10 +454,15 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             e_next = e_next2;
             k = kn;
         };
+        if (ZK_ACC_UNIT != 0 && k < k1) {
+            step(std::false_type{});
+            fresh = !acc.inf;
+            if (k < k1) step(std::true_type{});
+        }
         while (k < k1) {
-            step();
-            if constexpr (Shape::UNROLL >= 2) { if (k >= k1) break; step(); }
-            if constexpr (Shape::UNROLL >= 3) { if (k >= k1) break; step(); }
+            step(std::false_type{});
+            if constexpr (Shape::UNROLL >= 2) { if (k >= k1) break; step(std::false_type{}); }
+            if constexpr (Shape::UNROLL >= 3) { if (k >= k1) break; step(std::false_type{}); }
         }
     }
     img[run.dest].a = acc;

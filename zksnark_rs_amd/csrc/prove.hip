@@ -970,7 +970,11 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     ctx->cur_slot = ticket;
     S.partial = false;
     const size_t n = q.n, m = q.m, l = q.input, nl = m > l + 1 ? m - l - 1 : 0, cl = std::max<size_t>(nl, 1);
-    S.bx_l.ensure(cl * count); S.bx_v.ensure(n * count); S.bx_u.ensure(n * count); S.bx_h.ensure(2 * n * count);
+    // merge_lh (see prove_submit): the witness scalars of proof j sit behind its h | r v + s u scalars in ONE array per proof -- stride
+    // hs = off_l + cl, witness at off_l -- and L joins the H product (group j = proof j); ms->l stays infinity (the blobs are cleared)
+    const bool merge_lh = ctx->opt_merge_lh != 0;
+    const size_t off_l = crs.off_l, hs = merge_lh ? off_l + cl : 2 * n;
+    S.bx_l.ensure(merge_lh ? 1 : cl * count); S.bx_v.ensure(n * count); S.bx_u.ensure(n * count); S.bx_h.ensure(hs * count);
     S.b_rs.ensure(2 * ZK_MAX_BATCH); S.b_pre.ensure(ZK_MAX_BATCH);
     S.b_partials.ensure((size_t)ZK_MAX_BATCH * ZK_PARTIAL_BYTES); S.b_proofs.ensure((size_t)ZK_MAX_BATCH * ZK_PROOF_BYTES);
     ZK_HIP(hipMemsetAsync(S.flag.p, 0, sizeof(int), st));
@@ -998,28 +1002,31 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         ps.last_acc = S.acc_evt[k];
     };
     // L needs only the witnesses (zip truncation, mod.rs:233-253: zero scalars behind a short witness)
-    ZK_HIP(hipMemsetAsync(S.bx_l.p, 0, cl * count * sizeof(Fr), st));
+    if (merge_lh) ZK_HIP(hipMemsetAsync(S.bx_h.p, 0, hs * count * sizeof(Fr), st));
+    else ZK_HIP(hipMemsetAsync(S.bx_l.p, 0, cl * count * sizeof(Fr), st));
     std::vector<size_t> a_len(count), n_l(count);
     for (int j = 0; j < count; ++j) {
         a_len[j] = std::min(m_in[j], m);
         n_l[j] = a_len[j] > l + 1 ? std::min(a_len[j] - l - 1, m - l - 1) : 0;
-        if (n_l[j]) ZK_HIP(hipMemcpyAsync(S.bx_l.p + (size_t)j * cl, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        Fr* dst = merge_lh ? S.bx_h.p + (size_t)j * hs + off_l : S.bx_l.p + (size_t)j * cl;
+        if (n_l[j]) ZK_HIP(hipMemcpyAsync(dst, (const Fr*)d_weights[j] + l + 1, n_l[j] * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     }
-    launch(1, -1, crs.t_hb1, S.bx_l.p, cl, nl, &ms->l, crs.off_l);   // sum_delta sits behind xi_t | xi in the table
+    if (!merge_lh) launch(1, -1, crs.t_hb1, S.bx_l.p, cl, nl, &ms->l, crs.off_l);   // sum_delta sits behind xi_t | xi in the table
+    const size_t hb_extra = merge_lh ? nl : 0;   // valid scalars of a group beyond the h | r v + s u part
     if (form == 2) {
         // arbitrary roots (arbroots.hip): every proof interpolates its own U, V (the tree's transforms are per proof); the inner products
         // of the batch run grouped like those of the other forms
         const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1);
         (void)amax;
-        ZK_HIP(hipMemsetAsync(S.bx_h.p, 0, 2 * n * cnt * sizeof(Fr), st));
+        if (!merge_lh) ZK_HIP(hipMemsetAsync(S.bx_h.p, 0, 2 * n * cnt * sizeof(Fr), st));
         for (size_t j = 0; j < cnt; ++j) {
             fr_check_range(ctx, (const Fr*)d_weights[j], a_len[j], S.flag.p);
             arb_scalar_stage(ctx, S, q, (const Fr*)d_weights[j], a_len[j], Fr::from_canonical(S.h_b_rs[2 * j]), Fr::from_canonical(S.h_b_rs[2 * j + 1]),
-                             S.bx_v.p + j * n, S.bx_u.p + j * n, S.bx_h.p + j * 2 * n, [] {});
+                             S.bx_v.p + j * n, S.bx_u.p + j * n, S.bx_h.p + j * hs, [] {});
         }
         launch(2, 1, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
         launch(0, 2, crs.t_xi2, S.bx_v.p, n, n, &ms->b2);
-        launch(4, 0, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n - 1, &ms->hb);      // bases: xi_t (n-1) | xi (n); group stride 2n
+        launch(4, 0, crs.t_hb1, S.bx_h.p, hs, 2 * n - 1 + hb_extra, &ms->hb);      // bases: xi_t (n-1) | xi (n) [| sum_delta]; group stride hs
     } else if (form == 1) {
         // integer roots (aproots.hip): evaluation values as scalars of A and B, h on {n+1..2n-1} by one batched convolution
         const size_t cnt = (size_t)count, amax = std::max<size_t>(*std::max_element(a_len.begin(), a_len.end()), 1), M = (size_t)1 << q.ap->log_m;
@@ -1037,9 +1044,9 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
         launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
         for (size_t j = 0; j < cnt; ++j)       // bases: L^S t/delta (n-1) | L (n); group stride 2n, 2n-1 valid
             fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]), ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]),
-                                    S.bx_h.p + j * 2 * n + (n - 1), n);
-        ap_quotient_values(ctx, q, ue, ve, S.xy.p, S.bx_h.p, cnt, 2 * n);
-        launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n - 1, &ms->hb);
+                                    S.bx_h.p + j * hs + (n - 1), n);
+        ap_quotient_values(ctx, q, ue, ve, S.xy.p, S.bx_h.p, cnt, hs);
+        launch(4, 2, crs.t_hb1, S.bx_h.p, hs, 2 * n - 1 + hb_extra, &ms->hb);
     } else {
     auto tabs = ntt_get_tables(ctx, q.log_n);
     ntt_ensure_coset_tables(ctx, *tabs);
@@ -1064,15 +1071,15 @@ int prove_batch_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int co
     launch(2, 0, crs.t_xi1, S.bx_u.p, n, n, &ms->a);
     for (size_t j = 0; j < cnt; ++j)
         fr_lincomb_to_canonical(ctx, ve + j * n, Fr::from_canonical(S.h_b_rs[2 * j]) * n_inv, ue + j * n, Fr::from_canonical(S.h_b_rs[2 * j + 1]) * n_inv,
-                                S.bx_h.p + j * 2 * n + n, n);
+                                S.bx_h.p + j * hs + n, n);
     ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * cnt * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2 * cnt);   // V, U on g<w>
     fr_pointwise_mul(ctx, ug, vg, y0, n * cnt);                             // U.V on g<w>
     ntt_dif(ctx, S.xy.p, q.log_n, true, false, 2 * cnt);                    // n (lo + hi) | n (lo - hi)_i * g^i
     const Fr half = host_fr_from_u64(2).inv() * n_inv;
     for (size_t j = 0; j < cnt; ++j)
-        h_combine(ctx, x0 + j * n, y0 + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * 2 * n, n);
-    launch(4, 2, crs.t_hb1, S.bx_h.p, 2 * n, 2 * n, &ms->hb);
+        h_combine(ctx, x0 + j * n, y0 + j * n, tabs->coset_inv_brev_half.p, half, S.bx_h.p + j * hs, n);
+    launch(4, 2, crs.t_hb1, S.bx_h.p, hs, 2 * n + hb_extra, &ms->hb);
     }
 
     hipStream_t fin = ctx->finish;
