@@ -146,9 +146,18 @@ def cpu_baseline(zk, ctx, seed, main_inst, full=False):
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
 # counter passes of THIS round's build (tools/profile_round.sh); a missing file makes the fields null, nothing is typed in here
-PMC_FILES = {20: "r4_pmc_traffic.json", 16: "r4_pmc_traffic_2p16.json"}   # passes exist for the metric's size and for config 3 (2^16)
-PMC_ACC_FILES = {20: "r4_pmc_acc.json", 16: "r4_pmc_acc_2p16.json"}
-UBENCH_FILE = "r2_ubench_valu.txt"   # tools/ubench_valu.hip: sustained issue rates per instruction class, waves per SIMD and chains
+def _round_file(name, rounds=(5, 4, 3, 2)):
+    """the newest committed profiles/rN_<name> (this round's, else the one before it: the line names the file it read)"""
+    for r in rounds:
+        f = "r%d_%s" % (r, name)
+        if os.path.exists(os.path.join(ROOT, "profiles", f)):
+            return f
+    return "r%d_%s" % (rounds[0], name)
+
+
+PMC_FILES = {20: _round_file("pmc_traffic.json"), 16: _round_file("pmc_traffic_2p16.json")}   # passes exist for the metric's size and for config 3 (2^16)
+PMC_ACC_FILES = {20: _round_file("pmc_acc.json"), 16: _round_file("pmc_acc_2p16.json")}
+UBENCH_FILE = _round_file("ubench_valu.txt")   # tools/ubench_valu.hip: sustained issue rates per instruction class, waves per SIMD and chains
 
 # VALU issue ceiling of gfx950 for the two instruction classes of the multiplier:
 #   64-bit / integer-multiply class (v_mad_u64_u32, v_mad_i64_i32, v_mul_lo_u32, v_lshl_add_u64, v_ashrrev_i64, carry adds): 4 cycles

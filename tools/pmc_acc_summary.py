@@ -47,7 +47,8 @@ def main():
     d, log_n = sys.argv[1], int(sys.argv[2])
     from bench import msm_window
     n = 1 << log_n
-    counts = {"k_msm_accumulate": [2 * n - 1, n, 2 * n], "k_msm_accumulate<G2>": [n]}
+    # round 5: L (2n - 1 points) and H + r B1 + s A (2n) are ONE product over xi_t | xi | sum_delta (option merge_lh)
+    counts = {"k_msm_accumulate": [n, 4 * n - 1], "k_msm_accumulate<G2>": [n]}
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
     dur = collections.defaultdict(list)
