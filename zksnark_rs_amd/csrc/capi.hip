@@ -151,6 +151,7 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_run_entries")) return &ctx->opt_run_entries;
     if (!std::strcmp(key, "msm_run_whole")) return &ctx->opt_run_whole;
     if (!std::strcmp(key, "msm_run_fill")) return &ctx->opt_run_fill;
+    if (!std::strcmp(key, "alt_stream")) return &ctx->opt_alt_stream;
 #endif
     return nullptr;
 }

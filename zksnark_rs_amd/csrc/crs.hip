@@ -269,14 +269,21 @@ void crs_ensure_rank_tables(zk_ctx* ctx, zk_crs& c, bool brev, unsigned log_n, b
     };
     build1(b_xi1, n, cn, R.t_xi1);
     {
+        // the rank's points of xi_t | xi ([g ch, (g + 1) ch), padded with infinity to ch entries) followed by its points of sum_delta
+        // ([g cl, (g + 1) cl)): ONE table for the merged product L + H of the exchange (prove_msm_submit); sum_delta starts at point ch
         const size_t nt = brev ? n : n - 1;
-        DevBuf<G1A> cat(nt + n);
+        DevBuf<G1A> cat(nt + n), mine(ch + cl);
         if (nt) ZK_HIP(hipMemcpyAsync(cat.p, b_xit, nt * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
         ZK_HIP(hipMemcpyAsync(cat.p + nt, b_xi1, n * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
-        build1(cat.p, nt + n, ch, R.t_hb1);
+        ZK_HIP(hipMemsetAsync(mine.p, 0, (ch + cl) * sizeof(G1A), ctx->stream));   // all-zero = the point at infinity
+        size_t lo_h, lo_l;
+        const size_t cnt_h = range(ch, nt + n, &lo_h), cnt_l = range(cl, nl, &lo_l);
+        if (cnt_h) ZK_HIP(hipMemcpyAsync(mine.p, cat.p + lo_h, cnt_h * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        if (cnt_l) ZK_HIP(hipMemcpyAsync(mine.p + ch, c.sum_delta1.p + lo_l, cnt_l * sizeof(G1A), hipMemcpyDeviceToDevice, ctx->stream));
+        msm_build_table<Fq>(ctx, mine.p, ch + cl, pick(ch + cl), R.t_hb1);
+        R.off_l = ch;
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    build1(c.sum_delta1.p, nl, cl, R.t_sum_delta1);
     cnt = range(cn, n, &lo);
     msm_build_table<Fq2>(ctx, b_xi2 + lo, cnt, o_g2 > 0 ? (int)o_g2 : (o_all % 10000 > 0 ? pick(cnt) : msm_auto_window_g2(cnt)), R.t_xi2);
     ZK_HIP(hipStreamSynchronize(ctx->stream));

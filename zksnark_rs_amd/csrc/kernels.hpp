@@ -99,9 +99,14 @@ struct MsmGroups {
 // [split, split + n2) from scalars2 -- n_used is then split + n2.  How prove() multiplies its witness (the caller's array) and its
 // quotient / r v + s u scalars (the slot's) over ONE table sum_delta-behind-xi_t-and-xi with one set of buckets: both sums only ever
 // occur added together in the proof element c (prove.hip).
+// Grouped form (the proofs of a scalar-exchange round): group j reads its first `split` scalars from d_scalars + j stride1 and the
+// rest from scalars2 + j stride2; glen = split + (length of the second part), and the two parts have their own counts of valid scalars
+// (valid1 <= split, n2 <= glen - split: what the rank's point ranges hold of each).
 struct MsmSplit {
     const Fr* scalars2 = nullptr;
     size_t split = ~(size_t)0, n2 = 0;
+    size_t valid1 = ~(size_t)0;        // valid scalars of the first part (default: all `split` of them)
+    size_t stride1 = 0, stride2 = 0;   // grouped form only
 };
 // Returns the stream the result lands on (st).
 template <class F>

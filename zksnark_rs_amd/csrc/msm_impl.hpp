@@ -637,8 +637,16 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t glen = groups > 1 ? grp.glen : std::max<size_t>(n_used, 1), gvalid = groups > 1 ? grp.valid : n_used;
     if (groups > 1) n_used = (size_t)groups * glen;
     ZK_REQUIRE(groups >= 1 && (groups == 1 || gvalid <= glen), ZK_ERR_ARG, "msm: bad grouping");
-    ZK_REQUIRE(!sp.scalars2 || (groups == 1 && sp.split <= n_used && n_used - sp.split == sp.n2), ZK_ERR_ARG, "msm: bad scalar split");
-    const size_t split = sp.scalars2 ? sp.split : ~(size_t)0;
+    // two scalar arrays (MsmSplit): a group's valid scalars are [0, valid1) of the first part and [split, split + n2) of the second
+    ZK_REQUIRE(!sp.scalars2 || (sp.split <= gvalid && gvalid - sp.split == sp.n2 && (groups == 1 || (sp.stride1 >= sp.split && sp.stride2 >= sp.n2))),
+               ZK_ERR_ARG, "msm: bad scalar split");
+    ScalarSrc src;
+    src.scalars = d_scalars; src.scalars2 = sp.scalars2;
+    src.split = sp.scalars2 ? sp.split : ~(size_t)0;
+    src.stride1 = sp.scalars2 && groups > 1 ? sp.stride1 : glen;
+    src.stride2 = sp.scalars2 && groups > 1 ? sp.stride2 : 0;
+    src.glen = (uint32_t)glen; src.gvalid = (uint32_t)gvalid;
+    src.valid1 = sp.scalars2 ? (uint32_t)std::min(sp.valid1, sp.split) : (uint32_t)gvalid;
     ZK_REQUIRE(point_offset <= n && gvalid <= n - point_offset, ZK_ERR_ARG, "msm: more scalars than table points");
     ZK_REQUIRE(n_used < ((size_t)1 << 32) && (size_t)groups * bpg <= ((size_t)1 << 24), ZK_ERR_SIZE, "msm: too many scalars or buckets");
     const int buckets = bpg * groups;
@@ -753,8 +761,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     if (!reuse_sort) {
         {
             ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
-            hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, sp.scalars2, split, n_used, chunk_len, c, windows, rank, world, sub_bits,
-                               (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p);
+            hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, src, n_used, chunk_len, c, windows, rank, world, sub_bits,
+                               groups, ws.hist.p);
         }
         {
             ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
@@ -764,8 +772,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         }
         {
             ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
-            hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, d_scalars, sp.scalars2, split, n_used, n, chunk_len, c, windows, rank, world,
-                               sub_bits, (uint32_t)glen, (uint32_t)gvalid, groups, ws.hist.p, ws.records.p);
+            hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, src, n_used, n, chunk_len, c, windows, rank, world,
+                               sub_bits, groups, ws.hist.p, ws.records.p);
         }
         {
             ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);

@@ -5,6 +5,25 @@
 // independent scalar multiplications; the sort is what turns them into bucket sums.
 #pragma once
 
+// Where scalar i of a (possibly grouped, possibly two-array) product lives, and whether it is one: group grp = i / glen, position il in
+// the group; il < split: scalars[grp stride1 + il] (valid below valid1), otherwise scalars2[grp stride2 + il - split] (valid below gvalid
+// counted from the group's start).  Without a second array split is the largest size_t and stride1 = glen: scalars[i].
+struct ScalarSrc {
+    const Fr* scalars; const Fr* scalars2;
+    size_t split, stride1, stride2;
+    uint32_t glen, gvalid, valid1;
+    __device__ __forceinline__ bool get(size_t i, uint32_t& grp, uint32_t& il, Fr& k) const {
+        grp = (uint32_t)i / glen; il = (uint32_t)i - grp * glen;
+        if (il >= gvalid) return false;
+        if (il < split) {
+            if (il >= valid1) return false;
+            k = scalars[(size_t)grp * stride1 + il];
+        } else {
+            k = scalars2[(size_t)grp * stride2 + (il - split)];
+        }
+        return true;
+    }
+};
 #ifdef ZK_MSM_COMMON
 // ---- two-level counting sort of the digits by bucket -------------------------------------------
 // A bucket id (|digit| - 1, c - 1 bits) splits into a bin (high bits, at most 2^10 bins) and a sub-bucket.
@@ -81,8 +100,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uin
 // Grouped form (several independent products over the same bases in one pass): scalar i belongs to group i / glen and
 // multiplies point i % glen (scalars at or behind gvalid are ignored); group g owns the bins [g bins_pg, (g+1) bins_pg).
 // Split form (MsmSplit): scalar i comes from scalars2[i - split] for i >= split.
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict__ scalars, const Fr* __restrict__ scalars2, size_t split, size_t n, size_t chunk_len, int c, int windows,
-                                                           int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(ScalarSrc src, size_t n, size_t chunk_len, int c, int windows,
+                                                           int first, int step, int sub_bits, int groups, uint32_t* __restrict__ hist) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
@@ -94,9 +113,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(const Fr* __restrict_
     // workgroup -- do not fit into the 208 registers that one retired accumulation wave leaves)
 #pragma unroll 1
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
-        if (il >= gvalid) continue;
-        Fr k = i < split ? scalars[i] : scalars2[i - split];
+        uint32_t grp, il;
+        Fr k;
+        if (!src.get(i, grp, il, k)) continue;
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit_auto(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
     }
@@ -158,8 +177,8 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 // level 1: records[pos] = (sub-bucket << 32) | ((w*n + i) << 1 | neg), grouped by bin: one 8-byte store per digit at the
 // position taken from the bin's LDS counter.  (An LDS-staged form that writes the records in runs, like level 2 below,
 // was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
-__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restrict__ scalars, const Fr* __restrict__ scalars2, size_t split, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                                     int first, int step, int sub_bits, uint32_t glen, uint32_t gvalid, int groups,
+__global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(ScalarSrc src, size_t n, size_t stride, size_t chunk_len, int c, int windows,
+                                                                     int first, int step, int sub_bits, int groups,
                                                                      const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -170,9 +189,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(const Fr* __restri
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk_len, hi = min(lo + chunk_len, n);
     for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
-        const uint32_t grp = (uint32_t)i / glen, il = (uint32_t)i - grp * glen;
-        if (il >= gvalid) continue;
-        Fr k = i < split ? scalars[i] : scalars2[i - split];
+        uint32_t grp, il;
+        Fr k;
+        if (!src.get(i, grp, il, k)) continue;
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit_auto(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
@@ -496,11 +515,11 @@ __global__ __launch_bounds__(256) void k_msm_runs_emit(const uint32_t* __restric
 }
 
 #else
-__global__ void k_msm_hist(const Fr*, const Fr*, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, uint32_t*);
+__global__ void k_msm_hist(ScalarSrc, size_t, size_t, int, int, int, int, int, int, uint32_t*);
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(const Fr*, const Fr*, size_t, size_t, size_t, size_t, int, int, int, int, int, uint32_t, uint32_t, int, const uint32_t*, uint64_t*);
+__global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*, uint32_t, const uint32_t*, uint32_t*);

@@ -78,7 +78,8 @@ struct zk_crs {
     struct RankTables {
         int rank = -1, world = 0, kind = -1;
         long c_opt = -1;
-        zk::MsmTable<zk::Fq> t_xi1, t_hb1, t_sum_delta1;
+        zk::MsmTable<zk::Fq> t_xi1, t_hb1;   // t_hb1: the rank's points of xi_t | xi (padded to ch) | its points of sum_delta (from point off_l = ch on)
+        size_t off_l = 0;
         zk::MsmTable<zk::Fq2> t_xi2;
     } rank_tabs;
     int tables_kind = -1;    // -1 none, 0 natural order, 1 bit-reversed, 2 Lagrange-basis points (integer roots)

@@ -603,7 +603,12 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
                 ZK_HIP(hipMemsetAsync(&ms->l, 0, sizeof(G1J), st));   // infinity: everything is in hb
             }
         }
-        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);   // serialize: measurement mode, no overlap at all
+        // Measurement switch alt_stream (default 0): the merged product of odd tickets on the (now idle) L stream.  On ONE stream its
+        // sort queues behind the previous proof's reduction tail and every other proof's last accumulation starts ~0.9 ms late
+        // (profiles/r5_timeline_pipelined_2p20.txt) -- but with the sort moved forward the accumulation it then overlaps runs 1.2 ms
+        // longer: 103.9 (one stream) against 102.4 proofs/s.  The chip is bound by the work, not by that gap (r5_experiments.txt item 8).
+        const int sk = (k == 4 && sp.scalars2 && (ticket & 1) && ctx->opt_alt_stream) ? 1 : k;
+        hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, sk);   // serialize: measurement mode, no overlap at all
         ZK_HIP(hipEventRecord(S.scal_evt[k], st));
         auto* tab = &table;
         deferred.emplace_back(k, [&, k, tab, scalars, count, out, ms_st, off, sp](int after) { launch_now(k, after, *tab, scalars, count, out, ms_st, off, sp); });
@@ -898,7 +903,10 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
     ZK_HIP(hipMemsetAsync(d_partials_out, 0, (size_t)sets * ZK_PARTIAL_BYTES, st));
     // one grouped product per base set: the `sets` proofs of the round share the sort, the accumulation launch and the
     // reduction tails (group j = proof j with its own 2^(c-1) buckets); chain L -> B2 -> A -> H as in a whole proof
-    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out, size_t base_off = 0) {
+    // base_off / rt_off: first point of the product in the whole table / in the rank's table.  scalars2 (chunk2, count2): the second
+    // scalar array of the merged product L + H (MsmSplit, grouped): its points follow the first part's `chunk` points in the rank's table.
+    auto launch = [&](int k, int after, auto& table, const Fr* scalars, size_t chunk, size_t count, auto* out, size_t base_off = 0, size_t rt_off = 0,
+                      const Fr* scalars2 = nullptr, size_t chunk2 = 0, size_t count2 = 0) {
         hipStream_t ms_st = ctx->opt_serialize ? st : msm_stream_for(ctx, k);
         ZK_HIP(hipEventRecord(S.fork_evt, st));
         ZK_HIP(hipStreamWaitEvent(ms_st, S.fork_evt, 0));
@@ -906,20 +914,32 @@ int prove_msm_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, int sets
         size_t lo;
         const size_t valid = range(chunk, count, &lo);
         MsmGroups grp;
-        grp.groups = sets; grp.glen = chunk; grp.valid = valid; grp.out_stride = ZK_PARTIAL_BYTES;
-        if (rt) lo = 0;   // the rank's table starts at its first point
-        else lo += base_off;
-        hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, valid, 0, 1, out, wait_evt, S.acc_evt[k], lo)
-                                       : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp);
+        MsmSplit sp;
+        size_t glen = chunk, total = valid;
+        if (scalars2) {
+            size_t lo2;
+            const size_t valid2 = range(chunk2, count2, &lo2);
+            sp.scalars2 = scalars2; sp.split = chunk; sp.n2 = valid2; sp.valid1 = valid; sp.stride1 = chunk; sp.stride2 = chunk2;
+            glen = chunk + chunk2; total = chunk + valid2;
+        }
+        grp.groups = sets; grp.glen = glen; grp.valid = total; grp.out_stride = ZK_PARTIAL_BYTES;
+        lo = rt ? rt_off : lo + base_off;   // the rank's table starts at its first point
+        hipStream_t end_st = sets == 1 ? msm_run(ctx, S.ws[k], ms_st, table, scalars, total, 0, 1, out, wait_evt, S.acc_evt[k], lo, MsmGroups(), sp)
+                                       : msm_run(ctx, S.ws[k], ms_st, table, scalars, 0, 0, 1, out, wait_evt, S.acc_evt[k], lo, grp, sp);
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
     };
     if (sets > 0) {
         MsmResults* ms = reinterpret_cast<MsmResults*>(d_partials_out);
-        launch(1, -1, rt ? crs.rank_tabs.t_sum_delta1 : crs.t_hb1, d_l, xd.cl, nl, &ms->l, crs.off_l);   // whole tables: sum_delta sits behind xi_t | xi
-        launch(0, 1, rt ? crs.rank_tabs.t_xi2 : crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
-        launch(2, 0, rt ? crs.rank_tabs.t_xi1 : crs.t_xi1, d_uc, xd.cn, n, &ms->a);
-        launch(4, 2, rt ? crs.rank_tabs.t_hb1 : crs.t_hb1, d_hb, xd.ch, q.roots ? 2 * n - 1 : 2 * n, &ms->hb);   // integer roots: L^S t/delta (n-1) | L (n)
+        const size_t n_hb = q.roots ? 2 * n - 1 : 2 * n;   // integer roots: L^S t/delta (n-1) | L (n)
+        // With per-rank tables L joins the H product as in a whole proof (merge_lh, prove_submit): the rank's table holds its points of
+        // xi_t | xi and of sum_delta back to back, the scalars come from the two exchanged arrays; ms->l stays infinity (cleared above).
+        const bool merge_lh = ctx->opt_merge_lh && rt;
+        if (!merge_lh) launch(1, -1, rt ? crs.rank_tabs.t_hb1 : crs.t_hb1, d_l, xd.cl, nl, &ms->l, crs.off_l, crs.rank_tabs.off_l);   // sum_delta sits behind xi_t | xi
+        launch(2, merge_lh ? -1 : 1, rt ? crs.rank_tabs.t_xi1 : crs.t_xi1, d_uc, xd.cn, n, &ms->a);
+        launch(0, 2, rt ? crs.rank_tabs.t_xi2 : crs.t_xi2, d_vc, xd.cn, n, &ms->b2);
+        if (merge_lh) launch(4, 0, crs.rank_tabs.t_hb1, d_hb, xd.ch, n_hb, &ms->hb, 0, 0, d_l, xd.cl, nl);
+        else launch(4, 0, rt ? crs.rank_tabs.t_hb1 : crs.t_hb1, d_hb, xd.ch, n_hb, &ms->hb);
     }
     hipStream_t fin = ctx->finish;
     ZK_HIP(hipEventRecord(S.fork_evt, st));
