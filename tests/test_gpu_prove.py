@@ -356,6 +356,38 @@ def test_prove_batch(ctx, orc, log_n):
     assert ctx.prove(crs, inst["qap"], wits[0], rs[0], ss[0]) == want[0]
 
 
+@pytest.mark.parametrize("log_n", [2, 8, 13])
+def test_merge_lh_option_gives_the_same_bytes(ctx, orc, log_n):
+    """Option merge_lh: L (witness over sum_delta) and H + r B1 + s A as ONE inner product over the table xi_t | xi | sum_delta
+    (default) or as two (round 4's form).  Same group element, so the same 259 bytes -- single proofs (also truncated, empty-L and
+    all-zero witnesses), batches, and against the oracle."""
+    torch = pytest.importorskip("torch")
+    inst = chain_instance(ctx, log_n, 1200 + log_n)
+    crs = ctx.setup(inst["qap"], inst["td"])
+    cdesc = ctx.crs_desc(inst["n"], inst["m"], inst["l"], ctx.crs_download(crs))
+    rng = SplitMix64(77 + log_n)
+    wits = [inst["weights"], inst["weights"][:inst["m"] - 3], inst["weights"][:inst["l"] + 1], np.zeros_like(inst["weights"])]
+    rs = [rng.fr() for _ in wits]
+    ss = [rng.fr() for _ in wits]
+    dws = [torch.from_numpy(np.ascontiguousarray(w).view(np.int64)).cuda() for w in wits]
+    torch.cuda.synchronize()
+    got = {}
+    try:
+        for merge in (1, 0, 1):
+            ctx.set_option("merge_lh", merge)
+            assert ctx.get_option("merge_lh") == merge
+            single = [ctx.prove(crs, inst["qap"], w, r, s) for w, r, s in zip(wits, rs, ss)]
+            t = ctx.prove_batch_submit(crs, inst["qap"], [d.data_ptr() for d in dws], [w.shape[0] for w in wits], rs, ss)
+            assert ctx.prove_batch_wait(t, len(wits)) == single, merge
+            got.setdefault(merge, single)
+            assert got[merge] == single
+    finally:
+        ctx.set_option("merge_lh", 1)
+    assert got[0] == got[1]
+    for w, r, s, pr in zip(wits, rs, ss, got[1]):
+        assert pr == orc.prove_sparse(inst["desc"], cdesc, w, r, s, log_n <= 6)
+
+
 def test_scalar_exchange_full_size_2_20(ctx, orc):
     """BASELINE size: one round of the 8-rank scalar exchange played on one device (rank g = chunk g of every array,
     two proofs per round so that the grouped inner products run) == the closed-form trapdoor proof == zk_prove."""
