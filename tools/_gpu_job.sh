@@ -1,6 +1,4 @@
 set -u
 cd $GRAFT_REPO_ROOT
-bash tools/soak.sh > /dev/null 2>&1
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-python bench.py --steps 100 --warmup 5 > gpurun_out/bench_final_100.json 2>> gpurun_out/bench_final.err
-cat gpurun_out/soak.txt; tail -c 400 gpurun_out/bench_final.json
+bash tools/ab.sh r5l_ab 3 60 -- "measure" "measure --opt msm_fold=2" "measure --opt msm_fold=8" "measure --opt msm_fold=16" "measure --opt msm_quad_buckets=0" "measure --opt msm_unchain_lanes=10000000"
+cat gpurun_out/r5l_ab/ab.txt
