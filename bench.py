@@ -566,6 +566,11 @@ def main():
             out.append((jj, ctx.prove_wait(t)))
         return out
 
+    def completion_intervals_ms():
+        """times between consecutive completions of the timed region (diagnostic: ZK_BENCH_DUMP_INTERVALS=1 prints them on stderr)"""
+        st = [x for x in state.get("stamps", []) if x is not None]
+        return [round(1e3 * (b - a), 3) for a, b in zip(st, st[1:])]
+
     def steady_state_ms():
         """median time between the completions of consecutive proofs of the timed region, pipeline fill (the first `depth` completions) and
         drain (completions with nothing submitted behind them) excluded; None when too few proofs were timed"""
@@ -691,6 +696,8 @@ def main():
                 res = timed_leg(mode, "leg_" + mode, profile=(mode == primary))
             if mode == primary:
                 state["ss_ms"] = steady_state_ms()
+                if os.environ.get("ZK_BENCH_DUMP_INTERVALS"):
+                    print("intervals_ms", completion_intervals_ms(), file=sys.stderr, flush=True)
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             if not collective:
                 raise

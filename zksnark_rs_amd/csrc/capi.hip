@@ -152,6 +152,8 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_run_whole")) return &ctx->opt_run_whole;
     if (!std::strcmp(key, "msm_run_fill")) return &ctx->opt_run_fill;
     if (!std::strcmp(key, "alt_stream")) return &ctx->opt_alt_stream;
+    if (!std::strcmp(key, "ntt_fuse")) return &ctx->opt_ntt_fuse;
+    if (!std::strcmp(key, "tail_stream")) return &ctx->opt_tail_stream;
 #endif
     return nullptr;
 }

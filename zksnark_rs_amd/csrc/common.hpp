@@ -116,6 +116,8 @@ struct zk_ctx {
     long opt_small_lanes = 65536; // inner products with fewer accumulation lanes than this take shorter runs (msm_impl.hpp)
     long opt_unchain_lanes = 140000; // inner products with fewer accumulation lanes than this are not chained behind the previous accumulation (2^16 gates: lone proof 2.83 -> 2.55 ms, two in flight level)
     long opt_alt_stream = 0;      // merged L + H product: odd tickets run it on the idle L stream (measurement switch; measured -1.4 %, profiles/r5_experiments.txt item 8)
+    long opt_tail_stream = 0;     // merged L + H product: its reduction tail on the idle L stream (measurement switch)
+    long opt_ntt_fuse = 1;        // roots-of-unity form, two-pass sizes: element-wise kernels folded into the DIF tile loads / stores (ntt_dif_fused); measurement switch
     long opt_merge_lh = 1;        // prove: L (witness over sum_delta) and H + r B1 + s A as ONE inner product over the table xi_t | xi | sum_delta (one bucket set, one tail); 0 = two products
     long opt_chain_order = 1;     // order of the accumulation chain of a proof: 0 = (L,) B2, A, HB; 1 = (L,) A, B2, HB; 2 = B2, (L,) HB, A.  Round 5, L merged into HB: 1 = 102.2 against 101.2 (0) and 100.8 (2) proofs/s, profiles/r5_experiments.txt item 5
     long opt_fold = 4;            // images summed per lane and pass in the row / column sums of the MSM tail

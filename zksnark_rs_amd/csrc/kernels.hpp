@@ -44,6 +44,16 @@ void ntt_dif(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv
 // to the input (in its bit-reversed order) as it is loaded.
 void ntt_dit(zk_ctx*, Fr* d_data, unsigned log_n, bool inverse, bool scale_n_inv, const Fr* d_pre, size_t batch = 1);
 void ntt_dif_pre(zk_ctx*, Fr* d_data, unsigned log_n, const Fr* table, size_t step, size_t batch);   // element i times table[i * step] on the first load
+// the prove pipeline's unscaled DIF transforms with the element-wise kernels around them folded in (ntt.hip ntt_dif_fused)
+struct NttFuse {
+    const Fr* src_a[2] = {nullptr, nullptr};   // first-pass sources per half of the batch (null: the output array itself)
+    const Fr* src_b[2] = {nullptr, nullptr};   // ... multiplied element-wise by these
+    size_t half = 0;                           // transforms [0, half) use set 0, the rest set 1
+    Fr* canon_out[2] = {nullptr, nullptr};     // last pass: canonical(value * canon_k) per half
+    Fr canon_k;                                // Montgomery form
+};
+bool ntt_dif_fusable(unsigned log_n);
+void ntt_dif_fused(zk_ctx*, Fr* d_out, unsigned log_n, bool inverse, size_t batch, const NttFuse&);
 void bitrev_permute(zk_ctx*, const Fr* d_in, Fr* d_out, unsigned log_n);
 // out[i] = a[i] * b[i]
 void fr_pointwise_mul(zk_ctx*, const Fr* a, const Fr* b, Fr* out, size_t n);
@@ -94,6 +104,7 @@ void msm_build_table(zk_ctx*, const Aff<F>* d_points, size_t n, int c, MsmTable<
 struct MsmGroups {
     int groups = 1;
     size_t glen = 0, valid = 0, out_stride = 0;
+    hipStream_t tail_stream = nullptr;   // when set (and acc_done given): the reduction tail runs there, behind the accumulation's event
 };
 // Two scalar arrays, one product (groups == 1 only): the scalars of the points [0, split) come from d_scalars, those of the points
 // [split, split + n2) from scalars2 -- n_used is then split + n2.  How prove() multiplies its witness (the caller's array) and its

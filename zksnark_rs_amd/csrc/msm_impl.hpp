@@ -857,6 +857,10 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         }
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     }
+    if (grp.tail_stream && acc_done) {   // the next product of this stream (the next proof's sort) does not queue behind this tail
+        ZK_HIP(hipStreamWaitEvent(grp.tail_stream, acc_done, 0));
+        st = grp.tail_stream;
+    }
     {
         ProfScope ps(ctx, g2 ? "msm_reduce_g2" : "msm_reduce_g1", (double)sizeof(AccSlot<F>) * (max_extra + 5.0 * buckets), st);
         ZK_HIP(hipMemsetAsync(ws.heavy.p, 0, 2 * sizeof(uint32_t), st));

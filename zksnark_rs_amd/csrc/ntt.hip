@@ -190,6 +190,18 @@ struct NttPass {
     int contig;      // a tile = 2^log_cols WHOLE transforms of 2^log_rows contiguous elements each (batches of small transforms): element idx of the tile at base + idx
     size_t pre_step; // > 0: `pre` is ONE table for every transform of the batch -- element i of a transform is multiplied by pre[(i & pre_mask) * pre_step]
     size_t pre_mask; //      (interp.hip: the twist w_4s^i in front of the second half of a parent's image)
+    // Fused element-wise work of the prove pipeline (ntt_dif_fused; all null / 0 otherwise).  Transform t of the batch belongs to half
+    // sel = t >= fuse_half and is number tl = t - sel fuse_half of it:
+    //   load   element from src_a[sel][tl n + ...] instead of the data array, times src_b[sel][tl n + ...] when that is set
+    //          (U.V on <w> and on the coset: the point-wise products never exist as arrays);
+    //   store  (to the data array as always -- with src_a set the pass reads one array and writes another -- and) ALSO
+    //          canonical(value * canon_k) to canon_out[sel][tl n + ...] (the scalars of the A and B products leave the last pass of
+    //          the inverse transform directly; canon_k is a plain integer, see qap.hip).
+    const Fr* src_a[2];
+    const Fr* src_b[2];
+    Fr* canon_out[2];
+    Fr canon_k;
+    unsigned fuse_half;
 };
 
 __device__ __forceinline__ FrL lds_get(const int32_t* lds, int e) {
@@ -278,6 +290,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
     Fr* base = data + (size_t)(blockIdx.x >> p.log_tiles) * p.n + (size_t)tile * p.tile_stride;
     const Fr* pre = p.pre ? (p.pre_step ? p.pre : p.pre + (size_t)tile * p.tile_stride) : nullptr;
     const Fr* mid = p.mid ? p.mid + (size_t)tile * p.tile_stride : nullptr;
+    // fused sources / sinks (ntt_dif_fused): uniform over the workgroup
+    const unsigned tnum = blockIdx.x >> p.log_tiles, sel = tnum >= p.fuse_half ? 1u : 0u, tl = tnum - sel * p.fuse_half;
+    const size_t toff = (size_t)tl * p.n + (size_t)tile * p.tile_stride;
+    const Fr* lsrc = p.src_a[sel] ? p.src_a[sel] + toff : base;
+    const Fr* lmul = p.src_b[sel] ? p.src_b[sel] + toff : nullptr;
+    Fr* scan = p.canon_out[sel] ? p.canon_out[sel] + toff : nullptr;
 
     // load: consecutive lanes walk the `cols` contiguous elements of a row, then the next row
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
@@ -285,7 +303,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
         size_t g = (size_t)row * p.row_stride + col;
         int at = (col << log_rows) + row;
         if (p.contig) { g = idx; at = idx; }
-        FrL v = FrL::load(base[g]);
+        FrL v = FrL::load(lsrc[g]);
+        if (lmul) v = v * FrL::load(lmul[g]);
         if (pre) v = v * FrL::load(pre[p.pre_step ? (((size_t)tile * p.tile_stride + g) & p.pre_mask) * p.pre_step : g]);
         lds_put(lds, at, v);
     }
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
         __syncthreads();
     }
 
-    const FrL post = FrL::load(p.post);
+    const FrL post = FrL::load(p.post), canon_k = FrL::load(p.canon_k);
     for (int idx = threadIdx.x; idx < elems; idx += NTT_THREADS) {
         int row = idx >> log_cols, col = idx & (cols - 1);
         size_t g = (size_t)row * p.row_stride + col;
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_tile(Fr* __restrict__ data,
         if (mid) v = v * FrL::load(mid[g]);
         if (p.has_post) v = v * post;
         base[g] = fr_store_exact(v);
+        if (scan) scan[g] = fr_store_exact(v * canon_k);
     }
 }
 
@@ -408,6 +428,46 @@ static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse,
 }
 
 void ntt_dif(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, size_t batch) { ntt_core(ctx, false, d, log_n, inverse, scale, nullptr, batch); }
+
+// The unscaled DIF transforms of the prove pipeline with their neighbouring element-wise kernels folded into the tile loads / stores
+// (two-pass sizes, 2^12 .. 2^22 points; `batch` transforms whose first `half` belong to source / sink set 0, the rest to set 1):
+//   * first pass: element = src_a[set][..] (x src_b[set][..] when given) instead of out[..] -- U.V on <w> and on the coset are formed in
+//     the load, and the pass writes `out` while its sources stay intact (the SpMV outputs are needed twice);
+//   * last pass: besides out[..] (Montgomery form, what the next transform reads) canonical(value x canon_k) goes to canon_out[set][..]
+//     -- the scalars of the A and B inner products (k_scale_to_canonical's work).
+// Saves two k_pointwise_mul, two k_scale_to_canonical and one 64 MB copy per proof (profiles/r5_experiments.txt item 10).
+bool ntt_dif_fusable(unsigned log_n) { return log_n <= 2 * NTT_MAX_LOCAL_LOG; }
+void ntt_dif_fused(zk_ctx* ctx, Fr* out, unsigned log_n, bool inverse, size_t batch, const NttFuse& f) {
+    ZK_REQUIRE(ntt_dif_fusable(log_n) && batch >= 1 && f.half <= batch, ZK_ERR_SIZE, "ntt_dif_fused: at most two passes (2^22 points)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
+        attr_set = true;
+    }
+    auto tabs = ntt_get_tables(ctx, log_n);
+    const size_t n = (size_t)1 << log_n, r2 = (size_t)1 << NTT_MAX_LOCAL_LOG;
+    const int32_t* tw = inverse ? tabs->tw29_inv.p : tabs->tw29_fwd.p;
+    if (log_n <= NTT_MAX_LOCAL_LOG) {   // one pass: a tile is one whole transform; load and store fusions meet in the same launch
+        NttPass p{log_n, 0, 0, n, 1, n, tw, nullptr, nullptr, tabs->n_inv, 0, 0};
+        p.fuse_half = (unsigned)f.half;
+        for (int k = 0; k < 2; ++k) { p.src_a[k] = f.src_a[k]; p.src_b[k] = f.src_b[k]; p.canon_out[k] = f.canon_out[k]; }
+        p.canon_k = f.canon_k.to_canonical();
+        launch_pass(ctx, false, out, p, batch, "ntt_tile", 64.0 * n * batch);
+        return;
+    }
+    const unsigned a = log_n - NTT_MAX_LOCAL_LOG, log_c = NTT_MAX_LOCAL_LOG > a ? NTT_MAX_LOCAL_LOG - a : 0;
+    NttPass col{a, log_c, NTT_MAX_LOCAL_LOG - log_c, n, r2, (size_t)1 << log_c, tw, inverse ? tabs->mid_inv.p : tabs->mid_fwd.p, nullptr, tabs->n_inv, 0, 0};
+    NttPass row{NTT_MAX_LOCAL_LOG, 0, a, n, 1, r2, tw, nullptr, nullptr, tabs->n_inv, 0, 0};
+    col.fuse_half = row.fuse_half = (unsigned)f.half;
+    for (int k = 0; k < 2; ++k) {
+        col.src_a[k] = f.src_a[k]; col.src_b[k] = f.src_b[k];
+        row.canon_out[k] = f.canon_out[k];
+    }
+    row.canon_k = f.canon_k.to_canonical();
+    const double pass_bytes = 64.0 * n * batch;
+    launch_pass(ctx, false, out, col, (r2 >> log_c) * batch, "ntt_tile", pass_bytes);
+    launch_pass(ctx, false, out, row, ((size_t)1 << a) * batch, "ntt_tile", pass_bytes);
+}
 void ntt_dit(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch) { ntt_core(ctx, true, d, log_n, inverse, scale, d_pre, batch); }
 // forward DIF of `batch` transforms whose element i is first multiplied by table[i * step] (one table for the whole batch, fused into
 // the first tile load); log_n <= 22

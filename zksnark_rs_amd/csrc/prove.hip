@@ -465,10 +465,28 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     launch(1, -1, d_weights + l + 1, n_l);
     spmv(ctx, q.u_gate, d_weights, a_len, ue);
     spmv(ctx, q.v_gate, d_weights, a_len, ve);
-    fr_pointwise_mul(ctx, ue, ve, x0, n);                             // U.V on <w>
     // The inverse transforms run WITHOUT their 1 / n (a multiplication per element in the last pass): the factor rides in the
     // kernels that consume their outputs anyway -- the conversions to canonical scalars, r v + s u, the coset table, the h combine.
     const Fr n_inv = tabs->n_inv;
+    if (ctx->opt_ntt_fuse && ntt_dif_fusable(q.log_n)) {
+        // Two-pass sizes: the element-wise kernels around the three DIF transforms ride in their tile loads / stores (ntt_dif_fused):
+        // the first transform reads the SpMV outputs and writes uvg (the evaluations in uv stay for U.V on <w>), its last pass also
+        // emits the canonical scalars of A and B; U.V on <w> and on g<w> are formed in the load of the last transform.  No
+        // k_pointwise_mul, no k_scale_to_canonical, no copy uv -> uvg.
+        NttFuse f1;
+        f1.src_a[0] = ve; f1.src_a[1] = ue; f1.half = 1;
+        f1.canon_out[0] = vc_can; f1.canon_out[1] = uc_can; f1.canon_k = n_inv;
+        ntt_dif_fused(ctx, S.uvg.p, q.log_n, true, 2, f1);             // uvg = n V | n U coefficients (bit-reversed order)
+        launch(0, 1, vc_can, n);
+        launch(2, 0, uc_can, n);
+        if (ctx->graph_capture) fr_lincomb_to_canonical_p(ctx, vg, ug, S.d_lp.p->rs_lin, hb_can + n, n);
+        else fr_lincomb_to_canonical(ctx, vg, r_mont * n_inv, ug, s_mont * n_inv, hb_can + n, n);
+        ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w> (the table holds g^i / n)
+        NttFuse f3;
+        f3.src_a[0] = ue; f3.src_b[0] = ve; f3.src_a[1] = ug; f3.src_b[1] = vg; f3.half = 1;
+        ntt_dif_fused(ctx, S.xy.p, q.log_n, true, 2, f3);              // n (lo + hi) | n (lo - hi)_i * g^i
+    } else {
+    fr_pointwise_mul(ctx, ue, ve, x0, n);                             // U.V on <w>
     ntt_dif(ctx, S.uv.p, q.log_n, true, false, 2);                    // n V, n U coefficients (bit-reversed order), one launch per pass
     fr_scale_to_canonical(ctx, ve, n_inv, vc_can, n);
     launch(0, 1, vc_can, n);
@@ -481,6 +499,7 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w> (the table holds g^i / n)
     fr_pointwise_mul(ctx, ug, vg, y0, n);                             // U.V on g<w>
     ntt_dif(ctx, S.xy.p, q.log_n, true, false, 2);                    // n (lo + hi) | n (lo - hi)_i * g^i
+    }
     Fr half = host_fr_from_u64(2).inv() * n_inv;
     h_combine(ctx, x0, y0, tabs->coset_inv_brev_half.p, half, hb_can, n);        // the table holds g^-i / (2 n)
     // bases: xi_t (n entries, entry brev(n-1) = n-1 is infinity) | xi (n entries)
@@ -570,7 +589,11 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             const size_t lo = count * (size_t)rank / (size_t)world, hi = count * ((size_t)rank + 1) / (size_t)world;
             end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], off + lo);
         } else {
-            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k], off, MsmGroups(), sp);
+            MsmGroups ex;
+            // measurement switch tail_stream: the merged product's reduction tail on the idle L stream, so that the next proof's sort of
+            // the same product starts when this accumulation ends instead of ~1 ms later (r5_experiments.txt item 11)
+            if (k == 4 && sp.scalars2 && ctx->opt_tail_stream && !ctx->opt_serialize && !ctx->graph_capture) ex.tail_stream = ctx->msm_stream[1];
+            end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k], off, ex, sp);
         }
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
         ps.last_acc = S.acc_evt[k];
