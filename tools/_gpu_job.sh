@@ -1,6 +1,9 @@
 set -u
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r5o
-( timeout 1500 python -m pytest tests/test_gpu_prove.py tests/test_golden.py tests/test_gpu_blocks.py -m gpu -x -q 2>&1 | tail -6 ) > gpurun_out/r5o/pytest.txt
-bash tools/ab.sh r5o_ab 5 60 -- "measure --opt ntt_fuse=0" "measure" "measure --opt tail_stream=1" "measure --opt tail_stream=1 --depth 3"
-cat gpurun_out/r5o/pytest.txt gpurun_out/r5o_ab/ab.txt gpurun_out/r5o_ab/ab_raw.txt
+mkdir -p gpurun_out/r5p
+( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) > gpurun_out/r5p/pytest.txt
+bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
+python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
+python bench.py --steps 100 --warmup 5 > gpurun_out/bench_final_100.json 2>> gpurun_out/bench_final.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_final_20.json 2>> gpurun_out/bench_final.err
+cat gpurun_out/r5p/pytest.txt; tail -3 gpurun_out/profile_round.log
