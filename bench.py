@@ -651,6 +651,8 @@ def main():
         state["stamps"] = []
         t0 = time.perf_counter()
         outs = run(args.steps, mode)
+        state["t_run_ms"] = round(1e3 * (time.perf_counter() - t0), 3)
+        state["t_first_ms"] = round(1e3 * (next((x for x in state["stamps"] if x is not None), t0) - t0), 3)
         torch.cuda.synchronize()
         leg_barrier(tag + "_b1", collective)
         elapsed = leg_max(tag + "_t", time.perf_counter() - t0, collective)
@@ -697,7 +699,7 @@ def main():
             if mode == primary:
                 state["ss_ms"] = steady_state_ms()
                 if os.environ.get("ZK_BENCH_DUMP_INTERVALS"):
-                    print("intervals_ms", completion_intervals_ms(), file=sys.stderr, flush=True)
+                    print("first_completion_ms", state.get("t_first_ms"), "all_waited_ms", state.get("t_run_ms"), "intervals_ms", completion_intervals_ms(), file=sys.stderr, flush=True)
         except Exception as e:   # noqa: BLE001 -- reported in the JSON line
             if not collective:
                 raise
