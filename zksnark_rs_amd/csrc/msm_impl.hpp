@@ -722,11 +722,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.hist.ensure((size_t)chunks * bins);
     ws.total.ensure(bins);
     ws.bin_start.ensure(bins + 1);
-    // level-1 records: entries (4 B each) | sub-buckets (2 B each), back to back in one allocation
-    const size_t rec_words = (entries * 4 + 15) / 16 * 2;                  // uint64 words of the entry array, 16-byte aligned
-    ws.records.ensure(rec_words + (entries * 2 + 7) / 8 + 2);
-    uint32_t* const rec_entry = reinterpret_cast<uint32_t*>(ws.records.p);
-    uint16_t* const rec_sub = reinterpret_cast<uint16_t*>(ws.records.p + rec_words);
+    ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
     ws.sorted.ensure(entries_padded);
     if (!ws.runs_cnt.p) {   // cleared once; k_msm_runs_scan leaves it cleared
@@ -775,12 +771,12 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             hipLaunchKernelGGL(k_msm_chunk_prefix, dim3(ceil_div(bins, 64)), dim3(64), 0, st, ws.hist.p, chunks, bins, ws.bin_start.p);
         }
         {
-            ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 6.0 * entries + 4.0 * chunks * bins, st);
+            ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
             hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, src, n_used, n, chunk_len, c, windows, rank, world,
-                               sub_bits, groups, ws.hist.p, rec_entry, rec_sub);
+                               sub_bits, groups, ws.hist.p, ws.records.p);
         }
         {
-            ProfScope ps(ctx, "msm_sort_bins", 12.0 * entries + 4.0 * buckets, st);
+            ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
             // ~2048 level-2 workgroups in all, dealt to the bins in proportion to their records (at least BIN_STAGE records each)
             const int subs = 1 << sub_bits;
             const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries + 2047) / 2048);
@@ -788,7 +784,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             ws.bin_cnt.ensure((size_t)grid2 * subs);
             ws.part_start.ensure((size_t)bins + 1);
             hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
-            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, rec_sub, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
+            hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
             if (aff_rounds) {
                 ws.ptotal.ensure(bins);
                 ws.pbin_start.ensure(bins + 1);
@@ -799,7 +795,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             }
             hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p, aff_pad,
                                aff_rounds ? (const uint32_t*)ws.pbin_start.p : (const uint32_t*)nullptr, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, rec_entry, rec_sub, ws.bin_start.p, ws.part_start.p, bins,
+            hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                                sub_bits, ws.bin_cnt.p, ws.sorted.p);
         }
         if (aff_rounds) {

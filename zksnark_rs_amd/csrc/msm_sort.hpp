@@ -27,9 +27,8 @@ struct ScalarSrc {
 #ifdef ZK_MSM_COMMON
 // ---- two-level counting sort of the digits by bucket -------------------------------------------
 // A bucket id (|digit| - 1, c - 1 bits) splits into a bin (high bits, at most 2^10 bins) and a sub-bucket.
-// Level 1 (one workgroup per scalar chunk) groups the digits by bin: per (chunk, bin) the records -- a 4-byte entry
-// (w*n + i) << 1 | sign and a 2-byte sub-bucket, in two arrays: level 2's histogram reads only the 2 bytes (round 5: 14 instead
-// of 24 bytes of record traffic per digit) -- form runs of hundreds of bytes, so the stores fill whole lines --
+// Level 1 (one workgroup per scalar chunk) groups the digits by bin: per (chunk, bin) the 8-byte records
+// (sub-bucket, (w*n + i) << 1 | sign) form runs of hundreds of bytes, so the stores fill whole lines --
 // a direct counting sort over 2^15 buckets emits 16-byte runs and was bound by partial-line write
 // bursts (1.35 ms of a 2^20 proof).  Level 2 (one workgroup per bin) finishes the sort inside a bin
 // whose records and 4-byte output both sit in L2, and emits the bucket offsets.  LDS holds only
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 // was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(ScalarSrc src, size_t n, size_t stride, size_t chunk_len, int c, int windows,
                                                                      int first, int step, int sub_bits, int groups,
-                                                                     const uint32_t* __restrict__ prefix, uint32_t* __restrict__ rec_entry, uint16_t* __restrict__ rec_sub) {
+                                                                     const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
@@ -197,8 +196,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(ScalarSrc src, siz
         for_each_digit_auto(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
             const uint32_t b = mag - 1;
             uint32_t pos = lds_inc(lds, bin0 + (b >> sub_bits));
-            rec_entry[pos] = ((uint32_t)((size_t)w * stride + il) << 1) | neg;
-            rec_sub[pos] = (uint16_t)(b & sub_mask);
+            records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + il) << 1) | neg);
         });
     }
 }
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_msm_bin_parts(const uint32_t* __restri
     if (threadIdx.x == 0) part_start[bins] = total;
 }
 
-__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint16_t* __restrict__ rec_sub, const uint32_t* __restrict__ bin_start,
+__global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
                                                                 const uint32_t* __restrict__ part_start, int bins, int sub_bits, uint32_t* __restrict__ cnt) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -247,12 +245,12 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint16_t* 
     __syncthreads();
     // four records in flight per lane: a bin holding a heavy bucket makes this loop long and latency-bound
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 4 * SORT2_THREADS) {
-        uint32_t r[4];
+        uint64_t r[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? rec_sub[k + j * SORT2_THREADS] : 0;
+        for (int j = 0; j < 4; ++j) r[j] = k + j * SORT2_THREADS < hi ? records[k + j * SORT2_THREADS] : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k + j * SORT2_THREADS < hi) lds_inc(lds, r[j] & (uint32_t)(subs - 1));
+            if (k + j * SORT2_THREADS < hi) lds_inc(lds, (uint32_t)(r[j] >> 32) & (uint32_t)(subs - 1));
     }
     __syncthreads();
     uint32_t* row = cnt + (size_t)blockIdx.x * subs;
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
 
 // level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
 // them by sub-bucket inside LDS and stores runs of consecutive 4-byte entries
-__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint32_t* __restrict__ rec_entry, const uint16_t* __restrict__ rec_sub, const uint32_t* __restrict__ bin_start,
+__global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t* __restrict__ records, const uint32_t* __restrict__ bin_start,
                                                                   const uint32_t* __restrict__ part_start, int bins, int sub_bits,
                                                                   const uint32_t* __restrict__ pos_in, uint32_t* __restrict__ sorted) {
     ZK_LATENCY_KERNEL();
@@ -372,8 +370,9 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint32_t
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j) {
             const uint32_t k = base + j * BINS_THREADS + threadIdx.x;
-            ent[j] = k < hi ? rec_entry[k] : 0;
-            sub[j] = (k < hi ? (uint32_t)rec_sub[k] : 0u) & (uint32_t)(subs - 1);
+            const uint64_t r = k < hi ? records[k] : 0;
+            ent[j] = (uint32_t)r;
+            sub[j] = (uint32_t)(r >> 32) & (uint32_t)(subs - 1);
         }
 #pragma unroll
         for (int j = 0; j < BIN_PER_LANE; ++j)
@@ -520,13 +519,13 @@ __global__ void k_msm_hist(ScalarSrc, size_t, size_t, int, int, int, int, int, i
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, const uint32_t*, uint32_t*, uint16_t*);
+__global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
-__global__ void k_msm_bin_hist(const uint16_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
+__global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*, uint32_t, const uint32_t*, uint32_t*);
 __global__ void k_msm_shift_starts(uint32_t*, uint32_t, int);
 __global__ void k_msm_identity_entries(uint32_t*, uint32_t);
-__global__ void k_msm_bin_scatter(const uint32_t*, const uint16_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
+__global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 __global__ void k_msm_runs_count(const uint32_t*, int, uint32_t, uint32_t*, uint32_t*);
 __global__ void k_msm_runs_scan(uint32_t*, uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);
 __global__ void k_msm_runs_emit(const uint32_t*, int, uint32_t, uint32_t*, const uint32_t*, MsmRun*, uint32_t*);
