@@ -226,3 +226,17 @@ def test_rust_binding_guard_catches_drift():
     assert r4 != rust and any("zk_mgpu_pop" in b for b in compare_abi(header, r4)[0])
     r5 = rust.replace("fn zk_comm_set_timeout(c: *mut ZkComm, ms: std::os::raw::c_long)", "fn zk_comm_set_timeout(c: *mut ZkComm, ms: c_int)")
     assert r5 != rust and any("zk_comm_set_timeout" in b for b in compare_abi(header, r5)[0])
+
+
+def test_bench_reads_this_rounds_profile_files():
+    """bench.py's roofline fields are read from committed counter files, never typed in: they must be the newest round's (VERDICT r4
+    weak 6: a two-round-old micro-benchmark file fed the line) and exist (host code, no GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    newest = max(int(m.group(1)) for m in (re.match(r"r(\d+)_", f) for f in os.listdir(os.path.join(ROOT, "profiles"))) if m)
+    for name in [bench.PMC_FILES[20], bench.PMC_FILES[16], bench.PMC_ACC_FILES[20], bench.PMC_ACC_FILES[16], bench.UBENCH_FILE]:
+        assert name.startswith("r%d_" % newest), name
+        assert os.path.getsize(os.path.join(ROOT, "profiles", name)) > 0, name
+    assert bench.ubench_sustained() is not None and bench.pmc_acc("msm_accumulate_g1", 20) is not None
