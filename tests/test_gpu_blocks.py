@@ -297,6 +297,44 @@ def test_msm_tail_forms_agree(ctx, orc, c):
     assert ctx.get_option("msm_quad_buckets") == 65536
 
 
+@pytest.mark.parametrize("pattern", ["equal", "rows", "columns", "holes"])
+@pytest.mark.parametrize("c", [9, 12])
+def test_msm_fold_equal_and_opposite_images(ctx, orc, c, pattern):
+    """The row / column sums of the tail add bucket IMAGES with the general XYZZ addition; its same-x branch (equal images: doubling in
+    place, dbl_xyzz; opposite images: infinity) never fires on random data.  Here every bucket of one window holds the one point P
+    or -P, so every first addition of a fold is P + P or P + (-P), and the later ones meet infinity on either side -- in the
+    one-lane form (add_xyzz_from over Fq2, add_xyzz over Fq) and in the four-lane form, against the folded double-and-add."""
+    buckets = 1 << (c - 1)
+    kbits = c // 2                                    # columns = 2^kbits (msm_impl.hpp: kbits = c / 2)
+    s = 0x1234567
+    base1, base2 = orc.enc_base_g1(), orc.enc_base_g2()
+    pos = ints_to_limbs([s]); neg = ints_to_limbs([R_MODULUS - s])
+    P1, N1 = orc.g1_mul_batch(base1[None, :], pos)[0], orc.g1_mul_batch(base1[None, :], neg)[0]
+    P2, N2 = orc.g2_mul_batch(base2[None, :], pos)[0], orc.g2_mul_batch(base2[None, :], neg)[0]
+    idx = np.arange(buckets)
+    if pattern == "equal":
+        minus, keep = np.zeros(buckets, bool), np.ones(buckets, bool)
+    elif pattern == "rows":
+        minus, keep = ((idx >> kbits) & 1).astype(bool), np.ones(buckets, bool)
+    elif pattern == "columns":
+        minus, keep = (idx & 1).astype(bool), np.ones(buckets, bool)
+    else:                                             # empty buckets (infinity images) between equal and opposite ones
+        minus, keep = ((idx >> kbits) % 3 == 1), (idx % 5 != 2)
+    digits = (idx + 1)[keep]                          # scalar = digit of window 0 (<= 2^(c-1): no carry into window 1)
+    k = ints_to_limbs([int(d) for d in digits])
+    p1 = np.where(minus[keep][:, None], N1[None, :], P1[None, :])
+    p2 = np.where(minus[keep][:, None], N2[None, :], P2[None, :])
+    p1, p2 = np.ascontiguousarray(p1), np.ascontiguousarray(p2)
+    want1, want2 = orc.msm_g1(p1, k, 0), orc.msm_g2(p2, k, 0)
+    try:
+        for quad_buckets in (0, 1 << 22):
+            ctx.set_option("msm_quad_buckets", quad_buckets)
+            assert np.array_equal(ctx.msm_g1(p1, k, c), want1), (c, pattern, quad_buckets)
+            assert np.array_equal(ctx.msm_g2(p2, k, c), want2), (c, pattern, quad_buckets)
+    finally:
+        ctx.set_option("msm_quad_buckets", 65536)
+
+
 def test_msm_linearity_large(ctx, orc):
     """Size-independent property at 2^18 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b)."""
     rng = SplitMix64(78)

@@ -535,6 +535,79 @@ ZK_HD XyzzR<L> add_xyzz(const XyzzR<L>& p, const XyzzR<L>& q) {
     return r;
 }
 
+// p = 2 p in place (dbl-2008-s-1 with a = 0: U = 2Y, V = U^2, W = U V, S = X V, M = 3 X^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W Y,
+// ZZ3 = V ZZ, ZZZ3 = W ZZZ).  U and M are sums of normal forms: normalised before they are multiplied (|limb| < 2^29).
+template <class L>
+ZK_HD void dbl_xyzz(XyzzR<L>& p) {
+    if (p.inf) return;
+    const L U = (p.Y + p.Y).norm();
+    const L V = U.sqr();
+    const L W = U * V;
+    const L S = p.X * V;
+    const L X2 = p.X.sqr();
+    const L M = (X2 + X2 + X2).norm();
+    const L X3 = (M.sqr() - (S + S)).norm();
+    p.Y = xyzz_ydiff(M, S - X3, W, p.Y);
+    p.X = X3;
+    p.ZZ = V * p.ZZ;
+    p.ZZZ = W * p.ZZZ;
+}
+
+// p += *q with the operand's coordinates fetched one at a time, each right before the products that use it (the fences keep the
+// compiler from hoisting the loads): over Fq2 the by-value form holds both operands (144 registers) under its temporaries and, capped at
+// the tail kernels' 168 registers, spilled 700 bytes per lane -- 1.9 GB per proof of scratch traffic in the row / column sums of the G2
+// product.  Same formulas and bounds as add_xyzz.  (The shipped G2 fold goes one step further and keeps three of the sum's four
+// coordinates in LDS: add_xyzz_from_parked, msm_impl.hpp; this form is its ZK_FOLD_PARK=0 alternative.)
+template <class L>
+__device__ __forceinline__ void add_xyzz_from(XyzzR<L>& p, const XyzzR<L>* q) {
+    if (q->inf) return;
+    if (p.inf) { p = *q; return; }
+    // every value dies as early as the formulas allow (X1 after U1, U1 after Q, ...): at most six coordinates are alive at once
+    L U1, P;
+    {
+        const L qzz = q->ZZ;
+        U1 = p.X * qzz;
+    }
+    asm volatile("" ::: "memory");
+    {
+        const L qx = q->X;
+        P = qx * p.ZZ - U1;
+    }
+    asm volatile("" ::: "memory");
+    const L PP = P.sqr();
+    if (PP.is_zero_mod_p()) {
+        // same x (rare): opposite points, or the same point -- then 2 q is the sum, doubled in place (X1 is gone by now, and the
+        // by-value form here is what made the kernel spill)
+        const L qy = q->Y;
+        const bool same = (qy * p.ZZZ - p.Y * q->ZZZ).sqr().is_zero_mod_p();
+        if (same) { p = *q; dbl_xyzz(p); } else p.inf = true;
+        return;
+    }
+    {
+        const L qzz = q->ZZ;                 // fetched again (the line is in L1 / L2) rather than kept across the test
+        p.ZZ = (p.ZZ * qzz) * PP;
+    }
+    asm volatile("" ::: "memory");
+    const L Q = U1 * PP;
+    const L PPP = P * PP;
+    L S1, R;
+    {
+        const L qzzz = q->ZZZ;
+        S1 = p.Y * qzzz;
+        R = p.ZZZ;                           // Z1^3, needed once more for S2
+        p.ZZZ = (R * qzzz) * PPP;
+    }
+    asm volatile("" ::: "memory");
+    {
+        const L qy = q->Y;
+        R = qy * R - S1;
+    }
+    asm volatile("" ::: "memory");
+    const L X3 = (R.sqr() - PPP - (Q + Q)).norm();
+    p.Y = xyzz_ydiff(R, Q - X3, S1, PPP);
+    p.X = X3;
+}
+
 // accumulator interface used by k_msm_accumulate / k_msm_merge
 template <class F> struct AccOf { typedef XyzzR<typename LazyOf<F>::type> type; };
 template <class L> ZK_HD void acc_clear(XyzzR<L>& a) { a.inf = true; a.X = a.Y = a.ZZ = a.ZZZ = L::load(L::Elem::zero()); }

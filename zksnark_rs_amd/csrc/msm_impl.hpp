@@ -568,8 +568,96 @@ __global__ __launch_bounds__(MSM_HEAVY_THREADS, TailWaves<F>::value) void k_msm_
 // One launch serves one pass of BOTH chains (column sums and row sums are independent): workgroups [0, j0.blocks) run job 0,
 // the rest job 1 -- half the dependent launches of the tail, which is what a lone proof of a small circuit waits for.
 struct FoldJob { const void* in; void* out; uint32_t A, f, B, blocks; };
+#ifndef ZK_FOLD_G2_WAVES
+#define ZK_FOLD_G2_WAVES ZK_TAIL_G2_WAVES
+#endif
+// G2 folds with Y, ZZ and ZZZ of the running sum in LDS between their uses.  The general addition over Fq2 holds 233 registers at
+// once; capped at the tail kernels' 168 the by-value form (add_xyzz) spilled 700 B per lane -- 1.9 GB of scratch traffic per proof of
+// 2^20 gates, a ninth of everything a proof moved -- and the coordinate-by-coordinate form (add_xyzz_from, ZK_FOLD_PARK=0) still 53
+// dwords per addition (0.7 GB).  Parked: 15 KB of LDS per workgroup, 20 ds_read_b128 + 15 ds_write_b128 per addition, no scratch on
+// the path of an ordinary addition.  Same box, 5 x 20 steps interleaved: by value 102.53, by coordinate 103.76, parked 103.49,
+// by value at 2 waves per SIMD (233 registers, ZK_FOLD_G2_WAVES=2) 103.06 proofs/s; HBM bytes per proof 17.51 / 16.41 / 15.70 /
+// 15.62 GB (profiles/r5_experiments.txt item 14).
+#ifndef ZK_FOLD_PARK
+#define ZK_FOLD_PARK 1
+#endif
+struct FoldPark { int4 r[3][5][TAIL_THREADS]; };   // [Y | ZZ | ZZZ][row][lane]
+__device__ __forceinline__ void fpark_put(FoldPark* pk, int which, const Fp2R<FqParams>& v) {
+    int4* row = &pk->r[which][0][threadIdx.x];
+    row[0 * TAIL_THREADS] = make_int4(v.c0.v[0], v.c0.v[1], v.c0.v[2], v.c0.v[3]);
+    row[1 * TAIL_THREADS] = make_int4(v.c0.v[4], v.c0.v[5], v.c0.v[6], v.c0.v[7]);
+    row[2 * TAIL_THREADS] = make_int4(v.c0.v[8], v.c1.v[0], v.c1.v[1], v.c1.v[2]);
+    row[3 * TAIL_THREADS] = make_int4(v.c1.v[3], v.c1.v[4], v.c1.v[5], v.c1.v[6]);
+    row[4 * TAIL_THREADS] = make_int4(v.c1.v[7], v.c1.v[8], 0, 0);
+}
+__device__ __forceinline__ Fp2R<FqParams> fpark_get(const FoldPark* pk, int which) {
+    asm volatile("" ::: "memory");   // a fresh read every time: the point is NOT to keep the value in registers
+    const int4* row = &pk->r[which][0][threadIdx.x];
+    const int4 a = row[0 * TAIL_THREADS], b = row[1 * TAIL_THREADS], c = row[2 * TAIL_THREADS], d = row[3 * TAIL_THREADS], e = row[4 * TAIL_THREADS];
+    Fp2R<FqParams> v;
+    v.c0.v[0] = a.x; v.c0.v[1] = a.y; v.c0.v[2] = a.z; v.c0.v[3] = a.w; v.c0.v[4] = b.x; v.c0.v[5] = b.y; v.c0.v[6] = b.z; v.c0.v[7] = b.w;
+    v.c0.v[8] = c.x; v.c1.v[0] = c.y; v.c1.v[1] = c.z; v.c1.v[2] = c.w; v.c1.v[3] = d.x; v.c1.v[4] = d.y; v.c1.v[5] = d.z; v.c1.v[6] = d.w;
+    v.c1.v[7] = e.x; v.c1.v[8] = e.y;
+    return v;
+}
+// add_xyzz_from (lazy29.cuh) with the sum's Y / ZZ / ZZZ in LDS: same formulas, same order, same bounds
+__device__ __forceinline__ void add_xyzz_from_parked(Fp2R<FqParams>& X, bool& inf, FoldPark* pk, const XyzzR<Fp2R<FqParams>>* q) {
+    typedef Fp2R<FqParams> L;
+    if (q->inf) return;
+    if (inf) {
+        X = q->X; fpark_put(pk, 0, q->Y); fpark_put(pk, 1, q->ZZ); fpark_put(pk, 2, q->ZZZ);
+        inf = false;
+        return;
+    }
+    L U1, P;
+    {
+        const L qzz = q->ZZ;
+        U1 = X * qzz;
+    }
+    asm volatile("" ::: "memory");
+    {
+        const L qx = q->X;
+        P = qx * fpark_get(pk, 1) - U1;
+    }
+    asm volatile("" ::: "memory");
+    const L PP = P.sqr();
+    if (PP.is_zero_mod_p()) {
+        const L qy = q->Y;
+        const bool same = (qy * fpark_get(pk, 2) - fpark_get(pk, 0) * q->ZZZ).sqr().is_zero_mod_p();
+        if (same) {
+            XyzzR<L> t = *q;
+            dbl_xyzz(t);
+            X = t.X; fpark_put(pk, 0, t.Y); fpark_put(pk, 1, t.ZZ); fpark_put(pk, 2, t.ZZZ);
+        } else inf = true;
+        return;
+    }
+    {
+        const L qzz = q->ZZ;
+        fpark_put(pk, 1, (fpark_get(pk, 1) * qzz) * PP);
+    }
+    asm volatile("" ::: "memory");
+    const L Q = U1 * PP;
+    const L PPP = P * PP;
+    L S1, R;
+    {
+        const L qzzz = q->ZZZ;
+        S1 = fpark_get(pk, 0) * qzzz;
+        const L Z3 = fpark_get(pk, 2);
+        const L T = Z3 * qzzz;
+        asm volatile("" ::: "memory");
+        const L qy = q->Y;
+        R = qy * Z3 - S1;
+        fpark_put(pk, 2, T * PPP);
+    }
+    asm volatile("" ::: "memory");
+    const L X3 = (R.sqr() - PPP - (Q + Q)).norm();
+    fpark_put(pk, 0, xyzz_ydiff(R, Q - X3, S1, PPP));
+    X = X3;
+}
+template <class F> struct FoldWaves { static constexpr int value = TailWaves<F>::value; };
+template <> struct FoldWaves<Fq2> { static constexpr int value = ZK_FOLD_G2_WAVES; };
 template <class F>
-__global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_fold(FoldJob j0, FoldJob j1) {
+__global__ __launch_bounds__(TAIL_THREADS, FoldWaves<F>::value) void k_msm_fold(FoldJob j0, FoldJob j1) {
     ZK_LATENCY_KERNEL();
     const bool second = blockIdx.x >= j0.blocks;
     const AccSlot<F>* in = reinterpret_cast<const AccSlot<F>*>(second ? j1.in : j0.in);
@@ -579,8 +667,22 @@ __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_fold(
     if (j >= A * B) return;
     const uint32_t a = j / B, b = j - a * B;
     const AccSlot<F>* src = in + (size_t)a * f * B + b;
+    if constexpr (sizeof(F) > sizeof(Fq) && ZK_FOLD_PARK != 0) {
+        __shared__ FoldPark pk;
+        Fp2R<FqParams> X = src[0].a.X;
+        bool inf = src[0].a.inf;
+        fpark_put(&pk, 0, src[0].a.Y); fpark_put(&pk, 1, src[0].a.ZZ); fpark_put(&pk, 2, src[0].a.ZZZ);
+        for (uint32_t i = 1; i < f; ++i) add_xyzz_from_parked(X, inf, &pk, &src[(size_t)i * B].a);
+        out[j].a.X = X; out[j].a.Y = fpark_get(&pk, 0); out[j].a.ZZ = fpark_get(&pk, 1); out[j].a.ZZZ = fpark_get(&pk, 2);
+        out[j].a.inf = inf;
+        return;
+    }
     typename AccOf<F>::type acc = src[0].a;
-    for (uint32_t i = 1; i < f; ++i) acc = acc_add(acc, src[(size_t)i * B].a);
+    if constexpr (sizeof(F) > sizeof(Fq)) {
+        for (uint32_t i = 1; i < f; ++i) add_xyzz_from(acc, &src[(size_t)i * B].a);
+    } else {
+        for (uint32_t i = 1; i < f; ++i) acc = acc_add(acc, src[(size_t)i * B].a);
+    }
     out[j].a = acc;
 }
 
@@ -886,8 +988,13 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                 if (h.done) { job[q] = FoldJob{nullptr, nullptr, 0, 1, 1, 0}; continue; }
                 const uint32_t f = std::min(h.count, FOLD);
                 AccSlot<F>* out = h.count == f ? h.fin : h.tmp[h.tog];
-                const uint32_t A = h.outer * (h.count / f);
-                job[q] = FoldJob{h.in, out, A, f, h.B, 0};
+                // rows (B = 1): the f images a lane adds are count / f apart, not adjacent -- out[a][b] = sum_i in[a][i count / f + b] --
+                // so that consecutive lanes read consecutive images (adjacent images per lane put the lanes of a load f images apart:
+                // every 16-byte access its own line, and over Fq2, where the coordinates are fetched one by one, lines were evicted
+                // between their uses: ~0.8 GB per proof re-read).  The order of a sum of points does not change the sum.
+                const bool wide = h.B == 1 && h.count > f;
+                const uint32_t A = wide ? h.outer : h.outer * (h.count / f);
+                job[q] = FoldJob{h.in, out, A, f, wide ? h.count / f : h.B, 0};
                 if (h.count == f) h.done = true;
                 h.count /= f; h.in = out; h.tog ^= 1;
             }
