@@ -1,5 +1,7 @@
 #!/bin/bash
-# Copies the summaries a profile round left under gpurun_out/prof/ (tools/profile_round.sh) into profiles/ as rN_*:  tools/install_profiles.sh 5
+# Copies the summaries a profile round left under gpurun_out/prof/ (tools/profile_round.sh) into profiles/ as rN_*:  tools/install_profiles.sh 5 [commit]
+# [commit]: the profiled snapshot was an uncommitted working tree (files say "<HEAD>+uncommitted", tools/gpu.sh) that was committed
+# UNCHANGED as <commit> afterwards -- the files then name that commit.
 set -eu
 N=${1:?round number}
 cd "$(dirname "$0")/.."
@@ -14,4 +16,5 @@ done
 for s in "" _100 _20; do
   [ -s gpurun_out/bench_final$s.json ] && tail -1 gpurun_out/bench_final$s.json > profiles/r${N}_bench$( [ -z "$s" ] && echo "" || echo "${s}steps" ).json
 done
+if [ -n "${2:-}" ]; then sed -i -E "s/[0-9a-f]{12}\+uncommitted/$2/" $(grep -lE "[0-9a-f]{12}\+uncommitted" profiles/r${N}_* || echo /dev/null); fi
 ls -la profiles/r${N}_* | wc -l
