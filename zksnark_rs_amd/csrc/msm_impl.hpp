@@ -991,7 +991,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                 // rows (B = 1): the f images a lane adds are count / f apart, not adjacent -- out[a][b] = sum_i in[a][i count / f + b] --
                 // so that consecutive lanes read consecutive images (adjacent images per lane put the lanes of a load f images apart:
                 // every 16-byte access its own line, and over Fq2, where the coordinates are fetched one by one, lines were evicted
-                // between their uses: ~0.8 GB per proof re-read).  The order of a sum of points does not change the sum.
+                // between their uses: 0.2 GB per proof re-read, r5_experiments.txt item 14).  The order of a sum of points does not change the sum.
                 const bool wide = h.B == 1 && h.count > f;
                 const uint32_t A = wide ? h.outer : h.outer * (h.count / f);
                 job[q] = FoldJob{h.in, out, A, f, wide ? h.count / f : h.B, 0};
