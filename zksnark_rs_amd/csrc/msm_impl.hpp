@@ -202,6 +202,17 @@ template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
 #ifndef ZK_G2_SHAPE
 #define ZK_G2_SHAPE 1, 0, 1
 #endif
+// The sorted entries four at a time (one aligned 16-byte block every fourth trip) instead of one dword per trip.  A lane comes back
+// to the same line of the list 32 trips later, by which time the gathers have pushed it out of L2, so read dword by dword an entry
+// costs a sector of its own.  Build-time switches for A/B, both OFF: G1 (141 registers, +8 instructions per addition) moved 0.48 GB
+// per proof less (15.69 -> 15.21 GB) at 106.63 against 107.79 proofs/s, same box, 4 x 20 steps -- level at best on a loop that is
+// bound by instruction issue; G2 (at 256 registers) starts to spill with the four extra registers.  profiles/r5_experiments.txt item 16.
+#ifndef ZK_ACC_ENTRY_BLOCKS
+#define ZK_ACC_ENTRY_BLOCKS 0
+#endif
+#ifndef ZK_ACC_ENTRY_BLOCKS_G2
+#define ZK_ACC_ENTRY_BLOCKS_G2 0
+#endif
 template <bool NZ_, bool DEAD_, int UNROLL_> struct AccShapeOf { static constexpr bool NZ = NZ_, DEAD = DEAD_; static constexpr int UNROLL = UNROLL_; };
 template <class F> struct AccShape : AccShapeOf<ZK_G1_SHAPE> {};
 template <> struct AccShape<Fq2> : AccShapeOf<ZK_G2_SHAPE> {};
@@ -303,6 +314,10 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         constexpr int ROWS = (int)(sizeof(Aff<F>) / 16);
         __shared__ int4 stage[ROWS][256];
         int4* const wave_rows = &stage[0][threadIdx.x & ~63u];
+        [[maybe_unused]] uint4 ebp = make_uint4(0, 0, 0, 0);   // the block of four sorted entries the next one comes from (ZK_ACC_ENTRY_BLOCKS)
+        if constexpr (ZK_ACC_ENTRY_BLOCKS_G2 != 0) {
+            if (k + 2 < k1) ebp = *reinterpret_cast<const uint4*>(sorted + ((k + 2) & ~3u));
+        }
         auto issue = [&](uint32_t entry) {
             const int4* src = reinterpret_cast<const int4*>(table + (entry >> 1));
 #pragma unroll
@@ -321,7 +336,13 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             const uint32_t kn = k + 1;
             if (kn < k1) issue(e_next);
             e = e_next;
-            e_next = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            if constexpr (ZK_ACC_ENTRY_BLOCKS_G2 != 0) {
+                const uint32_t i = kn + 1, j = i & 3u;
+                if (i < k1 && j == 0) ebp = *reinterpret_cast<const uint4*>(sorted + i);
+                e_next = i < k1 ? (j == 0 ? ebp.x : j == 1 ? ebp.y : j == 2 ? ebp.z : ebp.w) : 0;
+            } else {
+                e_next = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            }
             k = kn;
             return u.pt;
         };
@@ -425,13 +446,27 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         // `second`: the peeled second trip of the run -- when the first one started the accumulator from a finite point (`fresh`), the
         // sum is an affine + affine addition (madd_xyzz_second)
         bool fresh = false;
+        // entries [i & ~3, (i & ~3) + 4) of the list, i = the next entry the loop will ask for (the list is padded to whole blocks)
+        [[maybe_unused]] uint4 eb = make_uint4(0, 0, 0, 0);
+        if constexpr (ZK_ACC_ENTRY_BLOCKS != 0) {
+            if (k + 2 < k1) eb = *reinterpret_cast<const uint4*>(sorted + ((k + 2) & ~3u));
+        }
+        auto entry = [&](uint32_t i) -> uint32_t {   // i < k1, one more than at the previous call
+            if constexpr (ZK_ACC_ENTRY_BLOCKS != 0) {
+                const uint32_t j = i & 3u;
+                if (j == 0) eb = *reinterpret_cast<const uint4*>(sorted + i);
+                return j == 0 ? eb.x : j == 1 ? eb.y : j == 2 ? eb.z : eb.w;
+            } else {
+                return sorted[i];
+            }
+        };
         auto step = [&](auto second) {
             if constexpr (Shape::DEAD) {
                 if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
             }
             const uint32_t kn = k + 1;
             const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
-            const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            const uint32_t e_next2 = kn + 1 < k1 ? entry(kn + 1) : 0;
             if (!p.is_inf()) {
                 L qx = L::load(p.x), qy = L::load(p.y);
                 if (e & 1) qy = qy.neg();
@@ -826,7 +861,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.bin_start.ensure(bins + 1);
     ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
-    ws.sorted.ensure(entries_padded);
+    ws.sorted.ensure(entries_padded + 4);   // + 4: ZK_ACC_ENTRY_BLOCKS builds read the list in aligned blocks of four entries
     if (!ws.runs_cnt.p) {   // cleared once; k_msm_runs_scan leaves it cleared
         ws.runs_cnt.alloc(2 * (RUN_MAX + 2) + 2);
         ZK_HIP(hipMemsetAsync(ws.runs_cnt.p, 0, ws.runs_cnt.bytes(), st));
@@ -923,7 +958,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
                     out += pairs;
                 }
                 if (ws.ident_filled < entries_acc) {
-                    ws.ident.ensure(entries_acc);
+                    ws.ident.ensure(entries_acc + 4);
                     hipLaunchKernelGGL(k_msm_identity_entries, dim3(ceil_div(entries_acc, 256)), dim3(256), 0, st, ws.ident.p, (uint32_t)entries_acc);
                     ws.ident_filled = entries_acc;
                 }
