@@ -9,7 +9,8 @@ carry chain and the column sum in two 64-bit accumulators that it joins with one
 137 of the 2262 instructions of a G1 addition), subtracts the second product of mont_diff with 64-bit v_sub_co / v_subb_co pairs
 and copies operands between the unrolled iterations.  The sequences below are the same algorithm with ONE accumulator per
 column chain: the first multiply-add of a column takes the shifted carry of the previous one as its addend, m_k lives in the
-register that later receives output limb k, and nothing else is issued: 162 + 43 instructions per multiplication.
+register that later receives output limb k, and nothing else is issued: 162 + 43 instructions per multiplication (round 6: the
+last column's 64-bit shift and the copy of its low half are one v_alignbit_b32).
 
 Every sequence is a list of abstract instructions; `simulate` executes the list on Python integers with the wrap-around
 semantics of the hardware instructions (so register reuse and ordering are checked here, on the CPU), and `render` prints it
@@ -23,6 +24,7 @@ import os
 M29 = (1 << 29) - 1
 ACC = ["v[4:5]", "v[6:7]"]
 ACC_LO = ["v4", "v6"]
+ACC_HI = ["v5", "v7"]
 CLOBBER = {0: ["v4", "v5"], 1: ["v6", "v7"]}
 
 
@@ -57,6 +59,9 @@ class Seq:
     def movlo(self, d, acc):                     # d = lo32(acc)
         self.ins.append(("movlo", d, acc))
 
+    def shr29lo(self, d, acc):                   # d = lo32(acc >> 29): ONE v_alignbit_b32 instead of the last column's 64-bit shift + v_mov
+        self.ins.append(("shr29lo", d, acc))
+
     def shl1(self, d, s):
         self.ins.append(("shl1", d, s))
 
@@ -69,7 +74,8 @@ def column_range(k):
 
 
 def reduce_column(q, acc, k, m, r):
-    """the Montgomery part of column k on accumulator `acc`: m[i] * p[k-i] terms, then m_k or the output limb, then the shift"""
+    """the Montgomery part of column k on accumulator `acc`: m[i] * p[k-i] terms, then m_k or the output limb, then the shift
+    (column 16: the shifted value IS output limb 8 -- one v_alignbit_b32 of the accumulator's halves)"""
     lo, hi = column_range(k)
     for i in range(lo, hi + 1):
         if i < k or k >= 9:
@@ -80,7 +86,10 @@ def reduce_column(q, acc, k, m, r):
         q.mad(acc, m[k], "p0")
     else:
         q.and29(r[k - 9], ("lo", acc))
-    q.ashr(acc)
+    if k == 16:
+        q.shr29lo(r[8], acc)
+    else:
+        q.ashr(acc)
 
 
 def gen_mul(kind):
@@ -109,7 +118,6 @@ def gen_mul(kind):
             for i in range(lo, hi + 1):
                 q.mad(0, "c%d" % i, "d%d" % (k - i))
         reduce_column(q, 0, k, r, r)
-    q.movlo("r8", 0)
     return q
 
 
@@ -137,8 +145,6 @@ def gen_fp2():
         for x, y in zip(q0.ins, q1.ins):
             q.ins.append(x)
             q.ins.append(y)
-    q.movlo("r8", 0)
-    q.movlo("s8", 1)
     return q
 
 
@@ -168,6 +174,8 @@ def simulate(q, regs, P29, INV29):
             acc[ins[1]] = acc[ins[1]] >> 29
         elif op == "movlo":
             regs[ins[1]] = s32(acc[ins[2]])
+        elif op == "shr29lo":
+            regs[ins[1]] = s32(acc[ins[2]] >> 29)
         elif op == "shl1":
             regs[ins[1]] = s32(regs[ins[2]] << 1)
         elif op == "neg":
@@ -286,6 +294,8 @@ def render(q, name, ins_groups, out_groups, tmp_groups, naccs):
             lines.append("v_ashrrev_i64 %s, 29, %s" % (ACC[ins[1]], ACC[ins[1]]))
         elif op == "movlo":
             lines.append("v_mov_b32 %s, %s" % (reg(ins[1]), ACC_LO[ins[2]]))
+        elif op == "shr29lo":
+            lines.append("v_alignbit_b32 %s, %s, %s, 29" % (reg(ins[1]), ACC_HI[ins[2]], ACC_LO[ins[2]]))
         elif op == "shl1":
             lines.append("v_lshlrev_b32 %s, 1, %s" % (reg(ins[1]), reg(ins[2])))
         elif op == "neg":

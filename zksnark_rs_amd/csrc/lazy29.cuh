@@ -43,6 +43,7 @@ namespace zk {
 
 #if ZK_MONT_ASM_ON
 #include "mont_asm.inc"
+#include "madd_asm.inc"
 #endif
 
 template <class PR>

@@ -285,6 +285,15 @@ __device__ __forceinline__ int madd_xyzz_nz_parked(Fp2R<FqParams>& X, Fp2R<FqPar
 #ifndef ZK_ACC_UNIT
 #define ZK_ACC_UNIT 1
 #endif
+// The G1 loop over the whole-addition asm bodies of madd_asm.inc (tools/gen_madd_asm.py): multipliers in place, X alternating between
+// two register sets, Y alternating in sign -- no copy of the accumulator and no negation on the hot path.
+#ifndef ZK_ACC_BODY_G1
+#define ZK_ACC_BODY_G1 1
+#endif
+template <class F> struct AccAsmBody { static constexpr bool on = false; };
+#if ZK_MONT_ASM_ON
+template <> struct AccAsmBody<Fq> { static constexpr bool on = ZK_ACC_BODY_G1 != 0 && ZK_ACC_PF_G1 == 0; };
+#endif
 template <class F> struct AccPrefetchLds { static constexpr bool on = ZK_ACC_PF_G1 != 0; };
 template <> struct AccPrefetchLds<Fq2> { static constexpr bool on = ZK_ACC_PF_G2 != 0; };
 
@@ -383,6 +392,102 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
             else if (st == 2) acc_clear(acc);
         }
+    } else if constexpr (AccAsmBody<F>::on) {
+        // ---- G1: whole-addition asm bodies (madd_asm.inc) -----------------------------------------------------------------
+        // Trips 1 and 2 through the generic step (the run's first point starts the accumulator, the second joins it as an affine +
+        // affine addition); then the FAST loop, two additions per trip: the even body takes X from acc.X and leaves X3 in xb and -Y3
+        // in acc.Y, the odd body takes both back.  Anything unusual -- a table entry at infinity, a point with the accumulator's x
+        // (the sum is 2 P or infinity and is rebuilt from the affine point: the body has overwritten the accumulator), an empty
+        // accumulator -- makes the LANE leave the fast loop (kf = k) in the canonical state; the generic loop behind it finishes its run.
+        bool fresh = false;
+        auto step = [&](auto second) {
+            const uint32_t kn = k + 1;
+            const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
+            const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
+            if (!p.is_inf()) {
+                L qx = L::load(p.x), qy = L::load(p.y);
+                if (e & 1) qy = qy.neg();
+                bool done = false;
+                if constexpr (decltype(second)::value) {
+                    if (fresh && !acc.inf) {
+                        const int st = madd_xyzz_second(acc, qx, qy);
+                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));
+                        else if (st == 2) acc.inf = true;
+                        done = true;
+                    }
+                }
+                if (!done && !acc_madd(acc, qx, qy)) acc_load(acc, jac_dbl(acc_store(acc)));
+            }
+            p = p_next; e = e_next; e_next = e_next2; k = kn;
+        };
+        if (k < k1) {
+            step(std::false_type{});
+            fresh = !acc.inf;
+            if (k < k1) step(std::true_type{});
+        }
+        uint32_t kf = acc.inf ? k : k1;       // the fast loop's bound for this lane
+        L xb = acc.X;
+        const uint32_t lane = __lane_id();
+        uint32_t ev = 0, ev_k = 0;            // a point with the accumulator's x met at position ev_k of the list: 1 = opposite points, 2 = the same point
+        bool odd_state = false;               // the lane's accumulator is as the even body leaves it (X in xb, -Y in acc.Y)
+        // The next point's gather is issued BEHIND the conversion of the current one, into the registers the point has just left (one
+        // set of sixteen, no rotation), and has the whole addition to arrive.  The loads are unconditional: behind the end of the run
+        // the entry index is clamped to the run's last entry (a valid table index whose point is then not used).
+        const uint32_t klast = k1 - 1;
+        while (k < kf) {
+            // ---- even half: acc.X -> xb, Y -> -Y
+            if (p.y.l[0] == 0 && p.is_inf()) {
+                kf = k;                                                      // canonical state, entry k not consumed
+            } else {
+                L qx = L::load(p.x), qy = L::load(p.y);
+                if (e & 1) qy = qy.neg();
+                p = table[e_next >> 1];
+                e = e_next;
+                e_next = sorted[min(k + 2, klast)];
+                uint64_t sx, sp;
+                madd_asm_g1_even<FqParams>(acc.X.v, acc.Y.v, acc.ZZ.v, acc.ZZZ.v, qx.v, qy.v, xb.v, sx, sp);
+                if (sx) {
+                    asm volatile("" : "+s"(sx));                             // the lane test stays behind the (scalar) branch
+                    if ((sx >> lane) & 1) { ev = 1 + (uint32_t)((sp >> lane) & 1); ev_k = k; kf = k + 1; }
+                }
+                ++k;
+                odd_state = true;
+            }
+            // ---- odd half: xb -> acc.X, -Y -> Y
+            if (k < kf) {
+                if (p.y.l[0] == 0 && p.is_inf()) {
+                    kf = k;                                                  // odd state, entry k not consumed
+                } else {
+                    L qx = L::load(p.x), qy = L::load(p.y);
+                    if (e & 1) qy = qy.neg();
+                    p = table[e_next >> 1];
+                    e = e_next;
+                    e_next = sorted[min(k + 2, klast)];
+                    uint64_t sx, sp;
+                    madd_asm_g1_odd<FqParams>(xb.v, acc.Y.v, acc.ZZ.v, acc.ZZZ.v, qx.v, qy.v, acc.X.v, sx, sp);
+                    if (sx) {
+                        asm volatile("" : "+s"(sx));
+                        if ((sx >> lane) & 1) { ev = 1 + (uint32_t)((sp >> lane) & 1); ev_k = k; kf = k + 1; }
+                    }
+                    ++k;
+                    odd_state = false;
+                }
+            }
+        }
+        if (odd_state) { acc.X = xb; acc.Y = acc.Y.neg().norm(); }
+        if (ev) {
+            // same x: the accumulator was +-the point (the body has overwritten it): the sum is 2 P or infinity, from the affine point alone
+            acc_clear(acc);
+            if (ev == 2) {
+                const uint32_t ev_e = sorted[ev_k];
+                const Aff<F> pt = table[ev_e >> 1];
+                L qx = L::load(pt.x), qy = L::load(pt.y);
+                if (ev_e & 1) qy = qy.neg();
+                acc.X = qx; acc.Y = qy.norm(); acc.ZZ = acc.ZZZ = L::load(F::one()); acc.inf = false;
+                acc_load(acc, jac_dbl(acc_store(acc)));
+            }
+        }
+        while (k < k1) step(std::false_type{});   // lanes that left the fast loop (rare)
     } else if constexpr (Shape::NZ) {
         auto advance = [&] {
             const uint32_t kn = k + 1;
