@@ -146,7 +146,7 @@ def cpu_baseline(zk, ctx, seed, main_inst, full=False):
 
 PMC_KERNEL = {"msm_accumulate_g1": "zk::k_msm_accumulate<zk::Fp<zk::FqParams> >", "msm_accumulate_g2": "zk::k_msm_accumulate<zk::Fq2>"}
 # counter passes of THIS round's build (tools/profile_round.sh); a missing file makes the fields null, nothing is typed in here
-def _round_file(name, rounds=(5, 4, 3, 2)):
+def _round_file(name, rounds=(6, 5, 4, 3, 2)):
     """the newest committed profiles/rN_<name> (this round's, else the one before it: the line names the file it read)"""
     for r in rounds:
         f = "r%d_%s" % (r, name)
@@ -320,9 +320,6 @@ def main():
     ap.add_argument("--latency", action="store_true",
                     help="one proof at a time (--depth 1), no per-kernel event timing (two extra API calls per launch, which small "
                          "circuits feel), no CPU baseline: ms_per_step is the latency of a lone zk_prove_dev call")
-    ap.add_argument("--lone-graph", action="store_true",
-                    help="with --latency: option lone_graph -- a lone proof replays one captured hipGraph (witness through the slot's buffer, "
-                         "(r, s) and blinding factors through a device-side parameter block)")
     ap.add_argument("--cpu-baseline", choices=["default", "full"], default="default",
                     help="full: also the same-algorithm CPU path at 2^20 on ONE thread (minutes)")
     args = ap.parse_args()
@@ -408,8 +405,6 @@ def main():
         return x
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
-    if args.lone_graph:
-        ctx.set_option("lone_graph", 1)
     if (args.serialize or args.opt) and ctx.get_option("measure_build") != 1:
         raise SystemExit("--serialize / --opt are measurement switches: load the ZK_MEASURE build (make -C zksnark_rs_amd/csrc measure; "
                          "ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so)")
@@ -826,6 +821,8 @@ def main():
                         "wave_instr_per_addition": winst, "share_4_cycle_class": slow,
                         "int64_share": src.get("int64_share"), "int32_share": src.get("int32_share"),
                         "sustained_clock_GHz_stand_alone": src.get("sustained_clock_GHz"),
+                        # the issue ceiling of this mix scaled to the clock the chip holds under the kernel (counter passes, stand-alone)
+                        "frac_at_sustained_clock": round(g_inst / (meas_mix * src["sustained_clock_GHz"] / 2.4), 3) if (meas_mix and src.get("sustained_clock_GHz")) else None,
                         "source": "profiles/%s (SQ_INSTS_VALU / additions; SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU)" % PMC_ACC_FILES[args.log_n],
                         "note": "peak = 1024 SIMDs x 2.4 GHz / (share x 4 + (1 - share) x 2 cycles); peak_measured = the same mix at the rates "
                                 "tools/ubench_valu.hip sustains (read from peak_measured_source).  Under this kernel the chip clocks below 2.4 GHz "
@@ -856,6 +853,31 @@ def main():
             el4 = [int(x_) for x_ in ctx.prove_exchange_elems(inst["qap"], world)]
             if el4:
                 xg = int(sum(el4) * 32 * (world - 1) // world + zk.PARTIAL_BYTES * (world - 1))
+        # the three kernels that carry a proof, each with SURVEY 8(d)'s algorithmic bytes, the counter bytes of the committed PMC passes
+        # and their ratio (what DESIGN.md 4 quotes; per PROOF, launches summed): the accumulations gather one table entry per window
+        kernels = None
+        pf_ = pmc_file(args.log_n) if (args.log_n in PMC_FILES and world == 1 and args.roots == "unity" and not args.window_bits and args.batch <= 1) else None
+        if pf_ and pf_.get("kernels") and pf_.get("proofs_sampled"):
+            def _per_proof(prefixes):
+                tot, launches = 0.0, 0
+                for kname, kv in pf_["kernels"].items():
+                    if any(kname.startswith(pp) for pp in prefixes):
+                        tot += kv["hbm_bytes_per_launch_corrected"] * kv["launches_sampled"]
+                        launches += kv["launches_sampled"]
+                return tot / pf_["proofs_sampled"], launches / float(pf_["proofs_sampled"])
+            rows = (("msm_accumulate_g1", (PMC_KERNEL["msm_accumulate_g1"],), 96.0 * (5 * n - 2), "96 B per scalar-point pair: A (n), H + r B1 + s A (2n - 1), L (m - l - 1 = 2n - 1)"),
+                    ("msm_accumulate_g2", (PMC_KERNEL["msm_accumulate_g2"],), 160.0 * n, "160 B per pair: B2 (n)"),
+                    ("ntt_tile", ("zk::k_ntt_tile",), 448.0 * n, "7 transforms x 64 B per element"))
+            kernels = []
+            for kname, prefixes, algo, what in rows:
+                cb, lp = _per_proof(prefixes)
+                live = prof.get(kname)
+                if live and live.get("algo_bytes"):
+                    algo = live["algo_bytes"] / float(args.steps)      # the library's own count of the pairs it multiplied
+                kernels.append({"kernel": kname, "launches_per_proof": round(lp, 2), "algorithmic_bytes_per_proof": algo, "algorithmic": what,
+                                "counter_bytes_per_proof": round(cb), "counter_over_algorithmic": round(cb / algo, 2) if algo else None,
+                                "avg_launch_ms_live": round(live["total_ms"] / live["launches"], 4) if live else None,
+                                "source": "profiles/%s" % PMC_FILES[args.log_n]})
         out = {
             "metric": "Groth16 proofs/sec, 2^%d-constraint QAP" % args.log_n,
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -863,7 +885,8 @@ def main():
             # median time between consecutive proof completions of the timed region, pipeline fill and drain excluded (what
             # profiles/r5_timeline_pipelined_2p20.txt shows as the period); ms_per_step includes both
             "steady_state_ms_per_proof": state.get("ss_ms"),
-            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u256 (8x u32 Montgomery limbs)",
+            "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "dtype": "u254 mod p (9x29-bit lazy Montgomery limbs, R=2^261; 8xu32 at rest)",
             "data": "synthetic (chain circuit, %s inputs, SplitMix64 seed %d; %d distinct (witness, r, s) cycled through the timed region)" % (args.witness, args.seed, len(sets)),
             "config": {"workload": "synthetic 2^%d-constraint chain QAP (m=%d wires, l=2), BN254, prove() with CRS/QAP/witness resident in HBM%s"
                                    % (args.log_n, m, "" if args.roots == "unity" else "; QAP over the integer roots 1..n" if args.roots == "integers" else "; QAP over caller-supplied (arbitrary) roots"),
@@ -881,6 +904,7 @@ def main():
                        "proof_sha": sha(expected[0]), "proof_shas": [sha(e_) for e_ in expected], "verified": verified,
                        "expected_bytes_from": "one synchronous single-GPU zk_prove_dev per set in the untimed set-up; every timed proof is compared with it"},
             "roofline": roofline,
+            "kernels": kernels,
             **({k_: v_ for k_, v_ in (("exchange", legs.get("exchange")), ("window_shard", legs.get("window_shard") or (legs.get("shard") if args.shard == "windows" else None)),
                                       ("shard", legs.get("shard") if args.shard != "windows" else None), ("replicas", legs.get("single"))) if v_ and world > 1}),
             **({"rccl_ranks": comm.rccl_ranks() if (comm is not None and state["degraded"] is None) else 0, "xgmi_bytes_sent_per_rank_per_round": xg,

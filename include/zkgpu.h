@@ -62,28 +62,21 @@ void zk_ctx_destroy(zk_ctx* ctx);
 const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
 /* Options of the product build: "msm_window_bits" (Pippenger c of the fixed-base tables; 0 = automatic, c = the same for every table,
- * 100 * big + small = `big` for tables of 2^21 points and more, + 10000 * g2 = its own window for the G2 table), "profile" (0 off,
- * 1 event-time the bucket accumulations, 2 every launch group; read back with zk_profile_*), "msm_shard_points" (zk_prove_partial:
- * 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points), "rank_tables" (multi-GPU exchange: 1 = window tables of
- * the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the reference's long
- * division; default 0 = power-series inverse above 512 quotient coefficients), "msm_quad_buckets" (inner products of at most this
- * many buckets run their reduction tail with four lanes per point addition: shorter dependency chains for small circuits; default
- * 65536, 0 = never), "interp_large_log" (arbitrary-roots interpolation: trees of at least 2^value coefficients per level take the
- * form that re-uses the children's transforms; default 20; both forms give the same coefficients), "comm_cu_reserve" (zk_mgpu_create
- * over an RCCL communicator of more than one rank: compute units per XCD that the inner-product streams leave to the collectives'
- * kernels; default 0 = none: measured on one GPU it costs 4 % of the rate and shortens the p90 wait of an all-to-all only from 2.7 to
- * 2.2 ms, profiles/r4_rccl_starvation.txt), "lone_graph" (1: a synchronous zk_prove / zk_prove_dev of a (CRS, QAP, witness length) seen
- * before replays one captured hipGraph instead of enqueueing its ~113 launches; roots-of-unity form; measured SLOWER than the eager
- * path at every size -- 2^16 gates 2.17 against 1.59 ms, profiles/r4_lone_graph.txt -- hence default 0), "g2_affine" (1..4: G2 inner
- * products whose buckets hold 16..64 entries sum the first `value` halvings of every bucket as affine pairs with one inversion per
- * workgroup before the accumulation, and zk_g2_add_batch takes the same kernel; same points; measured SLOWER inside a proof --
- * 102.5 against 94..98 proofs/s, profiles/r4_experiments.txt item 12 -- hence default 0), "merge_lh" (default 1: the witness product
- * L = sum a_i sum_delta_i and H + r B1 + s A, which only occur added together in the proof element c, are ONE inner product over the
- * table xi_t | xi | sum_delta with one set of buckets and one reduction tail; 0 = two products as in round 4; same proof bytes, +1.3 %
- * proofs/s at 2^20 gates, profiles/r5_experiments.txt item 2).  Each is exercised by a -m gpu test.
- * A library built with -DZK_MEASURE (make -C zksnark_rs_amd/csrc measure; zk_get_option(ctx, "measure_build") == 1) also accepts the
- * measurement switches of bench.py --opt / --serialize ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole",
- * "msm_small_lanes", "msm_unchain_lanes", "chain_order"); the product build answers ZK_ERR_UNSUPPORTED to them and to unknown keys. */
+ * 100 * big + small = `big` for tables of 2^21 points and more, + 10000 * g2 = its own window for the G2 table), "msm_shard_points"
+ * (zk_prove_partial: 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points), "rank_tables" (multi-GPU exchange:
+ * 1 = window tables of the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the
+ * reference's long division; default 0 = power-series inverse above 512 quotient coefficients), "msm_quad_buckets" (inner products of
+ * at most this many buckets run their reduction tail with four lanes per point addition: shorter dependency chains for small
+ * circuits; default 65536, 0 = never), "interp_large_log" (arbitrary-roots interpolation: trees of at least 2^value coefficients per
+ * level take the form that re-uses the children's transforms; default 20; both forms give the same coefficients), "comm_cu_reserve"
+ * (zk_mgpu_create over an RCCL communicator of more than one rank: compute units per XCD that the inner-product streams leave to the
+ * collectives' kernels; default 0 = none: measured on one GPU it costs 4 % of the rate and shortens the p90 wait of an all-to-all only
+ * from 2.7 to 2.2 ms, profiles/r4_rccl_starvation.txt), "basis_tree_min" (see zk_crs_upload), "merge_lh" (default 1: the witness
+ * product L = sum a_i sum_delta_i and H + r B1 + s A, which only occur added together in the proof element c, are ONE inner product
+ * over the table xi_t | xi | sum_delta with one set of buckets and one reduction tail; 0 = two products as in round 4; same proof
+ * bytes, +1.3 % proofs/s at 2^20 gates, profiles/r5_experiments.txt item 2).  Each is exercised by a -m gpu test.  Unknown keys are
+ * answered with ZK_ERR_UNSUPPORTED.  Measurement entry points and switches -- kernel event timing, the tuning keys of bench.py --opt /
+ * --serialize -- are NOT part of this header: include/zkgpu_measure.h. */
 int zk_set_option(zk_ctx* ctx, const char* key, long value);
 long zk_get_option(const zk_ctx* ctx, const char* key);
 
@@ -122,19 +115,6 @@ int zk_msm_g2(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, size
  * FrLocal Add/Sub/Mul/Div: fr.rs:18-71 */
 int zk_fr_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zk_fq_batch(zk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
-/* The lazy radix-2^29 form of the same field arithmetic (what `Fr * Fr`, fr.rs:44-48, and bn's Fq multiply become inside
- * the bucket accumulation and the NTT tiles: csrc/lazy29.cuh, csrc/ntt.hip) on caller-supplied limb patterns, so that the
- * bounds the kernels rely on can be tested at their extremes.  Every operand is 9 signed 32-bit limbs per element, value =
- * sum v[k] 2^(29 k) (not reduced).  field: 0 = Fr, 1 = Fq.  out: canonical residues (4 words each) of the result;
- * raw_out (may be null): the result's 9 limbs before the final reduction.
- *   ZK_LAZY_MONT       a b 2^-261          (|a limbs| <= 2^30, |b limbs| < 2^29)
- *   ZK_LAZY_SQR        a a 2^-261          (|limbs| < 2^29)
- *   ZK_LAZY_MONT_DIFF  (a b - c d) 2^-261  (all |limbs| < 2^29)
- *   ZK_LAZY_NORM       a after carry propagation; ZK_LAZY_STORE  a itself        (|value| < 8 p)
- *   ZK_LAZY_FR_REDUCE  fr_reduce(a) of the NTT tiles (|value| < 2^9 r); ZK_LAZY_FR_STORE  fr_store_exact(a)   (Fr only) */
-enum { ZK_LAZY_MONT = 0, ZK_LAZY_SQR = 1, ZK_LAZY_MONT_DIFF = 2, ZK_LAZY_NORM = 3, ZK_LAZY_STORE = 4, ZK_LAZY_FR_REDUCE = 5, ZK_LAZY_FR_STORE = 6 };
-int zk_lazy29_batch(zk_ctx* ctx, int field, int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, size_t n,
-                    uint64_t* out, int32_t* raw_out);
 /* out[i] = scalars[i] * points[i]  (exp_encrypted_g1 / exp_encrypted_g2, fr.rs:114-119) */
 int zk_g1_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
 int zk_g2_mul_batch(zk_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t* out, size_t n);
@@ -370,7 +350,10 @@ typedef struct zk_comm zk_comm;
 /* Rank 0 draws the id (ncclGetUniqueId) and ships the bytes to the other ranks by any channel (file, TCP store, MPI). */
 int zk_comm_unique_id(uint8_t id_out[ZK_COMM_ID_BYTES]);
 /* Collective: every rank calls it with the same id and its own rank (ncclCommInitRank on ctx's device).  world == 1
- * needs no id and no RCCL. */
+ * needs no id and no RCCL.  The set-up is bounded like every other wait on a peer (ZK_COMM_TIMEOUT_MS): ncclCommInitRank runs on a
+ * helper thread, and when a peer never arrives the call returns ZK_ERR_COMM while that thread stays inside RCCL's bootstrap.  After
+ * such a time-out do NOT retry with the same id in this process and do not unload the library: report the failure and let the
+ * process end (bench.py's `degraded` path does exactly that). */
 int zk_comm_init(zk_ctx* ctx, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world, zk_comm** out);
 /* Caller-supplied transport.  Buffers are the ones the prover allocated (device memory with the GPU backend); the calls
  * are blocking: complete on return.  all_to_all: chunk g of `send` (bytes_per_rank bytes) goes to rank g, chunk j of `recv`
@@ -384,6 +367,8 @@ typedef struct {
     int (*max_f64)(void* user, double* value);
 } zk_comm_ops;
 int zk_comm_init_custom(zk_ctx* ctx /* may be NULL */, const zk_comm_ops* ops, int rank, int world, zk_comm** out);
+/* A communicator outlives the zk_mgpu provers created over it.  Destroying it while a prover still holds it is safe all the same:
+ * the call then only marks it, and the last zk_mgpu_destroy frees it. */
 void zk_comm_destroy(zk_comm* comm);
 int zk_comm_rank(const zk_comm* comm);
 int zk_comm_world(const zk_comm* comm);
@@ -394,7 +379,9 @@ int zk_comm_rccl_ranks(const zk_comm* comm);
  * milliseconds (default 120000, or ZK_COMM_TIMEOUT_MS at zk_comm_init; 0 = unbounded) the RCCL communicator is aborted and the call
  * returns ZK_ERR_COMM, as does every later one.  The reference's prove (mod.rs:213-217) cannot hang on a peer; neither may this. */
 int zk_comm_set_timeout(zk_comm* comm, long ms);
-/* Gives up on the peers now (ncclCommAbort): callable from another thread while a collective is being waited for. */
+/* Gives up on the peers now (ncclCommAbort): callable from another thread while a collective is being waited for OR enqueued -- an
+ * enqueue that is under way finishes its RCCL calls first (the abort waits for it, 200 ms at most); every later call answers
+ * ZK_ERR_COMM. */
 int zk_comm_abort(zk_comm* comm);
 int zk_comm_barrier(zk_comm* comm);
 int zk_comm_max_f64(zk_comm* comm, double* value);      /* *value = max over the ranks (timing of the slowest rank) */
@@ -454,14 +441,6 @@ int zk_verify(zk_ctx* ctx, const zk_crs* crs, const uint64_t* inputs, size_t n_i
  * Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (9+i)).  Host only; needs no context.  ZK_ERR_RANGE when a coordinate
  * is >= q, a point is off its curve or g2 is outside the order-r subgroup. */
 int zk_pairing(const uint64_t g1[ZK_G1_WORDS], const uint64_t g2[ZK_G2_WORDS], uint64_t out[48]);
-
-/* ------------------------------------------------------------------------------------------
- * Profiling: HIP-event timing of the library's own kernels on the stream they run on.
- * ---------------------------------------------------------------------------------------- */
-int zk_profile_reset(zk_ctx* ctx);
-/* n_names = number of distinct kernels recorded; name(i) / stats(i) enumerate them */
-int zk_profile_count(const zk_ctx* ctx);
-int zk_profile_entry(const zk_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches, double* algo_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
-"""-m "not gpu": the C-ABI library loads and exports every symbol include/zkgpu.h declares, the
-binding covers exactly that set, and the product refuses to run without a GPU (no CPU fallback)."""
+"""-m "not gpu": the C-ABI library loads and exports every symbol include/zkgpu.h (the product ABI) and include/zkgpu_measure.h (the
+measurement / test entry points) declare, the binding covers exactly that set, the product header carries no measurement switch, and
+the product refuses to run without a GPU (no CPU fallback)."""
 import ctypes
 import os
 import re
@@ -9,10 +10,38 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "zkgpu.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("zkgpu.h", "zkgpu_measure.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+MEASUREMENT_KEYS = ("serialize", "ablate", "msm_fold", "msm_run_entries", "msm_run_whole", "msm_run_fill", "msm_small_lanes", "msm_unchain_lanes",
+                    "chain_order", "alt_stream", "tail_stream", "ntt_fuse", "apply_cu_reserve")
+
+
+def test_product_header_exports_no_measurement_switch():
+    """include/zkgpu.h is the product ABI -- no profiling entry point, no test hook, no tuning key, none of the
+    closed experiments (lone_graph, g2_affine); those live in include/zkgpu_measure.h or are gone.  The option table of the product
+    build (csrc/capi.hip outside #ifdef ZK_MEASURE) accepts none of the measurement keys either."""
+    product = open(os.path.join(ROOT, "include", "zkgpu.h")).read()
+    for banned in ("zk_profile_", "zk_lazy29_batch", "lone_graph", "g2_affine") + tuple('"%s"' % k for k in MEASUREMENT_KEYS):
+        assert banned not in product, banned
+    only_measure = set(declared_symbols(("zkgpu_measure.h",))) - set(declared_symbols(("zkgpu.h",)))
+    assert only_measure == {"zk_profile_reset", "zk_profile_count", "zk_profile_entry", "zk_lazy29_batch"}
+    capi = open(os.path.join(ROOT, "zksnark_rs_amd", "csrc", "capi.hip")).read()
+    slot = capi[capi.index("static long* option_slot"):capi.index("int zk_set_option")]
+    product_part = slot[:slot.index("#ifdef ZK_MEASURE")]
+    measure_part = slot[slot.index("#ifdef ZK_MEASURE"):]
+    for k in MEASUREMENT_KEYS:
+        assert '"%s"' % k not in product_part, k
+        if k != "apply_cu_reserve":
+            assert '"%s"' % k in measure_part, k
+    for gone in ("lone_graph", "g2_affine"):
+        assert gone not in capi
 
 
 def test_header_symbols_are_exported_and_bound():

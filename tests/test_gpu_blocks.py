@@ -87,35 +87,6 @@ def test_point_mul_and_add(ctx, orc):
     assert np.array_equal(ctx.g2_add_batch(p2, q2), orc.g2_add_batch(p2, q2))
 
 
-@pytest.mark.parametrize("n", [1, 5, 700, 5000])
-def test_g2_pair_sums_affine(ctx, orc, n):
-    """zk_g2_add_batch through the affine pair sums with one shared inversion per workgroup (option g2_affine, g2_affine.cuh):
-    the same points as the mixed-addition kernel and as the oracle, with P + P, P + (-P), P + inf, inf + P and inf + inf spread over
-    the lanes (every exceptional pair takes the denominator 1 or 2y inside the shared product)."""
-    rng = SplitMix64(77 + n)
-    uniq = min(n, 40)
-    bp, bq = g2_points(orc, rng, uniq), g2_points(orc, rng, uniq)
-    idx = np.arange(n) % uniq
-    p, q = bp[idx].copy(), bq[idx].copy()
-    neg = ints_to_limbs([R_MODULUS - 1])
-    for j in range(n):
-        kind = (j * 7 + j // 3) % 11
-        if kind == 0: q[j] = p[j]
-        elif kind == 1: q[j] = orc.g2_mul_batch(p[j:j + 1], neg)[0]
-        elif kind == 2: q[j] = 0
-        elif kind == 3: p[j] = 0
-        elif kind == 4: p[j] = 0; q[j] = 0
-    want = orc.g2_add_batch(p[:uniq * 11], q[:uniq * 11]) if n > uniq * 11 else orc.g2_add_batch(p, q)
-    plain = ctx.g2_add_batch(p, q)
-    ctx.set_option("g2_affine", 1)
-    try:
-        got = ctx.g2_add_batch(p, q)
-    finally:
-        ctx.set_option("g2_affine", 0)
-    assert np.array_equal(got, plain)
-    assert np.array_equal(got[:len(want)], want)
-
-
 def test_exp_encrypted(ctx, orc):
     """fr.rs:240-246: a.exp_encrypted_g1(b.encrypt_g1()) == (a*b).encrypt_g1()"""
     rng = SplitMix64(6)
@@ -347,32 +318,6 @@ def test_msm_linearity_large(ctx, orc):
     sa, sb = ctx.msm_g1(p1, a), ctx.msm_g1(p1, b)
     sab = ctx.msm_g1(p1, ctx.fr_batch("add", a, b))
     assert np.array_equal(ctx.g1_add_batch(sa.reshape(1, 8), sb.reshape(1, 8))[0], sab)
-
-
-@pytest.mark.parametrize("distinct", [2048, 1])
-def test_msm_g2_affine_rounds(ctx, orc, distinct):
-    """zk_msm_g2 with the first halvings of every bucket done as affine pair sums (option g2_affine = rounds, g2_affine.cuh; the
-    proofs' B product): 2^17 points at a 17-bit window -- 2^16 buckets of ~30 entries, each padded to a multiple of 2^rounds -- give
-    the same point as the plain accumulation for 1..4 rounds.  distinct = 1: every table row repeats ONE point, so buckets are full
-    of P + P and P + (-P) pairs; scalars mix full-size, small and zero values."""
-    rng = SplitMix64(79)
-    n = 1 << 17
-    base = g2_points(orc, rng, distinct)
-    p2 = np.tile(base, (n // distinct, 1))
-    gen = np.random.default_rng(5)
-    k = gen.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); k[:, 3] &= np.uint64((1 << 60) - 1)
-    k[::7, 1:] = 0
-    k[::11] = 0
-    want = ctx.msm_g2(p2, k, 17)
-    try:
-        for rounds in (1, 2, 3, 4):
-            ctx.set_option("g2_affine", rounds)
-            assert np.array_equal(ctx.msm_g2(p2, k, 17), want), rounds
-    finally:
-        ctx.set_option("g2_affine", 0)
-    # the plain form against the oracle through linearity: MSM(P, k) + MSM(P, k) == MSM(P, 2k)
-    k2 = ctx.fr_batch("add", k, k)
-    assert np.array_equal(ctx.g2_add_batch(want.reshape(1, 16), want.reshape(1, 16))[0], ctx.msm_g2(p2, k2, 17))
 
 
 # ---- the first stage of prove on its own: u_sum = sum_i qap.u[i] * weights[i] ------------------------------------------

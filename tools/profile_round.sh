@@ -15,7 +15,6 @@ python bench.py --steps 100 --warmup 5 > $OUT/bench_100steps.json 2>> $OUT/bench
   python bench.py --log-n 16 --steps 320 --warmup 64 --batch 32 --no-cpu-baseline
   python bench.py --log-n 16 --latency --steps 40 --warmup 8
   python bench.py --log-n 4 --latency --steps 40 --warmup 8
-  python bench.py --log-n 16 --latency --steps 40 --warmup 8 --lone-graph
   python bench.py --log-n 4 --roots integers --steps 640 --warmup 64 --batch 32
   python bench.py --roots integers --steps 60 --warmup 5
   python bench.py --roots arbitrary --steps 30 --warmup 4

@@ -136,8 +136,6 @@ static long* option_slot(zk_ctx* ctx, const char* key) {
     if (!std::strcmp(key, "msm_quad_buckets")) return &ctx->opt_quad_buckets;
     if (!std::strcmp(key, "interp_large_log")) return &ctx->opt_interp_large_log;
     if (!std::strcmp(key, "comm_cu_reserve")) return &ctx->opt_comm_cu_reserve;
-    if (!std::strcmp(key, "lone_graph")) return &ctx->opt_lone_graph;
-    if (!std::strcmp(key, "g2_affine")) return &ctx->opt_g2_affine;
     if (!std::strcmp(key, "basis_tree_min")) return &ctx->opt_basis_tree_min;
     if (!std::strcmp(key, "merge_lh")) return &ctx->opt_merge_lh;
 #ifdef ZK_MEASURE

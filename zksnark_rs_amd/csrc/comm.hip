@@ -43,6 +43,14 @@ struct zk_comm {
     int* d_flag = nullptr;          // barrier / max-reduce scratch (device)
     long timeout_ms = 120000;       // every host wait for a collective is bounded by this (zk_comm_set_timeout; ZK_COMM_TIMEOUT_MS)
     std::atomic<bool> aborted{false};   // a wait timed out or the caller gave up: the RCCL communicator is gone, every later call is refused
+    // Enqueue paths hold this while they make their RCCL calls with the handle they loaded; zk_comm_abort takes it (for at most 200 ms:
+    // an enqueue that blocks inside RCCL must not keep the abort away for ever) before it exchanges the handle out, so a communicator is
+    // not aborted under a thread that is between its load and its last ncclSend / ncclRecv.
+    std::timed_mutex enqueue_mu;
+    // zk_mgpu provers that hold this communicator: zk_comm_destroy while users > 0 only marks it, the last zk_mgpu_destroy frees it --
+    // either order of the two destroy calls is safe (the header documents "the communicator outlives its provers" anyway)
+    std::atomic<int> users{0};
+    std::atomic<bool> destroy_pending{false};
 };
 
 struct zk_mgpu {
@@ -61,6 +69,7 @@ struct zk_mgpu {
     size_t first = 0;               // round number of rounds.front()
     std::string last_error;
     bool failed = false;            // a stage or a collective failed: the pipeline state is unknown, every later call is refused
+    bool counted = false;           // this prover is counted in comm->users
     bool cu_reserved = false;       // zk_mgpu_create masked the inner-product streams (comm_cu_reserve): undone by zk_mgpu_destroy
     // stream-ordered hand-overs (the library's own GPU stages over the library's own transport, see inner_products): events of round
     // k at index k % 3 -- scalars written, scalars exchanged, inner products done -- and the pinned landing places of the range flag
@@ -88,6 +97,7 @@ static void comm_all_to_all(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_to_all(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_to_all failed");
         return;
     }
+    std::lock_guard<std::timed_mutex> enq(c->enqueue_mu);
     ncclComm_t nc = c->nccl.load();
     if (!nc) {   // one rank, no communicator (loopback: the copies a `world`-rank exchange would receive, same sizes)
         ZK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank * (c->loopback ? (size_t)c->world : 1), hipMemcpyDeviceToDevice, c->stream));
@@ -108,6 +118,7 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
         ZK_REQUIRE(c->ops.all_gather(c->ops.user, d_send, d_recv, bytes_per_rank) == 0, ZK_ERR_COMM, "custom all_gather failed");
         return;
     }
+    std::lock_guard<std::timed_mutex> enq(c->enqueue_mu);
     ncclComm_t nc = c->nccl.load();
     if (!nc) {
         for (int g = 0; g < (c->loopback ? c->world : 1); ++g)
@@ -119,7 +130,8 @@ static void comm_all_gather(zk_comm* c, const void* d_send, void* d_recv, size_t
 // Tears the RCCL communicator down without waiting for its peers (ncclCommAbort makes the collectives' kernels exit), so that a
 // rank whose peer died or never arrived gets its stream back instead of hanging in a device synchronisation for ever.
 static void comm_abort(zk_comm* c) {
-    c->aborted.store(true);
+    c->aborted.store(true);      // enqueue paths that start from now on are refused (comm_live)
+    std::unique_lock<std::timed_mutex> enq(c->enqueue_mu, std::chrono::milliseconds(200));   // one that is under way finishes its calls first (bounded)
     ncclComm_t nc = c->nccl.exchange(nullptr);   // a time-out's abort racing the caller's: one of them gets the handle
     if (nc) (void)ncclCommAbort(nc);
 }
@@ -358,6 +370,7 @@ int zk_comm_init_custom(zk_ctx* ctx, const zk_comm_ops* ops, int rank, int world
 
 void zk_comm_destroy(zk_comm* c) {
     if (!c) return;
+    if (c->users.load() > 0) { c->destroy_pending.store(true); return; }   // a prover still holds it: freed by the last zk_mgpu_destroy
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
     if (ncclComm_t nc = c->nccl.exchange(nullptr)) (void)ncclCommDestroy(nc);
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -396,7 +409,10 @@ int zk_comm_barrier(zk_comm* c) {
     if (c->custom) return c->ops.barrier ? c->ops.barrier(c->ops.user) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
         comm_live(c);
-        if (ncclComm_t nc = c->nccl.load()) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, nc, c->stream));
+        {
+            std::lock_guard<std::timed_mutex> enq(c->enqueue_mu);
+            if (ncclComm_t nc = c->nccl.load()) ZK_NCCL(ncclAllReduce(c->d_flag, c->d_flag + 1, 1, ncclInt32, ncclSum, nc, c->stream));
+        }
         comm_sync(c);
     });
 }
@@ -406,12 +422,15 @@ int zk_comm_max_f64(zk_comm* c, double* value) {
     if (c->custom) return c->ops.max_f64 ? c->ops.max_f64(c->ops.user, value) : ZK_ERR_UNSUPPORTED;
     return comm_guard(c, nullptr, [&] {
         comm_live(c);
-        ncclComm_t nc = c->nccl.load();
-        if (!nc) return;
-        double* d = reinterpret_cast<double*>(c->d_flag) + 2;
-        ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, nc, c->stream));
-        ZK_HIP(hipMemcpyAsync(value, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        {
+            std::lock_guard<std::timed_mutex> enq(c->enqueue_mu);
+            ncclComm_t nc = c->nccl.load();
+            if (!nc) return;
+            double* d = reinterpret_cast<double*>(c->d_flag) + 2;
+            ZK_HIP(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            ZK_NCCL(ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, nc, c->stream));
+            ZK_HIP(hipMemcpyAsync(value, d + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
         comm_sync(c);
     });
 }
@@ -450,6 +469,7 @@ static int mgpu_create(zk_comm* c, const zk_mgpu_backend* be, GpuBackend* gpu, z
     zk_mgpu* g = new (std::nothrow) zk_mgpu();
     if (!g) { delete gpu; return ZK_ERR_HIP; }
     g->comm = c; g->be = *be; g->gpu = gpu;
+    c->users.fetch_add(1); g->counted = true;
     int rc = comm_guard(c, &g->last_error, [&] {
         be_check(g, g->be.elems(g->be.user, c->world, g->elems), "elems");
         for (int set = 0; set < 2; ++set) {
@@ -536,7 +556,9 @@ void zk_mgpu_destroy(zk_mgpu* g) {
         if (g->part_recv[set]) g->be.free(g->be.user, g->part_recv[set]);
     }
     delete g->gpu;
+    zk_comm* const held = g->counted ? g->comm : nullptr;
     delete g;
+    if (held && held->users.fetch_sub(1) == 1 && held->destroy_pending.load()) zk_comm_destroy(held);
 }
 const char* zk_mgpu_last_error(const zk_mgpu* g) { return g ? g->last_error.c_str() : "null prover"; }
 

@@ -8,9 +8,11 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/zkgpu.h"
+#include "../../include/zkgpu_measure.h"   // the measurement / test entry points the library also exports (not part of the product ABI)
 #include "ec.cuh"
 
 namespace zk {
@@ -36,14 +38,21 @@ struct StatusError {
     } while (0)
 
 // RAII device allocation
-// Counts every device (re)allocation and release made through DevBuf, process wide.  A captured graph (prove.hip, option lone_graph)
-// bakes raw device pointers in: it is replayed only while this counter still has the value it had when the capture ended, so a slot,
-// workspace or table buffer that was regrown or freed in between -- or a new CRS / QAP at a recycled address -- can never be read
-// through a stale graph.
-inline std::atomic<uint64_t>& devbuf_generation() {
-    static std::atomic<uint64_t> g{0};
-    return g;
-}
+// hipFuncSetAttribute applies to the device that is current at the call, so "once" means once per DEVICE, not once per process: with a
+// process-wide flag only the first device of a multi-context process got the larger dynamic LDS limit.  Thread-safe.
+struct PerDeviceOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <class Fn>
+    void run(int device, Fn&& fn) {
+        std::lock_guard<std::mutex> g(mu);
+        const uint64_t bit = (uint64_t)1 << (device & 63);
+        if (done & bit) return;
+        fn();
+        done |= bit;
+    }
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -61,14 +70,14 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        if (count) { ZK_HIP(hipMalloc((void**)&p, count * sizeof(T))); devbuf_generation().fetch_add(1, std::memory_order_relaxed); }
+        if (count) ZK_HIP(hipMalloc((void**)&p, count * sizeof(T)));
     }
     // grow-only: keeps the allocation when it is already large enough
     void ensure(size_t count) {
         if (count > n) alloc(count);
     }
     void release() {
-        if (p) { (void)hipFree(p); devbuf_generation().fetch_add(1, std::memory_order_relaxed); }
+        if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
@@ -125,9 +134,6 @@ struct zk_ctx {
     long opt_run_fill = 1;        // products cut into several runs per bucket: runs as long as one round of accumulation lanes allows (fewer merges)
     long opt_run_whole = 128;     // products with at most this many entries per bucket (and enough buckets) keep every bucket in ONE run
     long opt_basis_tree_min = 16384; // integer-roots QAP over a powers-only CRS: from this many gates on the Lagrange-basis points come from the transposed interpolation tree (gbasis.hip), below from the n^2 inner products (basis.hip)
-    long opt_g2_affine = 0;       // G2 inner products: rounds of pairwise AFFINE sums with shared inversions in front of the XYZZ accumulation (g2_affine.cuh); zk_g2_add_batch takes the same kernel
-    long opt_lone_graph = 0;      // zk_prove / zk_prove_dev: a lone proof of a (CRS, QAP, witness length) seen before replays one captured hipGraph (prove.hip prove_graph)
-    bool graph_capture = false;   // prove_submit is being captured: per-proof factors come from the slot's parameter block, nothing outside the capture is waited for
     long opt_interp_large_log = 20; // interp.hip: trees of at least 2^this elements per level take the form that halves the upward transforms
     long opt_quad_buckets = 65536; // inner products of at most this many buckets run their reduction tail with four lanes per addition (msm_quad.hpp)
     std::map<std::string, zk::ProfEntry> prof;

@@ -4,7 +4,7 @@
 // issues two global_load_dwordx4 per operand and consecutive lanes touch consecutive memory.
 #include "common.hpp"
 #include "kernels.hpp"
-#include "g2_affine.cuh"
+#include "fr_tile.cuh"
 
 namespace zk {
 
@@ -208,23 +208,6 @@ void point_add_batch(zk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t
     ZK_HIP(hipMemcpyAsync(da.p, a, n * sizeof(Aff<F>), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemcpyAsync(db.p, b, n * sizeof(Aff<F>), hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
-    if constexpr (sizeof(F) > sizeof(Fq)) {
-        if (ctx->opt_g2_affine > 0) {   // the pair sums of the G2 inner product (g2_affine.cuh), stand-alone
-            ZK_REQUIRE(n < ((size_t)1 << 31), ZK_ERR_SIZE, "zk_g2_add_batch: too many pairs");
-            DevBuf<int32_t> prefix(aff_prefix_words(n, ctx->cu_count));
-            hipLaunchKernelGGL(k_points_from_canonical<F>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, da.p, n, flag.p);
-            hipLaunchKernelGGL(k_points_from_canonical<F>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, db.p, n, flag.p);
-            hipLaunchKernelGGL(k_g2_pair_sums<PairArrays>, dim3(aff_grid(n, ctx->cu_count)), dim3(AFF_THREADS), 0, ctx->stream, PairArrays{da.p, db.p}, (uint32_t)n, nullptr, 0, prefix.p, dout.p);
-            hipLaunchKernelGGL(k_points_to_canonical<F>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, dout.p, n);
-            ZK_HIP(hipGetLastError());
-            int hflag = 0;
-            ZK_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            ZK_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(Aff<F>), hipMemcpyDeviceToHost, ctx->stream));
-            ZK_HIP(hipStreamSynchronize(ctx->stream));
-            ZK_REQUIRE(!hflag, ZK_ERR_RANGE, "coordinate >= modulus");
-            return;
-        }
-    }
     hipLaunchKernelGGL(k_point_add<F>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, da.p, db.p, dout.p, n, flag.p);
     ZK_HIP(hipGetLastError());
     int hflag = 0;

@@ -79,10 +79,6 @@ struct MsmWorkspace {
     DevBuf<uint64_t> records;
     DevBuf<uint32_t> runs_cnt, wg_extra, xbase, runs;   // runs of the accumulation (msm_impl.hpp): class counts | cursors | info, ..., 3 words per run
     DevBuf<uint8_t> bucket_sums, fold, seg_sums;
-    DevBuf<uint32_t> ptotal, pbin_start, ident;   // G2 products with affine pair sums in front (g2_affine.cuh): padded bins, identity entries of the halved list
-    DevBuf<int32_t> aff_prefix;
-    DevBuf<uint8_t> aff_list;
-    size_t ident_filled = 0;
     uint64_t sorted_for = 0;             // signature of the sorted list held (option ablate, ZK_MEASURE builds)
 };
 int msm_auto_window(size_t n);

@@ -33,7 +33,6 @@
 #include "kernels.hpp"
 #include "lazy29.cuh"
 #include "quad29.cuh"
-#include "g2_affine.cuh"
 
 namespace zk {
 
@@ -176,46 +175,14 @@ __device__ __forceinline__ void for_each_digit_auto(const Fr& k, int c, int wind
 #include "msm_sort.hpp"   // the counting sort and the runs (shared, field-independent kernels)
 
 // ---- bucket accumulation: one run per lane -------------------------------------------------------
-// waves per SIMD the accumulate kernel is compiled for.  G1 (XYZZ accumulator, 145 VGPRs) fits 3
-// waves; the G2 body (XYZZ over Fq2: 72 accumulator limbs + the affine point before any temporary)
-// fits 2 with 16 dwords of scratch.
-#ifndef ZK_ACC_G1_LDS
-#define ZK_ACC_G1_LDS 0
-#endif
+// Waves per SIMD the accumulate kernel is compiled for.  G1 (the asm bodies of madd_asm.inc: 141 VGPRs) runs three -- a fourth
+// (128 VGPRs, -DZK_ACC_G1_WAVES=4) buys no rate on a chip that is bound by its package power and takes the registers the other
+// kernels' waves start in (profiles/r6_experiments.txt item 1); G2 (XYZZ over Fq2: 72 accumulator limbs) runs two at 256 VGPRs.
 #ifndef ZK_ACC_G1_WAVES
 #define ZK_ACC_G1_WAVES 3
 #endif
 template <class F> struct AccWaves { static constexpr int value = ZK_ACC_G1_WAVES; };
 template <> struct AccWaves<Fq2> { static constexpr int value = 2; };
-
-// Shape of the accumulation loop per field.  The loop body is ~6 k (G1) / ~19 k (G2) instructions whose register allocation and
-// schedule the compiler finds afresh for every source form, and semantically equivalent forms differ by up to 10 % in EXECUTED
-// instructions (SQ_INSTS_VALU per addition, tools/valu_budget.py; profiles/r3_acc_shapes.txt):
-//   NZ      the accumulator is started from the run's first point and the loop body has no test for infinity
-//   DEAD    a block that parks and clears the accumulator at a position the compiler cannot know (run.end, which equals the loop's own
-//           bound: never reached) -- what is left of the bucket-boundary bookkeeping of the equal-slices form, whose presence makes
-//           the allocator keep the accumulator in place instead of copying it between the unrolled iterations
-//   UNROLL  iterations per trip
-#ifndef ZK_G1_SHAPE
-#define ZK_G1_SHAPE 0, 1, 2
-#endif
-#ifndef ZK_G2_SHAPE
-#define ZK_G2_SHAPE 1, 0, 1
-#endif
-// The sorted entries four at a time (one aligned 16-byte block every fourth trip) instead of one dword per trip.  A lane comes back
-// to the same line of the list 32 trips later, by which time the gathers have pushed it out of L2, so read dword by dword an entry
-// costs a sector of its own.  Build-time switches for A/B, both OFF: G1 (141 registers, +8 instructions per addition) moved 0.48 GB
-// per proof less (15.69 -> 15.21 GB) at 106.63 against 107.79 proofs/s, same box, 4 x 20 steps -- level at best on a loop that is
-// bound by instruction issue; G2 (at 256 registers) starts to spill with the four extra registers.  profiles/r5_experiments.txt item 16.
-#ifndef ZK_ACC_ENTRY_BLOCKS
-#define ZK_ACC_ENTRY_BLOCKS 0
-#endif
-#ifndef ZK_ACC_ENTRY_BLOCKS_G2
-#define ZK_ACC_ENTRY_BLOCKS_G2 0
-#endif
-template <bool NZ_, bool DEAD_, int UNROLL_> struct AccShapeOf { static constexpr bool NZ = NZ_, DEAD = DEAD_; static constexpr int UNROLL = UNROLL_; };
-template <class F> struct AccShape : AccShapeOf<ZK_G1_SHAPE> {};
-template <> struct AccShape<Fq2> : AccShapeOf<ZK_G2_SHAPE> {};
 
 // register image of an accumulator as it is parked in HBM between accumulate, merge and the folds
 template <class F>
@@ -223,81 +190,12 @@ struct alignas(16) AccSlot {
     typename AccOf<F>::type a;
 };
 
-// G2: ZZ and ZZZ of the accumulator parked in LDS between their uses (option at build time, ZK_G2_PARK).  The Fq2 kernel holds 72
-// accumulator limbs, the prefetched point and a multiplier that needs 63 registers at once: at 256 registers it spills ~47 of them to
-// scratch (160 B per lane, 1.2 GB of scratch writes per launch).  ZZ / ZZZ are read twice and written once per
-// addition and idle in between: 2 x 20 dwords per lane as five 16-byte rows, lane-contiguous (conflict-free ds_read_b128).
-#ifndef ZK_G2_PARK
-#define ZK_G2_PARK 0
-#endif
-template <class F> struct ParkAcc { static constexpr bool on = false; };
-template <> struct ParkAcc<Fq2> { static constexpr bool on = ZK_G2_PARK != 0; };
-struct ParkRows { int4 r[2][5][256]; };   // [ZZ | ZZZ][row][lane]
-__device__ __forceinline__ void park_put(ParkRows* pk, int which, const Fp2R<FqParams>& v) {
-    int4* row = &pk->r[which][0][threadIdx.x];
-    row[0 * 256] = make_int4(v.c0.v[0], v.c0.v[1], v.c0.v[2], v.c0.v[3]);
-    row[1 * 256] = make_int4(v.c0.v[4], v.c0.v[5], v.c0.v[6], v.c0.v[7]);
-    row[2 * 256] = make_int4(v.c0.v[8], v.c1.v[0], v.c1.v[1], v.c1.v[2]);
-    row[3 * 256] = make_int4(v.c1.v[3], v.c1.v[4], v.c1.v[5], v.c1.v[6]);
-    row[4 * 256] = make_int4(v.c1.v[7], v.c1.v[8], 0, 0);
-}
-__device__ __forceinline__ Fp2R<FqParams> park_get(const ParkRows* pk, int which) {
-    asm volatile("" ::: "memory");   // a fresh read every time: the point is NOT to keep the value in registers
-    const int4* row = &pk->r[which][0][threadIdx.x];
-    const int4 a = row[0 * 256], b = row[1 * 256], c = row[2 * 256], d = row[3 * 256], e = row[4 * 256];
-    Fp2R<FqParams> v;
-    v.c0.v[0] = a.x; v.c0.v[1] = a.y; v.c0.v[2] = a.z; v.c0.v[3] = a.w; v.c0.v[4] = b.x; v.c0.v[5] = b.y; v.c0.v[6] = b.z; v.c0.v[7] = b.w;
-    v.c0.v[8] = c.x; v.c1.v[0] = c.y; v.c1.v[1] = c.z; v.c1.v[2] = c.w; v.c1.v[3] = d.x; v.c1.v[4] = d.y; v.c1.v[5] = d.z; v.c1.v[6] = d.w;
-    v.c1.v[7] = e.x; v.c1.v[8] = e.y;
-    return v;
-}
-// madd_xyzz_nz (lazy29.cuh) with ZZ / ZZZ in LDS: same formulas, same bounds, same return codes
-__device__ __forceinline__ int madd_xyzz_nz_parked(Fp2R<FqParams>& X, Fp2R<FqParams>& Y, ParkRows* pk, const Fp2R<FqParams>& qx, const Fp2R<FqParams>& qy) {
-    typedef Fp2R<FqParams> L;
-    L U2 = qx * park_get(pk, 0);
-    L S2 = qy * park_get(pk, 1);
-    L P = U2 - X;
-    L R = S2 - Y;
-    L PP = P.sqr();
-    if (PP.is_zero_mod_p()) return R.sqr().is_zero_mod_p() ? 1 : 2;
-    L PPP = P * PP;
-    L Q = X * PP;
-    L X3 = (R.sqr() - PPP - (Q + Q)).norm();
-    Y = xyzz_ydiff(R, Q - X3, Y, PPP);
-    X = X3;
-    park_put(pk, 0, park_get(pk, 0) * PP);
-    park_put(pk, 1, park_get(pk, 1) * PPP);
-    return 0;
-}
-
-// The next point's gather straight into LDS (global_load_lds_dwordx4: no destination registers), build-time options ZK_ACC_PF_G1 /
-// ZK_ACC_PF_G2.  The shipped loops hold the prefetched point in 16 (G1) / 32 (G2) registers across a whole addition -- a seventh of
-// the G1 kernel's 137, and the reason the G2 kernel spills.  Here lane t's point lands in rows [j][t] of a per-workgroup stage
-// (16 B per row and lane: what the instruction writes for a wave is 64 consecutive 16-byte slots from the address in M0), is read back
-// at the top of the next trip and converted at once.  One loop shape for both fields: the accumulator's emptiness is tested per trip.
-#ifndef ZK_ACC_PF_G1
-#define ZK_ACC_PF_G1 0
-#endif
-#ifndef ZK_ACC_PF_G2
-#define ZK_ACC_PF_G2 1
-#endif
-// the second point of a run as an affine + affine addition (madd_xyzz_unit, lazy29.cuh); build-time switch for A/B
-#ifndef ZK_ACC_UNIT
-#define ZK_ACC_UNIT 1
-#endif
-// The G1 loop over the whole-addition asm bodies of madd_asm.inc (tools/gen_madd_asm.py): multipliers in place, X alternating between
-// two register sets, Y alternating in sign -- no copy of the accumulator and no negation on the hot path.
-#ifndef ZK_ACC_BODY_G1
-#define ZK_ACC_BODY_G1 1
-#endif
-template <class F> struct AccAsmBody { static constexpr bool on = false; };
-#if ZK_MONT_ASM_ON
-template <> struct AccAsmBody<Fq> { static constexpr bool on = ZK_ACC_BODY_G1 != 0 && ZK_ACC_PF_G1 == 0; };
-#endif
-template <class F> struct AccPrefetchLds { static constexpr bool on = ZK_ACC_PF_G1 != 0; };
-template <> struct AccPrefetchLds<Fq2> { static constexpr bool on = ZK_ACC_PF_G2 != 0; };
-
 // Lane t adds the entries of run t (k_msm_runs_emit) and stores the image of their sum in the run's slot.  info[0] = number of runs.
+// ONE loop per field (the forms rounds 3-5 tried are on record in tools/experiments/msm_accumulate_forms_r5.hpp.txt):
+//   G1  trips 1 and 2 through the generic step (the run's first point starts the accumulator, the second joins it as an affine + affine
+//       addition, madd_xyzz_second); then the FAST loop over the generated whole-addition bodies of madd_asm.inc, two additions per trip.
+//   G2  the next point's gather goes straight into LDS (global_load_lds_dwordx4: no destination registers -- 32 registers of a kernel
+//       that sits at the 256-register limit), trips 1 and 2 peeled the same way.
 template <class F>
 __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(const Aff<F>* __restrict__ table, const uint32_t* __restrict__ sorted,
                                                        const MsmRun* __restrict__ runs, const uint32_t* __restrict__ info, AccSlot<F>* __restrict__ img) {
@@ -306,27 +204,18 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
     const MsmRun run = runs[tid];
     const uint32_t k1 = run.k0 + run.len;
     typedef typename LazyOf<F>::type L;
-    typedef AccShape<F> Shape;
     typename AccOf<F>::type acc;
     acc_clear(acc);
-    __shared__ __attribute__((aligned(16))) uint8_t park_mem[ParkAcc<F>::on ? sizeof(ParkRows) : 16];
-    [[maybe_unused]] ParkRows* const pk = reinterpret_cast<ParkRows*>(park_mem);
-    // software pipeline: the next point's gather (a random line of a multi-GiB table) is in flight
-    // while the current addition executes
     uint32_t k = run.k0;
     uint32_t e = sorted[k];
     uint32_t e_next = k + 1 < k1 ? sorted[k + 1] : 0;
-    Aff<F> p = table[e >> 1];
-    uint32_t bend = run.end;      // == k1, but loaded: the compiler cannot fold the (dead) block below away (see AccShape)
-    if constexpr (AccPrefetchLds<F>::on) {
-        (void)p; (void)bend;
+    if constexpr (sizeof(F) > sizeof(Fq)) {
+        // ---- G2: the software pipeline runs through LDS.  Lane t's point lands in rows [j][t] of a per-workgroup stage (16 B per row
+        // and lane: what the instruction writes for a wave is 64 consecutive 16-byte slots from the address in M0), is read back at the
+        // top of the next trip and converted at once.
         constexpr int ROWS = (int)(sizeof(Aff<F>) / 16);
         __shared__ int4 stage[ROWS][256];
         int4* const wave_rows = &stage[0][threadIdx.x & ~63u];
-        [[maybe_unused]] uint4 ebp = make_uint4(0, 0, 0, 0);   // the block of four sorted entries the next one comes from (ZK_ACC_ENTRY_BLOCKS)
-        if constexpr (ZK_ACC_ENTRY_BLOCKS_G2 != 0) {
-            if (k + 2 < k1) ebp = *reinterpret_cast<const uint4*>(sorted + ((k + 2) & ~3u));
-        }
         auto issue = [&](uint32_t entry) {
             const int4* src = reinterpret_cast<const int4*>(table + (entry >> 1));
 #pragma unroll
@@ -345,13 +234,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             const uint32_t kn = k + 1;
             if (kn < k1) issue(e_next);
             e = e_next;
-            if constexpr (ZK_ACC_ENTRY_BLOCKS_G2 != 0) {
-                const uint32_t i = kn + 1, j = i & 3u;
-                if (i < k1 && j == 0) ebp = *reinterpret_cast<const uint4*>(sorted + i);
-                e_next = i < k1 ? (j == 0 ? ebp.x : j == 1 ? ebp.y : j == 2 ? ebp.z : ebp.w) : 0;
-            } else {
-                e_next = kn + 1 < k1 ? sorted[kn + 1] : 0;
-            }
+            e_next = kn + 1 < k1 ? sorted[kn + 1] : 0;
             k = kn;
             return u.pt;
         };
@@ -360,7 +243,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         // Trips 1 and 2 peeled: the run's first point starts the accumulator, the second joins it as an affine + affine addition
         // (madd_xyzz_second: 6 of 10 multiplications).  A padding entry in front falls through to the loop.  (Its own scope and its
         // own temporaries: written with shared ones, the hot loop below went back to spilling.)
-        if (ZK_ACC_UNIT != 0) {
+        {
             uint32_t ce;
             const Aff<F> p1 = fetch(ce);
             if (!p1.is_inf()) {
@@ -384,7 +267,7 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         while (k < k1) {
             uint32_t ce;
             const Aff<F> pt = fetch(ce);
-            if (pt.is_inf()) continue;                      // padding entries of a table
+            if (pt.is_inf()) continue;                      // points at infinity: unused entries of a table
             L qx = L::load(pt.x), qy = L::load(pt.y);
             if (ce & 1) qy = qy.neg();
             if (acc.inf) { start(qx, qy); continue; }       // first finite point of the run, or the one behind a P + (-P)
@@ -392,13 +275,9 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
             else if (st == 2) acc_clear(acc);
         }
-    } else if constexpr (AccAsmBody<F>::on) {
-        // ---- G1: whole-addition asm bodies (madd_asm.inc) -----------------------------------------------------------------
-        // Trips 1 and 2 through the generic step (the run's first point starts the accumulator, the second joins it as an affine +
-        // affine addition); then the FAST loop, two additions per trip: the even body takes X from acc.X and leaves X3 in xb and -Y3
-        // in acc.Y, the odd body takes both back.  Anything unusual -- a table entry at infinity, a point with the accumulator's x
-        // (the sum is 2 P or infinity and is rebuilt from the affine point: the body has overwritten the accumulator), an empty
-        // accumulator -- makes the LANE leave the fast loop (kf = k) in the canonical state; the generic loop behind it finishes its run.
+    } else {
+        // ---- G1.  The generic step: entry k's point is in registers, the next one's gather is issued before the addition.
+        Aff<F> p = table[e >> 1];
         bool fresh = false;
         auto step = [&](auto second) {
             const uint32_t kn = k + 1;
@@ -409,14 +288,14 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
                 if (e & 1) qy = qy.neg();
                 bool done = false;
                 if constexpr (decltype(second)::value) {
-                    if (fresh && !acc.inf) {
+                    if (fresh && !acc.inf) {          // the accumulator still is the run's first point: affine + affine
                         const int st = madd_xyzz_second(acc, qx, qy);
                         if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));
-                        else if (st == 2) acc.inf = true;
+                        else if (st == 2) acc.inf = true;   // P + (-P): the sum is infinity (the coordinates stay, as madd_xyzz leaves them)
                         done = true;
                     }
                 }
-                if (!done && !acc_madd(acc, qx, qy)) acc_load(acc, jac_dbl(acc_store(acc)));
+                if (!done && !acc_madd(acc, qx, qy)) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket (rare)
             }
             p = p_next; e = e_next; e_next = e_next2; k = kn;
         };
@@ -425,6 +304,13 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
             fresh = !acc.inf;
             if (k < k1) step(std::true_type{});
         }
+#if ZK_MONT_ASM_ON
+        // The FAST loop (madd_asm.inc, tools/gen_madd_asm.py): the whole mixed addition is one asm body whose multipliers work in place.
+        // X changes place once per addition and Y changes sign, so the loop is two halves: the even body takes X from acc.X and leaves X3
+        // in xb and -Y3 in acc.Y, the odd body takes both back -- no copy of the accumulator, no negation (round 5's loop: 36 + 9 moves
+        // per addition).  Anything unusual makes the LANE leave the loop (kf = k) and the generic loop behind it finish the run: a table
+        // entry at infinity, an empty accumulator, and a point with the accumulator's x -- then the accumulator WAS +-the point, the
+        // body has overwritten it, and the sum (2 P or infinity) is rebuilt from the affine point alone.
         uint32_t kf = acc.inf ? k : k1;       // the fast loop's bound for this lane
         L xb = acc.X;
         const uint32_t lane = __lane_id();
@@ -476,7 +362,6 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
         }
         if (odd_state) { acc.X = xb; acc.Y = acc.Y.neg().norm(); }
         if (ev) {
-            // same x: the accumulator was +-the point (the body has overwritten it): the sum is 2 P or infinity, from the affine point alone
             acc_clear(acc);
             if (ev == 2) {
                 const uint32_t ev_e = sorted[ev_k];
@@ -487,123 +372,8 @@ __global__ __launch_bounds__(256, AccWaves<F>::value) void k_msm_accumulate(cons
                 acc_load(acc, jac_dbl(acc_store(acc)));
             }
         }
-        while (k < k1) step(std::false_type{});   // lanes that left the fast loop (rare)
-    } else if constexpr (Shape::NZ) {
-        auto advance = [&] {
-            const uint32_t kn = k + 1;
-            const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
-            const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
-            p = p_next; e = e_next; e_next = e_next2; k = kn;
-        };
-        // The accumulator starts from the run's first finite point, so that the hot loop never tests it for infinity.
-        // P + (-P) empties the accumulator and restarts from the next point.
-        while (k < k1) {
-            while (k < k1 && p.is_inf()) advance();     // points at infinity: padding entries of a table only
-            if (k >= k1) break;
-            acc.X = L::load(p.x);
-            acc.Y = L::load(p.y);
-            if (e & 1) acc.Y = acc.Y.neg().norm();
-            acc.ZZ = acc.ZZZ = L::load(F::one());
-            if constexpr (ParkAcc<F>::on) { park_put(pk, 0, acc.ZZ); park_put(pk, 1, acc.ZZZ); }
-            acc.inf = false;
-            advance();
-            bool emptied = false;
-#pragma unroll Shape::UNROLL
-            while (k < k1) {
-                if constexpr (Shape::DEAD) {
-                    if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
-                }
-                const uint32_t kn = k + 1;
-                const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
-                const uint32_t e_next2 = kn + 1 < k1 ? sorted[kn + 1] : 0;
-                if (!p.is_inf()) {
-                    L qx = L::load(p.x), qy = L::load(p.y);
-                    if (e & 1) qy = qy.neg();
-                    int st;
-                    if constexpr (ParkAcc<F>::on) {
-                        st = madd_xyzz_nz_parked(acc.X, acc.Y, pk, qx, qy);
-                        if (st == 1) {   // same point twice in one bucket: doubling through the generic formulas (rare)
-                            acc.ZZ = park_get(pk, 0); acc.ZZZ = park_get(pk, 1);
-                            acc_load(acc, jac_dbl(acc_store(acc)));
-                            park_put(pk, 0, acc.ZZ); park_put(pk, 1, acc.ZZZ);
-                        }
-                    } else {
-                        st = madd_xyzz_nz(acc, qx, qy);
-                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));   // same point twice in one bucket: doubling through the generic formulas (rare)
-                    }
-                    emptied = st == 2;
-                }
-                p = p_next;
-                e = e_next;
-                e_next = e_next2;
-                k = kn;
-                if (emptied) break;
-            }
-            if (!emptied) break;
-            acc_clear(acc);
-        }
-        if constexpr (ParkAcc<F>::on) {
-            if (!acc.inf) { acc.ZZ = park_get(pk, 0); acc.ZZZ = park_get(pk, 1); }
-        }
-    } else {
-        // one entry: the next point's gather is issued before the addition.  (Written out instead of #pragma unroll: the unroller
-        // declines loops that contain the inline-asm multipliers of mont_asm.inc.)
-        // `second`: the peeled second trip of the run -- when the first one started the accumulator from a finite point (`fresh`), the
-        // sum is an affine + affine addition (madd_xyzz_second)
-        bool fresh = false;
-        // entries [i & ~3, (i & ~3) + 4) of the list, i = the next entry the loop will ask for (the list is padded to whole blocks)
-        [[maybe_unused]] uint4 eb = make_uint4(0, 0, 0, 0);
-        if constexpr (ZK_ACC_ENTRY_BLOCKS != 0) {
-            if (k + 2 < k1) eb = *reinterpret_cast<const uint4*>(sorted + ((k + 2) & ~3u));
-        }
-        auto entry = [&](uint32_t i) -> uint32_t {   // i < k1, one more than at the previous call
-            if constexpr (ZK_ACC_ENTRY_BLOCKS != 0) {
-                const uint32_t j = i & 3u;
-                if (j == 0) eb = *reinterpret_cast<const uint4*>(sorted + i);
-                return j == 0 ? eb.x : j == 1 ? eb.y : j == 2 ? eb.z : eb.w;
-            } else {
-                return sorted[i];
-            }
-        };
-        auto step = [&](auto second) {
-            if constexpr (Shape::DEAD) {
-                if (k == bend) { img[run.dest + 1].a = acc; acc_clear(acc); bend = sorted[k]; }
-            }
-            const uint32_t kn = k + 1;
-            const Aff<F> p_next = kn < k1 ? table[e_next >> 1] : Aff<F>::infinity();
-            const uint32_t e_next2 = kn + 1 < k1 ? entry(kn + 1) : 0;
-            if (!p.is_inf()) {
-                L qx = L::load(p.x), qy = L::load(p.y);
-                if (e & 1) qy = qy.neg();
-                bool done = false;
-                if constexpr (decltype(second)::value) {
-                    if (fresh && !acc.inf) {
-                        const int st = madd_xyzz_second(acc, qx, qy);
-                        if (st == 1) acc_load(acc, jac_dbl(acc_store(acc)));
-                        else if (st == 2) acc.inf = true;   // P + (-P): the sum is infinity (the coordinates stay, as madd_xyzz leaves them)
-                        done = true;
-                    }
-                }
-                if (!done && !acc_madd(acc, qx, qy)) {
-                    // same point twice in one bucket: doubling through the generic formulas (rare)
-                    acc_load(acc, jac_dbl(acc_store(acc)));
-                }
-            }
-            p = p_next;
-            e = e_next;
-            e_next = e_next2;
-            k = kn;
-        };
-        if (ZK_ACC_UNIT != 0 && k < k1) {
-            step(std::false_type{});
-            fresh = !acc.inf;
-            if (k < k1) step(std::true_type{});
-        }
-        while (k < k1) {
-            step(std::false_type{});
-            if constexpr (Shape::UNROLL >= 2) { if (k >= k1) break; step(std::false_type{}); }
-            if constexpr (Shape::UNROLL >= 3) { if (k >= k1) break; step(std::false_type{}); }
-        }
+#endif
+        while (k < k1) step(std::false_type{});   // lanes that left the fast loop (rare); the whole run in a build without the asm bodies
     }
     img[run.dest].a = acc;
 }
@@ -932,20 +702,8 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         T = (uint32_t)std::min<size_t>(RUN_MAX, (entries / lanes + 3) & ~(size_t)3);
     }
     else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
-    // G2 products whose buckets hold 16 .. run_whole entries each (the proofs' B product at 2^20 gates: 25): the first `aff_rounds`
-    // halvings of every bucket are pairwise AFFINE sums with shared inversions (g2_affine.cuh: ~4400 instructions per addition against
-    // ~5800 for the mixed XYZZ addition); the accumulation below then runs over the list that is left.  Every bucket's segment of the
-    // sorted list is padded to a multiple of 2^aff_rounds entries for this (k_msm_bin_offsets).
-    int aff_rounds = 0;
-    if constexpr (sizeof(F) > sizeof(Fq)) {
-        if (ctx->opt_g2_affine > 0 && whole && entries / (size_t)buckets >= 16) aff_rounds = (int)std::min<long>(ctx->opt_g2_affine, 4);
-    }
-    const uint32_t aff_pad = (1u << aff_rounds) - 1;
-    const size_t entries_padded = entries + (size_t)buckets * aff_pad;         // upper bound of the padded list
-    const size_t entries_acc = aff_rounds ? entries_padded >> aff_rounds : entries;   // entries the accumulation walks
-    ZK_REQUIRE(entries_padded < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
     // upper bounds: a bucket of z entries has ceil(z / T) <= 1 + z / T runs, of which all but the first take an extra image slot
-    const size_t max_extra = entries_acc / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries_acc) + max_extra;
+    const size_t max_extra = entries / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries) + max_extra;
     // an accumulation that cannot fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
     if (std::min(max_runs, entries / std::min<size_t>(T, 32) + 1) < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
@@ -966,7 +724,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     ws.bin_start.ensure(bins + 1);
     ws.records.ensure(entries);
     ws.start.ensure(buckets + 1);
-    ws.sorted.ensure(entries_padded + 4);   // + 4: ZK_ACC_ENTRY_BLOCKS builds read the list in aligned blocks of four entries
+    ws.sorted.ensure(entries + 4);
     if (!ws.runs_cnt.p) {   // cleared once; k_msm_runs_scan leaves it cleared
         ws.runs_cnt.alloc(2 * (RUN_MAX + 2) + 2);
         ZK_HIP(hipMemsetAsync(ws.runs_cnt.p, 0, ws.runs_cnt.bytes(), st));
@@ -1027,48 +785,9 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             ws.part_start.ensure((size_t)bins + 1);
             hipLaunchKernelGGL(k_msm_bin_parts, dim3(1), dim3(1024), 0, st, ws.bin_start.p, bins, target, ws.part_start.p);
             hipLaunchKernelGGL(k_msm_bin_hist, dim3(grid2), dim3(SORT2_THREADS), (size_t)subs * 4, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.bin_cnt.p);
-            if (aff_rounds) {
-                ws.ptotal.ensure(bins);
-                ws.pbin_start.ensure(bins + 1);
-                hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p, aff_pad,
-                                   (const uint32_t*)nullptr, ws.ptotal.p);
-                hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), 0, st, ws.ptotal.p, ws.pbin_start.p, bins);
-                ZK_HIP(hipMemsetAsync(ws.sorted.p, 0xff, entries_padded * sizeof(uint32_t), st));   // AFF_PAD behind every bucket's entries
-            }
-            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p, aff_pad,
-                               aff_rounds ? (const uint32_t*)ws.pbin_start.p : (const uint32_t*)nullptr, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_msm_bin_offsets, dim3(bins), dim3(SORT2_THREADS), 0, st, ws.bin_cnt.p, ws.bin_start.p, ws.part_start.p, bins, sub_bits, ws.start.p);
             hipLaunchKernelGGL(k_msm_bin_scatter, dim3(grid2), dim3(BINS_THREADS), (size_t)BIN_STAGE * 6 + (size_t)subs * 12, st, ws.records.p, ws.bin_start.p, ws.part_start.p, bins,
                                sub_bits, ws.bin_cnt.p, ws.sorted.p);
-        }
-        if (aff_rounds) {
-            // start[buckets] = length of the padded list (on the device); round r halves the list of round r - 1
-            if constexpr (sizeof(F) > sizeof(Fq)) {
-                ProfScope ps(ctx, "msm_affine_g2", 720.0 * (double)entries, st);
-                size_t list_elems = 0;
-                for (int r = 1; r <= aff_rounds; ++r) list_elems += entries_padded >> r;
-                ws.aff_list.ensure(list_elems * sizeof(Aff<Fq2>));
-                ws.aff_prefix.ensure(aff_prefix_words(entries_padded >> 1, ctx->cu_count));
-                if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));   // the pair sums are the first part of this product's accumulation
-                acc_wait = nullptr;
-                Aff<Fq2>* out = reinterpret_cast<Aff<Fq2>*>(ws.aff_list.p);
-                const Aff<Fq2>* in = nullptr;
-                for (int r = 1; r <= aff_rounds; ++r) {
-                    const size_t pairs = entries_padded >> r;
-                    const unsigned grid = aff_grid(pairs, ctx->cu_count);
-                    if (r == 1) hipLaunchKernelGGL(k_g2_pair_sums<PairTable>, dim3(grid), dim3(AFF_THREADS), 0, st, PairTable{tab.table.p + point_offset, ws.sorted.p}, (uint32_t)pairs,
-                                                   (const uint32_t*)(ws.start.p + buckets), r, ws.aff_prefix.p, out);
-                    else hipLaunchKernelGGL(k_g2_pair_sums<PairList>, dim3(grid), dim3(AFF_THREADS), 0, st, PairList{in}, (uint32_t)pairs, (const uint32_t*)(ws.start.p + buckets), r,
-                                            ws.aff_prefix.p, out);
-                    in = out;
-                    out += pairs;
-                }
-                if (ws.ident_filled < entries_acc) {
-                    ws.ident.ensure(entries_acc + 4);
-                    hipLaunchKernelGGL(k_msm_identity_entries, dim3(ceil_div(entries_acc, 256)), dim3(256), 0, st, ws.ident.p, (uint32_t)entries_acc);
-                    ws.ident_filled = entries_acc;
-                }
-                hipLaunchKernelGGL(k_msm_shift_starts, dim3(ceil_div((size_t)buckets + 1, 256)), dim3(256), 0, st, ws.start.p, (uint32_t)buckets, aff_rounds);
-            }
         }
         {
             ProfScope ps(ctx, "msm_runs", 8.0 * buckets + 12.0 * max_runs, st);
@@ -1085,17 +804,9 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         if (acc_wait) ZK_HIP(hipStreamWaitEvent(st, acc_wait, 0));
         {
             ProfScope ps(ctx, g2 ? "msm_accumulate_g2" : "msm_accumulate_g1", (32.0 + pt_bytes) * (double)groups * (double)gvalid, st);
-            // dynamic LDS nobody touches: an occupancy cap (ZK_ACC_G1_LDS bytes per workgroup; 160 KiB per compute unit) that is independent of
-            // the register budget the kernel is compiled for
             const Aff<F>* acc_table = tab.table.p + point_offset;
             const uint32_t* acc_sorted = ws.sorted.p;
-            if (aff_rounds) {   // the list the last round of pair sums left is its own table
-                size_t skip = 0;
-                for (int r = 1; r < aff_rounds; ++r) skip += entries_padded >> r;
-                acc_table = reinterpret_cast<const Aff<F>*>(ws.aff_list.p) + skip;
-                acc_sorted = ws.ident.p;
-            }
-            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), g2 ? 0 : ZK_ACC_G1_LDS, st, acc_table, acc_sorted, d_runs, d_info, d_img);
+            hipLaunchKernelGGL(k_msm_accumulate<F>, dim3(ceil_div(max_runs, 256)), dim3(256), 0, st, acc_table, acc_sorted, d_runs, d_info, d_img);
         }
         if (acc_done) ZK_HIP(hipEventRecord(acc_done, st));
     }

@@ -81,8 +81,8 @@ inline void msm_lds_run_g1(zk_ctx* ctx, hipStream_t st, const MsmTable<Fq>& tab,
     parts.ensure((size_t)chunks * tab.windows);
     const size_t lds = (size_t)buckets * (sizeof(XyzzR<FpR<FqParams>>) + 4) + 64 * sizeof(Jac<Fq>);
     if (lds > 65536) {   // c = 10: beyond the default dynamic LDS limit
-        static bool attr = false;
-        if (!attr) { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_lds_g1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+        static PerDeviceOnce once;   // per device, not per process
+        once.run(ctx->device, [] { ZK_HIP(hipFuncSetAttribute((const void*)k_msm_lds_g1, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); });
     }
     {
         ProfScope ps(ctx, "msm_lds_buckets_g1", 96.0 * n_used, st);

@@ -258,13 +258,8 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_hist(const uint64_t* 
 }
 
 // one workgroup per bin: cnt[bin][part][sub] -> first position of that (part, sub); start[bucket]
-// Padded form (the affine pair sums of g2_affine.cuh): every bucket's segment of the sorted list is rounded up to a multiple of
-// pad + 1 entries (a power of two; the slots behind a bucket's entries keep the filler the list was cleared to), so that pairs
-// (2i, 2i + 1) of the list -- and of its halved successors -- never straddle two buckets.  The bins then no longer start where
-// their records do: a first launch with `ptotal` set only writes the bin's padded length, the scan of those lengths is `out_base`.
 __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ part_start,
-                                                                   int bins, int sub_bits, uint32_t* __restrict__ start, uint32_t pad, const uint32_t* __restrict__ out_base,
-                                                                   uint32_t* __restrict__ ptotal) {
+                                                                   int bins, int sub_bits, uint32_t* __restrict__ start) {
     ZK_LATENCY_KERNEL();
     __shared__ uint32_t part_sum[SORT2_THREADS];
     const int subs = 1 << sub_bits;
@@ -285,13 +280,12 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
             s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
             s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
         }
-        const uint32_t np = ~pad;
-        sum = ((s0.x + pad) & np) + ((s0.y + pad) & np) + ((s0.z + pad) & np) + ((s0.w + pad) & np) + ((s1.x + pad) & np) + ((s1.y + pad) & np) + ((s1.z + pad) & np) + ((s1.w + pad) & np);
+        sum = s0.x + s0.y + s0.z + s0.w + s1.x + s1.y + s1.z + s1.w;
     } else {
         for (int b = lo; b < hi; ++b) {
             uint32_t col = 0;
             for (int p = 0; p < parts; ++p) col += rows[(size_t)p * subs + b];
-            sum += (col + pad) & ~pad;
+            sum += col;
         }
     }
     part_sum[threadIdx.x] = sum;
@@ -302,12 +296,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
         part_sum[threadIdx.x] += v;
         __syncthreads();
     }
-    if (ptotal) {
-        if (threadIdx.x == SORT2_THREADS - 1) ptotal[bin] = part_sum[SORT2_THREADS - 1];
-        return;
-    }
-    const uint32_t* const base = out_base ? out_base : bin_start;
-    uint32_t run = base[bin] + (threadIdx.x ? part_sum[threadIdx.x - 1] : 0);
+    uint32_t run = bin_start[bin] + (threadIdx.x ? part_sum[threadIdx.x - 1] : 0);
     if (vec) {
         // per sub-bucket b the positions run over the parts: first pass the column totals (in registers), then the offsets
         uint32_t col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -318,7 +307,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
         }
         uint32_t at[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { at[i] = run; run += (col[i] + pad) & ~pad; }
+        for (int i = 0; i < 8; ++i) { at[i] = run; run += col[i]; }
         uint4* st4 = reinterpret_cast<uint4*>(start + (size_t)bin * subs + lo);
         st4[0] = make_uint4(at[0], at[1], at[2], at[3]);
         st4[1] = make_uint4(at[4], at[5], at[6], at[7]);
@@ -329,20 +318,18 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_msm_bin_offsets(uint32_t* __r
             r4[1] = make_uint4(at[4], at[5], at[6], at[7]);
             at[0] += a.x; at[1] += a.y; at[2] += a.z; at[3] += a.w; at[4] += b.x; at[5] += b.y; at[6] += b.z; at[7] += b.w;
         }
-        if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = base[bins];
+        if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = bin_start[bins];
         return;
     }
     for (int b = lo; b < hi; ++b) {
-        const uint32_t first = run;
         start[(size_t)bin * subs + b] = run;
         for (int p = 0; p < parts; ++p) {
             uint32_t v = rows[(size_t)p * subs + b];
             rows[(size_t)p * subs + b] = run;
             run += v;
         }
-        run = first + ((run - first + pad) & ~pad);
     }
-    if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = base[bins];
+    if (bin == bins - 1 && threadIdx.x == 0) start[(size_t)bins * subs] = bin_start[bins];
 }
 
 // level-2 scatter, staged like level 1: a workgroup takes BIN_STAGE records of its slice at a time, counting-sorts
@@ -395,17 +382,6 @@ __global__ __launch_bounds__(BINS_THREADS) void k_msm_bin_scatter(const uint64_t
         for (int b = threadIdx.x; b < subs; b += BINS_THREADS) pos[b] += cnt[b];
         __syncthreads();
     }
-}
-
-// start[b] >>= shift for b <= count: the bucket boundaries of a padded list after `shift` rounds of pair sums
-__global__ void k_msm_shift_starts(uint32_t* __restrict__ start, uint32_t count, int shift) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= count) start[b] >>= shift;
-}
-// entries of a list that is its own table: (k << 1 | 0)
-__global__ void k_msm_identity_entries(uint32_t* __restrict__ out, uint32_t count) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < count) out[k] = k << 1;
 }
 
 // ---- runs of the accumulation -----------------------------------------------------------------------
@@ -522,9 +498,7 @@ __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
 __global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
-__global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*, uint32_t, const uint32_t*, uint32_t*);
-__global__ void k_msm_shift_starts(uint32_t*, uint32_t, int);
-__global__ void k_msm_identity_entries(uint32_t*, uint32_t);
+__global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_scatter(const uint64_t*, const uint32_t*, const uint32_t*, int, int, const uint32_t*, uint32_t*);
 __global__ void k_msm_runs_count(const uint32_t*, int, uint32_t, uint32_t*, uint32_t*);
 __global__ void k_msm_runs_scan(uint32_t*, uint32_t*, const uint32_t*, uint32_t*, int, uint32_t*);

@@ -354,14 +354,18 @@ __global__ void k_mul_rows(Fr* __restrict__ d, const Fr* __restrict__ f, size_t 
     if (i < total) d[i] = d[i] * f[i & (n - 1)];
 }
 
-// post: the factor applied with `scale` (null: 1 / 2^log_n) -- the blocks of a three-pass transform are scaled by 1 / n of the whole
-static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch, const Fr* post = nullptr, size_t pre_step = 0) {
-    static bool attr_set = false;
-    if (!attr_set) {
+// the tiles' dynamic LDS exceeds the default limit: raised once per device
+static void ntt_tile_attributes(zk_ctx* ctx) {
+    static PerDeviceOnce once;
+    once.run(ctx->device, [] {
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
         ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
-        attr_set = true;
-    }
+    });
+}
+
+// post: the factor applied with `scale` (null: 1 / 2^log_n) -- the blocks of a three-pass transform are scaled by 1 / n of the whole
+static void ntt_core(zk_ctx* ctx, bool dit, Fr* d, unsigned log_n, bool inverse, bool scale, const Fr* d_pre, size_t batch, const Fr* post = nullptr, size_t pre_step = 0) {
+    ntt_tile_attributes(ctx);
     auto tabs = ntt_get_tables(ctx, log_n);
     size_t n = (size_t)1 << log_n;
     const int32_t* tw = inverse ? tabs->tw29_inv.p : tabs->tw29_fwd.p;
@@ -439,11 +443,7 @@ void ntt_dif(zk_ctx* ctx, Fr* d, unsigned log_n, bool inverse, bool scale, size_
 bool ntt_dif_fusable(unsigned log_n) { return log_n <= 2 * NTT_MAX_LOCAL_LOG; }
 void ntt_dif_fused(zk_ctx* ctx, Fr* out, unsigned log_n, bool inverse, size_t batch, const NttFuse& f) {
     ZK_REQUIRE(ntt_dif_fusable(log_n) && batch >= 1 && f.half <= batch, ZK_ERR_SIZE, "ntt_dif_fused: at most two passes (2^22 points)");
-    static bool attr_set = false;
-    if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)k_ntt_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES));
-        attr_set = true;
-    }
+    ntt_tile_attributes(ctx);
     auto tabs = ntt_get_tables(ctx, log_n);
     const size_t n = (size_t)1 << log_n, r2 = (size_t)1 << NTT_MAX_LOCAL_LOG;
     const int32_t* tw = inverse ? tabs->tw29_inv.p : tabs->tw29_fwd.p;

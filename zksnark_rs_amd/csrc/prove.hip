@@ -146,12 +146,6 @@ __global__ __launch_bounds__(192) void k_assemble(const MsmResults* __restrict__
     assemble_body(ms, pre, bl, proof);
 }
 
-// the blinding factors in device memory: the form a captured graph replays (prove_graph)
-__global__ __launch_bounds__(192) void k_assemble_p(const MsmResults* __restrict__ ms, const AssemblePre* __restrict__ pre, const AssembleBlind* __restrict__ bl, uint8_t* __restrict__ proof) {
-    ZK_LATENCY_KERNEL();
-    assemble_body(ms, pre, *bl, proof);
-}
-
 // batch form: workgroup j assembles proof j from blob j of the partial sums
 __global__ __launch_bounds__(192) void k_assemble_batch(const uint8_t* __restrict__ blobs, const AssemblePre* __restrict__ pre, AssembleBlind bl, uint8_t* __restrict__ proofs) {
     ZK_LATENCY_KERNEL();
@@ -201,11 +195,6 @@ struct ProveSlot {
     // pass for both): uv = V | U evaluations / coefficients, uvg = V | U on the coset, xy = U.V on <w> | on g<w>; each half
     // holds `count` vectors of n elements (count = 1 outside batches)
     DevBuf<Fr> uv, uvg, xy;
-    // parameter block of a captured lone proof (prove_graph): what changes from proof to proof besides the witness
-    struct LoneParams { Fr rs_can[2]; Fr rs_lin[2]; AssembleBlind blind; };
-    LoneParams* h_lp = nullptr;      // pinned
-    DevBuf<LoneParams> d_lp;
-    hipEvent_t cap_evt = nullptr;
     DevBuf<Fr> arb_vals, arb_work;   // form 2 (arbitrary roots): SpMV outputs U | V, scratch of the interpolation
     MsmWorkspace ws[zk_ctx::MSM_STREAMS];
     DevBuf<MsmResults> ms;
@@ -245,8 +234,6 @@ struct ProveSlot {
         if (h_flag) (void)hipHostFree(h_flag);
         if (h_b_proofs) (void)hipHostFree(h_b_proofs);
         if (h_b_rs) (void)hipHostFree(h_b_rs);
-        if (h_lp) (void)hipHostFree(h_lp);
-        if (cap_evt) (void)hipEventDestroy(cap_evt);
         for (hipEvent_t e : {fork_evt, pre_evt, done_evt}) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < zk_ctx::MSM_STREAMS; ++k) {
             if (msm_done[k]) (void)hipEventDestroy(msm_done[k]);
@@ -314,18 +301,6 @@ struct ProveState {
         return b;
     }
     ProveSlot slot[SLOTS];
-    // one captured lone proof (option lone_graph): key = what the launch geometry and the baked-in pointers depend on
-    struct LoneGraph {
-        const void *crs = nullptr, *qap = nullptr;
-        size_t m_in = 0;
-        long window = 0;
-        uint64_t generation = 0;      // devbuf_generation() when the capture ended: any allocation or release since then invalidates the graph
-        int seen = 0;                 // proofs of this key so far: the first runs eagerly (allocations), the second is captured
-        bool disabled = false;        // capture failed once: eager from then on
-        hipGraphExec_t exec = nullptr;
-        void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; seen = 0; disabled = false; }
-        ~LoneGraph() { if (exec) (void)hipGraphExecDestroy(exec); }
-    } lone;
     int next = 0;
     hipEvent_t last_acc = nullptr;   // end of the most recently enqueued accumulation chain
     // zk_prove_combine scratch (allocated once)
@@ -479,8 +454,7 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
         ntt_dif_fused(ctx, S.uvg.p, q.log_n, true, 2, f1);             // uvg = n V | n U coefficients (bit-reversed order)
         launch(0, 1, vc_can, n);
         launch(2, 0, uc_can, n);
-        if (ctx->graph_capture) fr_lincomb_to_canonical_p(ctx, vg, ug, S.d_lp.p->rs_lin, hb_can + n, n);
-        else fr_lincomb_to_canonical(ctx, vg, r_mont * n_inv, ug, s_mont * n_inv, hb_can + n, n);
+        fr_lincomb_to_canonical(ctx, vg, r_mont * n_inv, ug, s_mont * n_inv, hb_can + n, n);
         ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w> (the table holds g^i / n)
         NttFuse f3;
         f3.src_a[0] = ue; f3.src_b[0] = ve; f3.src_a[1] = ug; f3.src_b[1] = vg; f3.half = 1;
@@ -493,8 +467,7 @@ static void sparse_scalar_stage(zk_ctx* ctx, ProveSlot& S, const zk_qap& q, NttT
     fr_scale_to_canonical(ctx, ue, n_inv, uc_can, n);
     launch(2, 0, uc_can, n);
     // r v_i + s u_i: B in G1 (needed only as r*B1) and s*A are folded into the H product as scalars
-    if (ctx->graph_capture) fr_lincomb_to_canonical_p(ctx, ve, ue, S.d_lp.p->rs_lin, hb_can + n, n);   // r / n, s / n from the parameter block
-    else fr_lincomb_to_canonical(ctx, ve, r_mont * n_inv, ue, s_mont * n_inv, hb_can + n, n);
+    fr_lincomb_to_canonical(ctx, ve, r_mont * n_inv, ue, s_mont * n_inv, hb_can + n, n);
     ZK_HIP(hipMemcpyAsync(S.uvg.p, S.uv.p, 2 * n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ntt_dit(ctx, S.uvg.p, q.log_n, false, false, tabs->coset_fwd_brev.p, 2);   // V, U on g<w> (the table holds g^i / n)
     fr_pointwise_mul(ctx, ug, vg, y0, n);                             // U.V on g<w>
@@ -556,17 +529,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     }
 
     // the r/s-only fixed-base multiplications run on the side stream beside everything below
-    if (ctx->graph_capture) {
-        // captured lone proof: (r, s) in their three forms and the blinding factors come from the slot's parameter block, refreshed
-        // by the graph's first node; the side stream joins the capture through an event of the main stream
-        ZK_HIP(hipMemcpyAsync(S.d_lp.p, S.h_lp, sizeof(ProveSlot::LoneParams), hipMemcpyHostToDevice, st));
-        ZK_HIP(hipEventRecord(S.cap_evt, st));
-        ZK_HIP(hipStreamWaitEvent(ctx->side, S.cap_evt, 0));
-        hipLaunchKernelGGL(k_assemble_pre_batch, dim3(1), dim3(320), 0, ctx->side, crs.ft_alpha1.p, crs.ft_beta1.p, crs.ft_delta1.p, crs.ft_delta2.p,
-                           crs.alpha1.p, crs.beta2.p, S.d_lp.p->rs_can, &S.as.p->pre);
-        ZK_HIP(hipGetLastError());
-        ZK_HIP(hipEventRecord(S.pre_evt, ctx->side));
-    } else if (!d_partial_out && !xout) {
+    if (!d_partial_out && !xout) {
         hipStream_t pre_st = ctx->opt_serialize ? st : ctx->side;
         launch_pre(ctx, crs, pre_st, rc, sc, S.as.p);
         ZK_HIP(hipEventRecord(S.pre_evt, pre_st));
@@ -582,7 +545,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // second scalar array (MsmSplit).
     auto launch_now = [&](int k, int after, auto& table, const Fr* scalars, size_t count, auto* out, hipStream_t ms_st, size_t off, MsmSplit sp) {
         ZK_HIP(hipStreamWaitEvent(ms_st, S.scal_evt[k], 0));
-        hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : (ctx->graph_capture ? nullptr : ps.last_acc);   // nothing outside a capture is waited for
+        hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         hipStream_t end_st;
         if (world > 1 && ctx->opt_shard_points) {
             // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
@@ -592,7 +555,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
             MsmGroups ex;
             // measurement switch tail_stream: the merged product's reduction tail on the idle L stream, so that the next proof's sort of
             // the same product starts when this accumulation ends instead of ~1 ms later (r5_experiments.txt item 11)
-            if (k == 4 && sp.scalars2 && ctx->opt_tail_stream && !ctx->opt_serialize && !ctx->graph_capture) ex.tail_stream = ctx->msm_stream[1];
+            if (k == 4 && sp.scalars2 && ctx->opt_tail_stream && !ctx->opt_serialize) ex.tail_stream = ctx->msm_stream[1];
             end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars, count, rank, world, out, wait_evt, S.acc_evt[k], off, ex, sp);
         }
         ZK_HIP(hipEventRecord(S.msm_done[k], end_st));
@@ -672,8 +635,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         launch(0, 1, crs.t_xi2, vc_can, n, &ms->b2);                     // B = sum V_k [L_k(x)]_2
         fr_from_mont(ctx, ue, uc_can, n);
         launch(2, 0, crs.t_xi1, uc_can, n, &ms->a);                      // A = sum U_k [L_k(x)]_1
-        if (ctx->graph_capture) fr_lincomb_to_canonical_p(ctx, ve, ue, S.d_lp.p->rs_lin, hb_can + (n - 1), n);
-        else fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
+        fr_lincomb_to_canonical(ctx, ve, r_mont, ue, s_mont, hb_can + (n - 1), n);   // bases: L^S t/delta (n-1) | L (n)
         ap_quotient_values(ctx, q, ue, ve, S.xy.p, hb_can);              // h on S = {n+1 .. 2n-1}
         launch(4, 2, crs.t_hb1, hb_can, 2 * n - 1, &ms->hb);
     } else if (form == 0) {
@@ -789,103 +751,18 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipStreamWaitEvent(fin, S.pre_evt, 0));
         {
             ProfScope pscope(ctx, "assemble", 0, fin);
-            if (ctx->graph_capture) hipLaunchKernelGGL(k_assemble_p, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, &S.d_lp.p->blind, S.d_proof.p);
-            else hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, ps.draw_blind(), S.d_proof.p);
+            hipLaunchKernelGGL(k_assemble, dim3(1), dim3(192), 0, fin, ms, &S.as.p->pre, ps.draw_blind(), S.d_proof.p);
         }
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipMemcpyAsync(S.h_proof, S.d_proof.p, ZK_PROOF_BYTES, hipMemcpyDeviceToHost, fin));
     }
     ZK_HIP(hipMemcpyAsync(S.h_flag, S.flag.p, sizeof(int), hipMemcpyDeviceToHost, fin));
     ZK_HIP(hipEventRecord(S.done_evt, fin));
-    if (ctx->graph_capture) ZK_HIP(hipStreamWaitEvent(st, S.done_evt, 0));   // every forked stream joins the capture's origin stream
     S.fin_stream = fin;
     S.busy = true;
     ctx->cur_slot = -1;
     pick_next_slot(ps);
     return ticket;
-}
-
-// ---- a lone proof as ONE captured graph (option lone_graph) -----------------------------------------------------------------------
-// The reference's call shape is one synchronous prove(&qap, (&s1, &s2), &weights) (mod.rs:213-217).  A lone proof of a small circuit is
-// ~113 launches on eight streams: the host needs 0.4 ms to enqueue them, and the GPU starts on the first while the last are still
-// being prepared.  Everything about those launches is the same from proof to proof of one (CRS, QAP, witness length) -- the grids are
-// upper bounds that do not depend on the data -- except the witness, (r, s) and the blinding factors.  So: the witness is copied into
-// the slot's own buffer, the factors into the slot's parameter block (pinned -> device by the graph's first node, read by the three
-// kernels that need them), and the whole of prove_submit is captured once and replayed.  The first proof of a key runs eagerly (it
-// allocates the slot's buffers), the second is captured; any failure of the capture disables the path for this context.
-// MEASURED, AND IT LOSES (profiles/r4_lone_graph.txt): replayed, a lone proof takes 0.93 ms at 16 gates (eager 0.72), 1.56 ms at 2^12
-// (1.08), 2.17 ms at 2^16 (1.59), 12.0 ms at 2^20 (11.2) -- the runtime's replay of an eight-stream graph of ~113 nodes costs more than
-// the host's own enqueue, which already overlaps the GPU's work.  The option therefore defaults to 0; the path stays as the measured
-// comparator the reviews asked for (bytes equal to the eager path: tests/test_gpu_prove.py).
-// Returns false when the caller should prove eagerly.
-static bool prove_graph(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& q, const Fr* d_weights, size_t m_in, const uint64_t* r, const uint64_t* s, uint8_t* proof_out) {
-    if (!ctx->opt_lone_graph || ctx->opt_profile || ctx->opt_serialize || q.dense || q.roots != 0) return false;   // the roots-of-unity form only
-    ProveState& ps = prove_state(ctx);
-    for (int k = 0; k < ProveState::SLOTS; ++k)
-        if (ps.slot[k].busy) return false;          // other proofs in flight: the eager path queues behind them
-    ProveState::LoneGraph& G = ps.lone;
-    if (G.crs != &crs_c || G.qap != &q || G.m_in != m_in || G.window != ctx->opt_window_bits) {
-        G.reset();
-        G.crs = &crs_c; G.qap = &q; G.m_in = m_in; G.window = ctx->opt_window_bits;
-    }
-    // The graph holds raw pointers into slot 0, the MSM workspaces and the CRS tables.  Other entry points (submit, batch, the multi-GPU
-    // paths, a destroyed and re-created CRS / QAP at the same address) may have regrown or freed any of them: replay only if nothing was
-    // allocated or released through DevBuf since the capture ended, otherwise start over (eager proof, then a new capture).
-    if (G.exec && G.generation != devbuf_generation().load()) { const bool was_disabled = G.disabled; G.reset(); G.disabled = was_disabled; }
-    if (G.disabled) return false;
-    if (G.seen++ == 0) return false;                // first proof of this key: eager (tables, slot buffers)
-    Fr rc = fr_from_words64(r), sc = fr_from_words64(s);
-    ZK_REQUIRE(rc.raw_in_range() && sc.raw_in_range(), ZK_ERR_RANGE, "prove: r or s >= modulus");
-    ProveSlot& S = ps.slot[0];
-    ps.next = 0;
-    const size_t mm = std::min(m_in, q.m);
-    S.d_wit.ensure(std::max<size_t>(mm, 1));
-    if (!S.h_lp) {
-        ZK_HIP(hipHostMalloc((void**)&S.h_lp, sizeof(ProveSlot::LoneParams)));
-        S.d_lp.alloc(1);
-        ZK_HIP(hipEventCreateWithFlags(&S.cap_evt, hipEventDisableTiming));
-    }
-    const Fr r_mont = Fr::from_canonical(rc), s_mont = Fr::from_canonical(sc);
-    const Fr f = q.roots == 0 ? ntt_get_tables(ctx, q.log_n)->n_inv : Fr::one();   // the inverse transforms run without their 1 / n
-    S.h_lp->rs_can[0] = rc; S.h_lp->rs_can[1] = sc;
-    S.h_lp->rs_lin[0] = (r_mont * f).to_canonical(); S.h_lp->rs_lin[1] = (s_mont * f).to_canonical();   // plain integers (k_lincomb_to_canonical_p)
-    S.h_lp->blind = ps.draw_blind();
-    hipStream_t st = ctx->stream;
-    if (mm) ZK_HIP(hipMemcpyAsync(S.d_wit.p, d_weights, mm * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    if (!G.exec) {
-        hipGraph_t graph = nullptr;
-        bool began = false;
-        try {
-            ZK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-            began = true;
-            ctx->graph_capture = true;
-            prove_submit(ctx, crs_c, q, S.d_wit.p, mm, r, s, 0, 1, nullptr, nullptr);
-            ctx->graph_capture = false;
-            began = false;
-            ZK_HIP(hipStreamEndCapture(st, &graph));
-            ZK_HIP(hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-        } catch (...) {
-            ctx->graph_capture = false;
-            if (began) (void)hipStreamEndCapture(st, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            G.disabled = true;
-            G.exec = nullptr;
-        }
-        // what prove_submit noted about the slot and the accumulation chain refers to captured work: undone
-        S.busy = false;
-        ps.last_acc = nullptr;
-        ps.next = 0;
-        ctx->cur_slot = -1;
-        if (G.disabled) { ZK_HIP(hipStreamSynchronize(st)); return false; }
-        G.generation = devbuf_generation().load();
-    }
-    ZK_HIP(hipGraphLaunch(G.exec, st));
-    ZK_HIP(hipStreamSynchronize(st));
-    ZK_REQUIRE(!*S.h_flag, ZK_ERR_RANGE, "prove: witness element >= r");
-    if (proof_out) std::memcpy(proof_out, S.h_proof, ZK_PROOF_BYTES);
-    return true;
 }
 
 // The inner products of `sets` proofs over this rank's points: d_l / d_vc / d_uc / d_hb hold `sets` chunks each (what
@@ -1197,7 +1074,6 @@ void prove_release(zk_ctx* ctx, int ticket, int* h_flag_pinned) {
 
 void prove_dev(zk_ctx* ctx, const zk_crs& crs, const zk_qap& qap, const Fr* d_weights, size_t m, const uint64_t* r, const uint64_t* s,
                uint8_t* proof_out, int rank, int world, void* d_partial_out) {
-    if (world == 1 && !d_partial_out && prove_graph(ctx, crs, qap, d_weights, m, r, s, proof_out)) return;
     int t = prove_submit(ctx, crs, qap, d_weights, m, r, s, rank, world, d_partial_out, nullptr);
     prove_wait(ctx, t, proof_out);
 }

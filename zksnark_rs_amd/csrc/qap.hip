@@ -227,17 +227,6 @@ __global__ void k_lincomb_to_canonical(const Fr* __restrict__ a, Fr kac, const F
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fr_store_exact(FrL::mont_sum(FrL::load(a[i]), FrL::load(kac), FrL::load(b[i]), FrL::load(kbc)));
 }
-// the same with the two factors in DEVICE memory (k[0], k[1], plain integers): a captured graph replays with other factors (prove.hip, lone proofs)
-__global__ void k_lincomb_to_canonical_p(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ k, Fr* __restrict__ out, size_t n) {
-    ZK_LATENCY_KERNEL();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = fr_store_exact(FrL::mont_sum(FrL::load(a[i]), FrL::load(k[0]), FrL::load(b[i]), FrL::load(k[1])));
-}
-void fr_lincomb_to_canonical_p(zk_ctx* ctx, const Fr* a, const Fr* b, const Fr* d_k, Fr* out, size_t n) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_lincomb_to_canonical_p, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, a, b, d_k, out, n);
-    ZK_HIP(hipGetLastError());
-}
 void fr_lincomb_to_canonical(zk_ctx* ctx, const Fr* a, Fr ka, const Fr* b, Fr kb, Fr* out, size_t n) {
     if (!n) return;
     ProfScope ps(ctx, "fr_lincomb_to_canonical", 96.0 * n);

@@ -8,7 +8,6 @@ void dense_matvec(zk_ctx*, const Fr* M, const Fr* a, size_t rows, size_t n, Fr* 
 void h_combine(zk_ctx*, const Fr* x, const Fr* y, const Fr* tab, Fr half, Fr* out, size_t n);
 void fr_scale_to_canonical(zk_ctx*, const Fr* in, Fr k, Fr* out, size_t n);
 void fr_lincomb_to_canonical(zk_ctx*, const Fr* a, Fr ka, const Fr* b, Fr kb, Fr* out, size_t n);
-void fr_lincomb_to_canonical_p(zk_ctx*, const Fr* a, const Fr* b, const Fr* d_k, Fr* out, size_t n);   // factors k[0], k[1] in device memory
 void fr_sub_inplace(zk_ctx*, Fr* a, const Fr* b, size_t n);
 void poly_divide(zk_ctx*, Fr* r, size_t len_r, const Fr* t, size_t d, const Fr* cinv, Fr* q);
 void qap_ensure_tinv(zk_ctx*, zk_qap& q, size_t K, unsigned log_size);
