@@ -281,8 +281,10 @@ def main():
                          "caller-supplied gloo transport, for functional runs of several ranks on ONE GPU")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="--transport torch: torch.distributed backend; gloo + several ranks on ONE GPU is a functional check of the N > 1 path only")
-    ap.add_argument("--shard", choices=["windows", "points"], default="points",
-                    help="what a rank owns of each inner product in --mode shard: Pippenger windows w = rank (mod N), or the "
+    ap.add_argument("--shard", choices=["windows", "points", "buckets"], default="points",
+                    help="what a rank owns of each inner product in --mode shard: buckets = 1 / N of the shared bucket range of every product "
+                         "(every window's digits, 1 / N of them kept: entries, accumulation and reduction tail all divide by N); "
+                         "Pippenger windows w = rank (mod N), or the "
                          "point range [count rank / N, count (rank+1) / N) with every window (5 %% faster at N = 8: 15 windows "
                          "do not divide by 8, and a rank sorts only its own scalars)")
     ap.add_argument("--serialize", action="store_true",
@@ -410,7 +412,8 @@ def main():
                          "ZKGPU_LIB=zksnark_rs_amd/libzkgpu_measure.so)")
     if args.serialize:
         ctx.set_option("serialize", 1)
-    ctx.set_option("msm_shard_points", 1 if args.shard == "points" else 0)
+    SHARD_OPT = {"windows": 0, "points": 1, "buckets": 2}
+    ctx.set_option("msm_shard_points", SHARD_OPT[args.shard])
     for kv in args.opt:
         key, val = kv.split("=", 1)
         ctx.set_option(key, int(val))
@@ -486,7 +489,7 @@ def main():
             pass
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"diagnostic": "rank 0 of a %d-way %s-sharded prover, partial sums only" % (W, "point-range" if args.shard == "points" else "window"), "ms_per_proof_per_rank": round(dt * 1e3, 3),
+        print(json.dumps({"diagnostic": "rank 0 of a %d-way %s-sharded prover, partial sums only" % (W, {"points": "point-range", "windows": "window", "buckets": "bucket-range"}[args.shard]), "ms_per_proof_per_rank": round(dt * 1e3, 3),
                           "implied_proofs_per_s_at_%d_gpus" % W: round(1.0 / dt, 2)}))
         return
 
@@ -516,7 +519,7 @@ def main():
             if use_zk:      # zk_mgpu_push / zk_mgpu_pop, two rounds pushed ahead of every pop
                 return list(zip(idx, state["mprover"].prove_stream([(d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"]) for j in idx], ahead=2)))
             return list(zip(idx, prove_exchange_stream(xprover, dist, rank, world, [(inst["r"], inst["s"])] * k)))   # k rounds = k * world proofs
-        if mode in ("shard", "window_shard"):
+        if mode in ("shard", "window_shard", "bucket_shard"):
             idx = [job(i, shared=True) for i in range(k)]
             if use_zk:
                 return [(j, prove_sharded_abi(ctx, comm, inst["crs"], inst["qap"], d_ws[j].data_ptr(), m, sets[j]["r"], sets[j]["s"])) for j in idx]
@@ -659,7 +662,7 @@ def main():
 
     def leg_record(name, mode, elapsed, wrong, per_step):
         return {"mode": name, "value": round(per_step * args.steps / elapsed, 4), "unit": "proofs/s", "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-                "scaling": "strong" if mode in ("shard", "window_shard") else "weak",
+                "scaling": "strong" if mode in ("shard", "window_shard", "bucket_shard") else "weak",
                 "bytes_equal_to_single_gpu_prove": wrong == 0, **({"mismatches": wrong} if wrong else {})}
 
     # ---- the legs ------------------------------------------------------------------------------------------------------------
@@ -673,7 +676,8 @@ def main():
     order = [primary]
     if world > 1:
         if use_zk:
-            order += [x for x in ("exchange", "window_shard") if x != primary and not (x == "window_shard" and primary == "shard" and args.shard == "windows")]
+            order += [x for x in ("exchange", "window_shard", "bucket_shard") if x != primary and not (x == "window_shard" and primary == "shard" and args.shard == "windows")
+                      and not (x == "bucket_shard" and primary == "shard" and args.shard == "buckets")]
         if "single" not in order:
             order.append("single")
     prof, elapsed, wrong_primary, raw_elapsed = {}, None, 0, {}
@@ -685,8 +689,8 @@ def main():
         try:
             if mode == "exchange" and use_zk and state.get("mprover") is None:
                 state["mprover"] = mprover = bounded(lambda: MgpuProver(ctx, comm, inst["crs"], inst["qap"]), TMO, "zk_mgpu_create", device)
-            if mode in ("shard", "window_shard"):
-                ctx.set_option("msm_shard_points", 0 if mode == "window_shard" else (1 if args.shard == "points" else 0))
+            if mode in ("shard", "window_shard", "bucket_shard"):
+                ctx.set_option("msm_shard_points", 0 if mode == "window_shard" else 2 if mode == "bucket_shard" else SHARD_OPT[args.shard])
             if collective:
                 res = bounded(lambda: timed_leg(mode, "leg_" + mode, profile=(mode == primary)), max(TMO, 4 * TMO if args.steps > 200 else TMO), "the %s leg" % mode, device)
             else:
@@ -724,7 +728,9 @@ def main():
         per_step = world if mode in ("exchange", "single") and world > 1 else 1
         name = {"single": "replicas x%d (independent provers, no collective)" % world if world > 1 else "single GPU",
                 "exchange": "scalar exchange by point ranges x%d (zk_mgpu_*: all-to-all of scalars and partial sums)" % world,
-                "shard": "msm-%s-shard x%d, one proof at a time (latency form)" % ("point-range" if args.shard == "points" else "window", world),
+                "shard": "msm-%s-shard x%d, one proof at a time (latency form)" % ({"points": "point-range", "windows": "window", "buckets": "bucket-range"}[args.shard], world),
+                "bucket_shard": "1 / %d of the shared bucket range of every inner product per GPU (every window's digits, 1 / %d kept), one proof at a time, "
+                                "all-gather of the partial sums: config 5 balanced -- entries, accumulation and reduction tail all divide by N" % (world, world),
                 "window_shard": "MSM windows w = rank (mod %d) per GPU, one proof at a time, all-gather of the partial sums (BASELINE config 5)" % world}[mode]
         legs[mode] = leg_record(name, mode, el, wrong, per_step)
         raw_elapsed[mode] = el
@@ -772,7 +778,7 @@ def main():
             ctx.host_free(hw)
         host_ws = None
 
-    shard = primary in ("shard", "window_shard")
+    shard = primary in ("shard", "window_shard", "bucket_shard")
     exchange = primary == "exchange"
     proofs = args.steps * (world if (world > 1 and not shard) else 1)   # exchange / replicas: a step is `world` proofs
     value = proofs / elapsed
@@ -905,8 +911,18 @@ def main():
                        "expected_bytes_from": "one synchronous single-GPU zk_prove_dev per set in the untimed set-up; every timed proof is compared with it"},
             "roofline": roofline,
             "kernels": kernels,
+            **({"config5": (lambda w_, b_: None if not (w_ or b_) else (lambda best_, form_: {
+                "value": best_["value"], "ms_per_step": best_["ms_per_step"], "scaling": "strong", "unit": "proofs/s", "form": form_,
+                "what": "BASELINE config 5: ONE 2^%d proof at a time with every inner product sharded over the %d GPUs and one RCCL all-gather of the "
+                        "768-byte partial sums; the faster of `window_shard` (the literal partition: windows w = rank mod N of the fixed-base tables) "
+                        "and `bucket_shard` (the tables share ONE bucket set over all windows: a rank owns 1 / N of it -- equal shares for every N)" % (args.log_n, world),
+                "window_shard_value": w_["value"] if w_ else None, "bucket_shard_value": b_["value"] if b_ else None})(
+                    *((b_, "bucket_shard") if (b_ and (not w_ or b_["value"] >= w_["value"])) else (w_, "window_shard"))))(
+                    legs.get("window_shard") or (legs.get("shard") if args.shard == "windows" else None),
+                    legs.get("bucket_shard") or (legs.get("shard") if args.shard == "buckets" else None))} if world > 1 else {}),
             **({k_: v_ for k_, v_ in (("exchange", legs.get("exchange")), ("window_shard", legs.get("window_shard") or (legs.get("shard") if args.shard == "windows" else None)),
-                                      ("shard", legs.get("shard") if args.shard != "windows" else None), ("replicas", legs.get("single"))) if v_ and world > 1}),
+                                      ("bucket_shard", legs.get("bucket_shard") or (legs.get("shard") if args.shard == "buckets" else None)),
+                                      ("shard", legs.get("shard") if args.shard == "points" else None), ("replicas", legs.get("single"))) if v_ and world > 1}),
             **({"rccl_ranks": comm.rccl_ranks() if (comm is not None and state["degraded"] is None) else 0, "xgmi_bytes_sent_per_rank_per_round": xg,
                 "comm_cu_reserve_per_xcd": ctx.get_option("comm_cu_reserve") if (use_zk and args.transport == "zk") else 0, "wait_bound_s": TMO} if world > 1 else {}),
             **({"pcie_inclusive": pcie} if pcie else {}),

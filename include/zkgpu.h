@@ -63,7 +63,9 @@ const char* zk_strerror(int status);
 const char* zk_last_error(const zk_ctx* ctx);          /* detail of the last failing call */
 /* Options of the product build: "msm_window_bits" (Pippenger c of the fixed-base tables; 0 = automatic, c = the same for every table,
  * 100 * big + small = `big` for tables of 2^21 points and more, + 10000 * g2 = its own window for the G2 table), "msm_shard_points"
- * (zk_prove_partial: 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points), "rank_tables" (multi-GPU exchange:
+ * (zk_prove_partial: 0 = a rank owns Pippenger windows, 1 = a rank owns a range of the points, 2 = a rank owns 1 / world of the BUCKET
+ * range of every product -- the fixed-base tables share one bucket set over all windows, so this divides entries, accumulation and
+ * the per-bucket reduction tail by world where 13 windows over 8 ranks leave 2 : 1; world a power of two, otherwise as 0), "rank_tables" (multi-GPU exchange:
  * 1 = window tables of the rank's own point ranges only), "dense_long_division" (1: the dense form always divides by t with the
  * reference's long division; default 0 = power-series inverse above 512 quotient coefficients), "msm_quad_buckets" (inner products of
  * at most this many buckets run their reduction tail with four lanes per point addition: shorter dependency chains for small

@@ -55,7 +55,7 @@ def run_two_ranks(extra, env=None, port_base=29600, backend="gloo"):
 
 
 @pytest.mark.parametrize("mode,shard,transport", [("exchange", "points", "zk-gloo"), ("shard", "points", "zk-gloo"), ("shard", "windows", "zk-gloo"),
-                                                  ("exchange", "points", "torch"), ("shard", "points", "torch")])
+                                                  ("shard", "buckets", "zk-gloo"), ("exchange", "points", "torch"), ("shard", "points", "torch")])
 def test_bench_line_two_ranks_on_one_gpu(mode, shard, transport):
     """zk-gloo: the pipeline and collectives inside libzkgpu.so (zk_mgpu_*, zk_comm_* with a caller-supplied gloo transport);
     torch: the round-1 Python driver over torch.distributed.  With the library's pipeline ONE line carries all three legs -- the
@@ -69,11 +69,15 @@ def test_bench_line_two_ranks_on_one_gpu(mode, shard, transport):
     assert d["replicas"]["value"] > 0 and d["replicas"]["scaling"] == "weak" and d["replicas"]["bytes_equal_to_single_gpu_prove"]
     assert "degraded" not in d and d["wait_bound_s"] > 0 and d["rccl_ranks"] == 0    # gloo / torch transports: no RCCL communicator behind the line
     if transport == "zk-gloo":
-        for leg, scaling in (("exchange", "weak"), ("window_shard", "strong")):
+        for leg, scaling in (("exchange", "weak"), ("window_shard", "strong"), ("bucket_shard", "strong")):
             assert d[leg]["value"] > 0 and d[leg]["ms_per_step"] > 0 and d[leg]["scaling"] == scaling and d[leg]["bytes_equal_to_single_gpu_prove"], leg
         assert d["xgmi_bytes_sent_per_rank_per_round"] > 0 and d["config"]["witness_sets"] >= 4
-        primary = d["exchange"] if mode == "exchange" else d["window_shard"] if shard == "windows" else d["shard"]
+        primary = d["exchange"] if mode == "exchange" else d["window_shard"] if shard == "windows" else d["bucket_shard"] if shard == "buckets" else d["shard"]
         assert primary["value"] == d["value"]
+        # BASELINE config 5 as a top-level object of the N > 1 line: one proof at a time, strong scaling
+        c5 = d["config5"]
+        assert c5["scaling"] == "strong" and c5["form"] in ("bucket_shard", "window_shard") and c5["value"] == max(d["bucket_shard"]["value"], d["window_shard"]["value"])
+        assert c5["window_shard_value"] == d["window_shard"]["value"] and c5["bucket_shard_value"] == d["bucket_shard"]["value"]
 
 
 def test_bench_falls_back_to_independent_provers():

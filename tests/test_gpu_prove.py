@@ -286,7 +286,7 @@ def test_multi_gpu_partials_on_one_gpu(ctx, orc):
     crs = ctx.setup(inst["qap"], inst["td"])
     want = ctx.prove(crs, inst["qap"], inst["weights"], inst["r"], inst["s"])
     dw = torch.from_numpy(inst["weights"].view(np.int64)).cuda()
-    for by_points in (0, 1):            # partial sums by Pippenger windows / by point ranges
+    for by_points in (0, 1, 2):         # partial sums by Pippenger windows / by point ranges / by bucket ranges (2: powers of two, else windows)
         ctx.set_option("msm_shard_points", by_points)
         for world in (1, 2, 3, 4, 8):
             buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
@@ -479,7 +479,11 @@ def test_prove_at_the_largest_size_2_23(ctx, orc):
 def test_window_sharded_full_size_2_20(ctx, orc):
     """BASELINE configs[4] as it is worded: the 2^20 proof with the Pippenger WINDOWS of every inner product sharded over the ranks
     (rank g accumulates the windows w = g mod world; msm_shard_points = 0), worlds 2 and 8 played on one device, the all-gather
-    replaced by writing into one buffer: zk_prove_combine of the partial sums == the closed-form trapdoor proof."""
+    replaced by writing into one buffer: zk_prove_combine of the partial sums == the closed-form trapdoor proof.  Then the balanced form
+    of the same idea for the fixed-base tables' ONE shared bucket set (msm_shard_points = 2, round 6): rank g keeps the digits -- of every
+    window -- whose bucket lies in its 1 / world of the bucket range, so entries, accumulation and the per-bucket reduction tail all
+    divide by world (13 windows do not divide by 8): worlds 2, 4 and 8, the same bytes, also for a boolean witness (one heavy bucket,
+    all of it on one rank)."""
     torch = pytest.importorskip("torch")
     inst = chain_instance(ctx, 20, 2021)
     crs = ctx.setup(inst["qap"], inst["td"])
@@ -493,6 +497,26 @@ def test_window_sharded_full_size_2_20(ctx, orc):
                 ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
             torch.cuda.synchronize()
             assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want, world
+        ctx.set_option("msm_shard_points", 2)
+        for world in (2, 4, 8):
+            buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            for rank in range(world):
+                ctx.prove_partial(crs, inst["qap"], dw.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+            torch.cuda.synchronize()
+            assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want, ("buckets", world)
+        rng = SplitMix64(77)
+        wb = chain_weights(20, rng.fr(), [rng.next() & 1 for _ in range(1 << 20)])       # inputs in {0, 1}
+        dwb = torch.from_numpy(wb.view(np.int64)).cuda()
+        ctx.set_option("msm_shard_points", 0)
+        want_b = ctx.prove_dev(crs, inst["qap"], dwb.data_ptr(), inst["m"], inst["r"], inst["s"])
+        assert want_b == orc.trapdoor_proof_sparse(inst["desc"], inst["td"], wb, inst["r"], inst["s"])
+        ctx.set_option("msm_shard_points", 2)
+        world = 8
+        buf = torch.zeros(world * zk.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            ctx.prove_partial(crs, inst["qap"], dwb.data_ptr(), inst["m"], inst["r"], inst["s"], rank, world, buf.data_ptr() + rank * zk.PARTIAL_BYTES)
+        torch.cuda.synchronize()
+        assert ctx.prove_combine(crs, buf.data_ptr(), world, inst["r"], inst["s"]) == want_b, "buckets, boolean witness"
     finally:
         ctx.set_option("msm_shard_points", 0)
 

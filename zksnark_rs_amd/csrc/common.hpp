@@ -114,7 +114,7 @@ struct zk_ctx {
     std::string last_error;
     long opt_window_bits = 0;
     long opt_profile = 0;
-    long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges
+    long opt_shard_points = 0;    // multi-GPU partial sums: 0 = by Pippenger windows, 1 = by point ranges, 2 = by bucket ranges (MsmGroups::bucket_shard)
     long opt_long_division = 0;   // dense form: always use the reference's long division (A/B check of the Newton form)
     long opt_rank_tables = 1;     // multi-GPU scalar exchange: window tables of this rank's point ranges only (prove_msm_submit)
     long opt_comm_cu_reserve = 0; // multi-GPU exchange over RCCL: compute units per XCD the inner-product streams leave free, so that the collectives' kernels never wait for an accumulation wave to retire (comm.hip, capi.hip ctx_reserve_cus); 0 = none

@@ -101,6 +101,10 @@ struct MsmGroups {
     int groups = 1;
     size_t glen = 0, valid = 0, out_stride = 0;
     hipStream_t tail_stream = nullptr;   // when set (and acc_done given): the reduction tail runs there, behind the accumulation's event
+    // Partial sum of a product shared by `world` ranks BY BUCKET RANGE (world a power of two): rank g keeps the digits whose bucket
+    // |digit| - 1 lies in [g 2^(c-1) / world, (g + 1) 2^(c-1) / world) -- of every window and every point -- so entries, accumulation
+    // AND the per-bucket reduction tail are 1 / world of the product's.  Otherwise (rank, world) of msm_run mean Pippenger windows.
+    bool bucket_shard = false;
 };
 // Two scalar arrays, one product (groups == 1 only): the scalars of the points [0, split) come from d_scalars, those of the points
 // [split, split + n2) from scalars2 -- n_used is then split + n2.  How prove() multiplies its witness (the caller's array) and its

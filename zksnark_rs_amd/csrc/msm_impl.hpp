@@ -600,13 +600,13 @@ __global__ __launch_bounds__(TAIL_THREADS, FoldWaves<F>::value) void k_msm_fold(
 // double-and-add (weight 0 gives infinity); k_msm_sum_points adds the K + rows terms of a group.
 template <class F>
 __global__ __launch_bounds__(TAIL_THREADS, TailWaves<F>::value) void k_msm_weigh(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
-                                                   Jac<F>* __restrict__ term) {
+                                                   uint32_t wbase, Jac<F>* __restrict__ term) {
     ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
     const int j = blockIdx.x * TAIL_THREADS + threadIdx.x;
     if (j >= K + rows) return;
     const AccSlot<F>* src = j < K ? C + (size_t)g * K + j : R + (size_t)g * rows + (j - K);
-    const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u;
+    const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u + wbase;   // wbase: first bucket of a bucket-range shard
     term[(size_t)g * (K + rows) + j] = jacr_store(mul_small_lazy(jacr_load(acc_store(src->a)), w));
 }
 
@@ -641,7 +641,18 @@ template <class F>
 hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTable<F>& tab, const Fr* d_scalars, size_t n_used,
                     int rank, int world, Jac<F>* d_out, hipEvent_t acc_wait, hipEvent_t acc_done, size_t point_offset, const MsmGroups& grp, const MsmSplit& sp) {
     const bool g2 = sizeof(F) > sizeof(Fq);
-    const int c = tab.c, windows = tab.windows, bpg = 1 << (c - 1);
+    const int c = tab.c, windows = tab.windows;
+    // Partial sums by BUCKET RANGE (grp.bucket_shard; world a power of two with at least 64 buckets per rank, otherwise by windows):
+    // this rank's bucket set is 2^(cb - 1) buckets from blo on; every window's digits are looked at, 1 / world of them kept.
+    int shard_log = 0;
+    if (grp.bucket_shard && world > 1 && (world & (world - 1)) == 0 && grp.groups == 1) {
+        while ((1 << shard_log) < world) ++shard_log;
+        if (c - 1 - shard_log < 6) shard_log = 0;
+    }
+    const bool bshard = shard_log > 0;
+    const int cb = c - shard_log, bpg = 1 << (cb - 1);
+    const uint32_t blo = bshard ? (uint32_t)rank * (uint32_t)bpg : 0u;
+    if (bshard) { rank = 0; world = 1; }       // windows: all of them
     const size_t n = tab.n;
     // grouped: `groups` products over the same bases [point_offset, point_offset + valid), scalars of group j at
     // d_scalars + j glen, result j at (bytes) d_out + j out_stride; bucket (group, |digit|) = group * 2^(c-1) + |digit| - 1
@@ -673,12 +684,12 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         return st;
     }
     // two-level sort: 2^8 bins per group (fewer when the window is narrow, more only to keep the sub-bucket level at 2^11 counters)
-    const int sub_bits = std::min(11, std::max(0, c - 1 - 8)), bins = (1 << (c - 1 - sub_bits)) * groups;
+    const int sub_bits = std::min(11, std::max(0, cb - 1 - 8)), bins = (1 << (cb - 1 - sub_bits)) * groups;
     int chunks = (int)std::min<size_t>((size_t)ctx->cu_count, (n_used + SORT_THREADS - 1) / SORT_THREADS);
     if (chunks < 1) chunks = 1;
     size_t chunk_len = (n_used + chunks - 1) / chunks;
     chunks = (int)((n_used + chunk_len - 1) / chunk_len);
-    const size_t entries = (size_t)owned * n_used;
+    const size_t entries = (size_t)owned * n_used;   // upper bound of the digits kept (a bucket-range shard keeps ~ 1 / 2^shard_log of them)
     // positions in the sorted list (start[], the scan totals, the runs) are 32-bit, and the level-1
     // counters of all bins live in LDS: refuse up front instead of wrapping silently / failing after the first launches
     ZK_REQUIRE(entries < ((size_t)1 << 32), ZK_ERR_SIZE, "msm: scalars x windows exceeds 2^32 digit records (use a wider window or fewer groups)");
@@ -692,22 +703,23 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     const size_t fill = (size_t)std::max<long>(ctx->opt_small_lanes, 0);
     // (one run of at most 128 entries up to 64 entries per bucket on average -- the separate products of 2^20 .. 2^21 points --, of at
     // most RUN_MAX = 256 beyond: the merged L + H product of a proof holds 104 per bucket, and 128 would cut one bucket in a hundred)
-    const bool whole = entries / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill;
-    if (whole) T = entries / (size_t)buckets <= 64 ? 128 : RUN_MAX;
-    else if (ctx->opt_run_fill && entries / T > (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count) {
+    const size_t entries_est = entries >> shard_log;   // what the run-length rules are tuned on
+    const bool whole = entries_est / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill;
+    if (whole) T = entries_est / (size_t)buckets <= 64 ? 128 : RUN_MAX;
+    else if (ctx->opt_run_fill && entries_est / T > (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count) {
         // More runs than the chip holds lanes (3 waves per SIMD in G1, 2 in G2): every run beyond a bucket's first costs a full
         // XYZZ + XYZZ addition in the merge, so the runs are made as long as one round of lanes allows.  The A product of a 2^20-gate
         // proof (c = 17: 240 entries per bucket): T = 80 instead of 32, 2 merges per bucket instead of 7 (round 5).
         const size_t lanes = (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count;
-        T = (uint32_t)std::min<size_t>(RUN_MAX, (entries / lanes + 3) & ~(size_t)3);
+        T = (uint32_t)std::min<size_t>(RUN_MAX, (entries_est / lanes + 3) & ~(size_t)3);
     }
-    else if (fill && entries / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries / fill) & ~(size_t)3);
+    else if (fill && entries_est / T < fill) T = (uint32_t)std::max<size_t>(4, std::min<size_t>(T, entries_est / fill) & ~(size_t)3);
     // upper bounds: a bucket of z entries has ceil(z / T) <= 1 + z / T runs, of which all but the first take an extra image slot
     const size_t max_extra = entries / T + 1, max_runs = std::min<size_t>((size_t)buckets, entries) + max_extra;
     // an accumulation that cannot fill the chip (3 waves per SIMD = 196608 lanes) is not chained behind the previous one
-    if (std::min(max_runs, entries / std::min<size_t>(T, 32) + 1) < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
+    if (std::min(max_runs, entries_est / std::min<size_t>(T, 32) + 1) < (size_t)std::max<long>(ctx->opt_unchain_lanes, 0)) acc_wait = nullptr;
     // rows x columns of the bucket index for the final weighted sum (see k_msm_fold)
-    const int kbits = c / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((c - 1) / 2) column bits
+    const int kbits = cb / 2, K = 1 << kbits, rows = bpg >> kbits;   // ceil((cb - 1) / 2) column bits
     const int wgs_w = (K + rows + TAIL_THREADS - 1) / TAIL_THREADS;
     // Few buckets: the tail is a chain of dependent additions on lanes that have nothing else to do, so four lanes share each
     // addition (msm_quad.hpp: ~3x shorter chains).  Many buckets (the products of 2^20 points and more, batches): one lane per addition.
@@ -762,7 +774,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         {
             ProfScope ps(ctx, "msm_hist", 32.0 * n_used + 4.0 * chunks * bins, st);
             hipLaunchKernelGGL(k_msm_hist, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, src, n_used, chunk_len, c, windows, rank, world, sub_bits,
-                               groups, ws.hist.p);
+                               groups, blo, cb - 1, ws.hist.p);
         }
         {
             ProfScope ps(ctx, "msm_offsets", 12.0 * chunks * bins, st);
@@ -773,13 +785,13 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
         {
             ProfScope ps(ctx, "msm_scatter", 32.0 * n_used + 8.0 * entries + 4.0 * chunks * bins, st);
             hipLaunchKernelGGL(k_msm_scatter, dim3(chunks), dim3(SORT_THREADS), (size_t)bins * 4, st, src, n_used, n, chunk_len, c, windows, rank, world,
-                               sub_bits, groups, ws.hist.p, ws.records.p);
+                               sub_bits, groups, blo, cb - 1, ws.hist.p, ws.records.p);
         }
         {
             ProfScope ps(ctx, "msm_sort_bins", 20.0 * entries + 4.0 * buckets, st);
             // ~2048 level-2 workgroups in all, dealt to the bins in proportion to their records (at least BIN_STAGE records each)
             const int subs = 1 << sub_bits;
-            const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries + 2047) / 2048);
+            const uint32_t target = (uint32_t)std::max<size_t>(BIN_STAGE, (entries_est + 2047) / 2048);
             const unsigned grid2 = (unsigned)(entries / target + 1) + (unsigned)bins;   // >= sum_b max(1, ceil(len_b / target))
             ws.bin_cnt.ensure((size_t)grid2 * subs);
             ws.part_start.ensure((size_t)bins + 1);
@@ -861,7 +873,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             const int terms = K + rows, parts = (terms + QUAD_SUM_THREADS - 1) / QUAD_SUM_THREADS;
             auto end = [&](auto big) {
                 constexpr bool BIG = decltype(big)::value;
-                hipLaunchKernelGGL((k_msm_weigh_q<F, BIG>), dim3(ceil_div(terms, QUAD_JOBS), groups), dim3(QUAD_THREADS), 0, st, d_C, d_R, kbits, rows, d_term);
+                hipLaunchKernelGGL((k_msm_weigh_q<F, BIG>), dim3(ceil_div(terms, QUAD_JOBS), groups), dim3(QUAD_THREADS), 0, st, d_C, d_R, kbits, rows, blo, d_term);
                 if (parts > 1) {
                     hipLaunchKernelGGL((k_msm_sum_q<F, false, BIG>), dim3(parts, groups), dim3(QUAD_SUM_THREADS), 0, st, d_term, terms, d_qpart, d_out, grp.out_stride);
                     hipLaunchKernelGGL((k_msm_sum_q<F, true, BIG>), dim3(1, groups), dim3(QUAD_SUM_THREADS), 0, st, d_qpart, parts, d_qpart, d_out, grp.out_stride);
@@ -873,7 +885,7 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
             ZK_HIP(hipGetLastError());
             return st;
         }
-        hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(TAIL_THREADS), 0, st, d_C, d_R, kbits, rows, d_seg);
+        hipLaunchKernelGGL(k_msm_weigh<F>, dim3(wgs_w, groups), dim3(TAIL_THREADS), 0, st, d_C, d_R, kbits, rows, blo, d_seg);
         // K + rows terms per group: one workgroup while each lane has at most 4 of them, otherwise two levels
         Jac<F>* d_part = d_seg + (size_t)groups * (K + rows);
         const int terms = K + rows, wgs2 = (terms + 1023) / 1024;

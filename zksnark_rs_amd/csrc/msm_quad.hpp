@@ -64,13 +64,13 @@ __global__ __launch_bounds__(QUAD_THREADS, (QuadWavesOf<F, BIG>::value)) void k_
 // term[group][j] as in k_msm_weigh, kept as accumulator images
 template <class F, bool BIG>
 __global__ __launch_bounds__(QUAD_THREADS, (QuadWavesOf<F, BIG>::value)) void k_msm_weigh_q(const AccSlot<F>* __restrict__ C, const AccSlot<F>* __restrict__ R, int kbits, int rows,
-                                                     AccSlot<F>* __restrict__ term) {
+                                                     uint32_t wbase, AccSlot<F>* __restrict__ term) {
     ZK_LATENCY_KERNEL();
     const int K = 1 << kbits, g = blockIdx.y;
     const int j = blockIdx.x * QUAD_JOBS + (threadIdx.x >> 2), role = threadIdx.x & 3;
     if (j >= K + rows) return;
     const AccSlot<F>* src = j < K ? C + (size_t)g * K + j : R + (size_t)g * rows + (j - K);
-    const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u;
+    const uint32_t w = j < K ? (uint32_t)j : ((uint32_t)(j - K) << kbits) + 1u + wbase;   // wbase: first bucket of a bucket-range shard
     const typename AccOf<F>::type t = quad_mul_small_xyzz(src->a, w, role);
     if (role == 0) term[(size_t)g * (K + rows) + j].a = t;
 }

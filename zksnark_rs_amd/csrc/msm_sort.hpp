@@ -100,11 +100,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t* in, uin
 // Grouped form (several independent products over the same bases in one pass): scalar i belongs to group i / glen and
 // multiplies point i % glen (scalars at or behind gvalid are ignored); group g owns the bins [g bins_pg, (g+1) bins_pg).
 // Split form (MsmSplit): scalar i comes from scalars2[i - split] for i >= split.
+// Bucket range (partial sums by bucket range, MsmGroups::bucket_shard): only digits whose bucket lies in [blo, blo + 2^bucket_bits) are kept,
+// re-indexed from blo; a whole product has blo = 0 and bucket_bits = c - 1.
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(ScalarSrc src, size_t n, size_t chunk_len, int c, int windows,
-                                                           int first, int step, int sub_bits, int groups, uint32_t* __restrict__ hist) {
+                                                           int first, int step, int sub_bits, int groups, uint32_t blo, int bucket_bits, uint32_t* __restrict__ hist) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
+    const int bins_pg = 1 << (bucket_bits - sub_bits), bins = bins_pg * groups;
 #pragma unroll 1
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = 0;
     __syncthreads();
@@ -117,7 +119,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_hist(ScalarSrc src, size_t
         Fr k;
         if (!src.get(i, grp, il, k)) continue;
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
-        for_each_digit_auto(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) { lds_inc(lds, bin0 + ((mag - 1) >> sub_bits)); });
+        for_each_digit_auto(k, c, windows, first, step, [&](int, uint32_t mag, uint32_t) {
+            const uint32_t b = mag - 1 - blo;
+            if ((b >> bucket_bits) == 0) lds_inc(lds, bin0 + (b >> sub_bits));
+        });
     }
     __syncthreads();
     uint32_t* row = hist + (size_t)blockIdx.x * bins;
@@ -178,11 +183,11 @@ __global__ __launch_bounds__(1024) void k_msm_scan(const uint32_t* __restrict__ 
 // position taken from the bin's LDS counter.  (An LDS-staged form that writes the records in runs, like level 2 below,
 // was slower here: 0.85 vs 0.50 ms per proof; with only 2^8 bins the hot lines of a chunk stay in L2.)
 __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(ScalarSrc src, size_t n, size_t stride, size_t chunk_len, int c, int windows,
-                                                                     int first, int step, int sub_bits, int groups,
+                                                                     int first, int step, int sub_bits, int groups, uint32_t blo, int bucket_bits,
                                                                      const uint32_t* __restrict__ prefix, uint64_t* __restrict__ records) {
     ZK_LATENCY_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int bins_pg = 1 << (c - 1 - sub_bits), bins = bins_pg * groups;
+    const int bins_pg = 1 << (bucket_bits - sub_bits), bins = bins_pg * groups;
     const uint32_t sub_mask = (1u << sub_bits) - 1;
     const uint32_t* row = prefix + (size_t)blockIdx.x * bins;
     for (int b = threadIdx.x; b < bins; b += SORT_THREADS) lds[b] = row[b];
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_msm_scatter(ScalarSrc src, siz
         if (!src.get(i, grp, il, k)) continue;
         const uint32_t bin0 = grp * (uint32_t)bins_pg;
         for_each_digit_auto(k, c, windows, first, step, [&](int w, uint32_t mag, uint32_t neg) {
-            const uint32_t b = mag - 1;
+            const uint32_t b = mag - 1 - blo;
+            if (b >> bucket_bits) return;
             uint32_t pos = lds_inc(lds, bin0 + (b >> sub_bits));
             records[pos] = ((uint64_t)(b & sub_mask) << 32) | (((uint32_t)((size_t)w * stride + il) << 1) | neg);
         });
@@ -491,11 +497,11 @@ __global__ __launch_bounds__(256) void k_msm_runs_emit(const uint32_t* __restric
 }
 
 #else
-__global__ void k_msm_hist(ScalarSrc, size_t, size_t, int, int, int, int, int, int, uint32_t*);
+__global__ void k_msm_hist(ScalarSrc, size_t, size_t, int, int, int, int, int, int, uint32_t, int, uint32_t*);
 __global__ void k_msm_bin_totals(const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_chunk_prefix(uint32_t*, int, int, const uint32_t*);
 __global__ void k_msm_scan(const uint32_t*, uint32_t*, int);
-__global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, const uint32_t*, uint64_t*);
+__global__ void k_msm_scatter(ScalarSrc, size_t, size_t, size_t, int, int, int, int, int, int, uint32_t, int, const uint32_t*, uint64_t*);
 __global__ void k_msm_bin_parts(const uint32_t*, int, uint32_t, uint32_t*);
 __global__ void k_msm_bin_hist(const uint64_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);
 __global__ void k_msm_bin_offsets(uint32_t*, const uint32_t*, const uint32_t*, int, int, uint32_t*);

@@ -547,12 +547,13 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
         ZK_HIP(hipStreamWaitEvent(ms_st, S.scal_evt[k], 0));
         hipEvent_t wait_evt = after >= 0 ? S.acc_evt[after] : ps.last_acc;
         hipStream_t end_st;
-        if (world > 1 && ctx->opt_shard_points) {
+        if (world > 1 && ctx->opt_shard_points == 1) {
             // partial sums by point ranges: rank g takes the scalars / bases [count g / world, count (g+1) / world) with every window
             const size_t lo = count * (size_t)rank / (size_t)world, hi = count * ((size_t)rank + 1) / (size_t)world;
             end_st = msm_run(ctx, S.ws[k], ms_st, table, scalars + lo, hi - lo, 0, 1, out, wait_evt, S.acc_evt[k], off + lo);
         } else {
             MsmGroups ex;
+            ex.bucket_shard = world > 1 && ctx->opt_shard_points == 2;   // partial sums by bucket range (1 / world of the entries AND of the buckets)
             // measurement switch tail_stream: the merged product's reduction tail on the idle L stream, so that the next proof's sort of
             // the same product starts when this accumulation ends instead of ~1 ms later (r5_experiments.txt item 11)
             if (k == 4 && sp.scalars2 && ctx->opt_tail_stream && !ctx->opt_serialize) ex.tail_stream = ctx->msm_stream[1];
@@ -565,7 +566,7 @@ int prove_submit(zk_ctx* ctx, const zk_crs& crs_c, const zk_qap& qap_c, const Fr
     // xi_t | xi | sum_delta with the scalars h | r v + s u (the slot's array) and the witness (the caller's): one set of 2^(c-1)
     // buckets instead of two, i.e. one reduction tail (2 additions per bucket), one sort, ~25 launches less per proof (option merge_lh;
     // round 5: profiles/r5_experiments.txt).  ms->l stays infinity.  Not with partial sums by point ranges (they slice ONE scalar array).
-    const bool merge_lh = ctx->opt_merge_lh && !xout && !(world > 1 && ctx->opt_shard_points);
+    const bool merge_lh = ctx->opt_merge_lh && !xout && !(world > 1 && ctx->opt_shard_points == 1);
     const Fr* l_scalars = nullptr;
     size_t l_count = 0;
     bool l_pending = false;
