@@ -45,7 +45,7 @@ python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.jso
 python tools/pmc_summary.py $OUT/pmc_fetch16 $OUT/pmc_write16 > $OUT/pmc_traffic_2p16.json
 python tools/pmc_acc_summary.py $OUT/pmc_acc 20 > $OUT/pmc_acc.json
 python tools/pmc_acc_summary.py $OUT/pmc_acc16 16 > $OUT/pmc_acc_2p16.json
-python tools/valu_budget.py $OUT/pmc_acc "round-5 build, 2^20 gates" > $OUT/valu_budget.txt
+python tools/valu_budget.py $OUT/pmc_acc "round-6 build, 2^20 gates" > $OUT/valu_budget.txt
 python tools/pmc_counters.py $OUT/pmc_acc k_msm k_ntt > $OUT/pmc_counters.txt
 find $OUT/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/prof_stats_ser -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_serialized.csv \;
@@ -58,6 +58,8 @@ python tools/trace_kernels.py "$(find $OUT/prof_stats_ser -name '*kernel_trace.c
   [ -x tools/_bin/ubench_assemble ] && timeout 60 tools/_bin/ubench_assemble
   python tools/time_root_tables.py 16 18 20 22
   python tools/time_change_of_basis.py 12 14 16
+  python tools/time_first_proof.py 20 16 22 | grep -v amdgpu.ids
+  python tools/host_pacing.py --log-n 16 --depth 4 --proofs 24 | grep -v amdgpu.ids | head -3
 } > $OUT/lone.txt 2>/dev/null
 # one GPU doing rank 0's share of every N > 1 leg on the round's build: the scalar exchange (copies in place of the all-to-alls),
 # the window shard (windows w = 0 mod N of every product) and the point-range shard
@@ -65,6 +67,7 @@ python tools/trace_kernels.py "$(find $OUT/prof_stats_ser -name '*kernel_trace.c
   for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --steps 20 --warmup 4 2>/dev/null | tail -1; done
   for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --mode shard --shard windows --steps 20 --warmup 4 2>/dev/null | tail -1; done
   for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --mode shard --shard points --steps 20 --warmup 4 2>/dev/null | tail -1; done
+  for w in 2 4 8; do ZKGPU_LIB=$M python bench.py --emulate-world $w --mode shard --shard buckets --steps 20 --warmup 4 2>/dev/null | tail -1; done
   python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(json.dumps({'diagnostic': 'one whole prover on the same box (replicas = N times this)', 'proofs_per_s': d['value'], 'steady_state_ms_per_proof': d.get('steady_state_ms_per_proof')}))"
 } > $OUT/emul.txt
 # same-round inputs of the bench line: the sustained issue rates (tools/ubench_valu.hip) and BASELINE config 4's window sweep, both regimes

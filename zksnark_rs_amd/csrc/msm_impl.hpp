@@ -82,16 +82,46 @@ constexpr int RUN_MAX = 256;         // longest run of the accumulation (length 
 struct MsmRun { uint32_t k0, len, dest, end; };
 
 // ---- table precompute: T[w][i] = 2^(c w) P_i ------------------------------------------------
+// One lane per point: c doublings per window in Jacobian coordinates, then ONE inversion for all of the point's windows (Montgomery's
+// trick along the lane's own chain: the Z of every window and the running products go through two scratch arrays, windows x points,
+// coalesced over the lanes).  Round 5 inverted per window -- 12 Fermat inversions per point were three quarters of the kernel, and the
+// tables are the 0.34 s of the 0.43 s a first proof over a new CRS took.  Points [first, first + count) per launch.
 template <class F>
-__global__ __launch_bounds__(64) void k_msm_precompute(const Aff<F>* __restrict__ pts, size_t n, int c, int windows, Aff<F>* __restrict__ table) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Aff<F> p = pts[i];
+__global__ __launch_bounds__(64) void k_msm_precompute(const Aff<F>* __restrict__ pts, size_t n, size_t first, size_t count, int c, int windows,
+                                                       Aff<F>* __restrict__ table, F* __restrict__ zbuf, F* __restrict__ pbuf) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t i = first + t;
+    const Aff<F> p = pts[i];
     table[i] = p;
-    Jac<F> j = Jac<F>::from_affine(p);
+    if (p.is_inf()) {
+        for (int w = 1; w < windows; ++w) table[(size_t)w * n + i] = Aff<F>::infinity();
+        return;
+    }
+    // the doublings run in the lazy radix (lazy29.cuh dbl_lazy: no conversion to and from 8 x 32 per multiplication); a window's point
+    // leaves it once, fully reduced, for the shared inversion
+    JacR<F> jr = jacr_load(Jac<F>::from_affine(p));
+    F run = F::one();
     for (int w = 1; w < windows; ++w) {
-        for (int k = 0; k < c; ++k) j = jac_dbl_ni(j);
-        table[(size_t)w * n + i] = jac_to_affine(j);
+        for (int k = 0; k < c; ++k) jr = dbl_lazy(jr);
+        const Jac<F> j = jacr_store(jr);
+        // (a doubling chain over a point of odd order never meets infinity; a caller's arbitrary point may: kept out of the product)
+        const bool inf = j.is_inf();
+        table[(size_t)w * n + i] = inf ? Aff<F>::infinity() : Aff<F>{j.X, j.Y};   // Jacobian X, Y until the second loop
+        const F z = inf ? F::one() : j.Z;
+        zbuf[(size_t)(w - 1) * count + t] = z;
+        pbuf[(size_t)(w - 1) * count + t] = run;                                  // z_1 ... z_(w-1)
+        run = run * z;
+    }
+    F inv = run.inv();                                                            // 1 / (z_1 ... z_(W-1))
+    for (int w = windows - 1; w >= 1; --w) {
+        const F zi = inv * pbuf[(size_t)(w - 1) * count + t];                     // 1 / z_w
+        inv = inv * zbuf[(size_t)(w - 1) * count + t];
+        const Aff<F> q = table[(size_t)w * n + i];
+        if (!q.is_inf()) {
+            const F zi2 = zi.sqr();
+            table[(size_t)w * n + i] = Aff<F>{q.x * zi2, q.y * zi2 * zi};
+        }
     }
 }
 
@@ -105,8 +135,15 @@ void msm_build_table(zk_ctx* ctx, const Aff<F>* d_points, size_t n, int c, MsmTa
     t.table.alloc(std::max<size_t>((size_t)t.windows * n, 1));
     if (!n) return;
     ProfScope ps(ctx, sizeof(F) > sizeof(Fq) ? "msm_precompute_g2" : "msm_precompute_g1", (double)sizeof(Aff<F>) * n * (t.windows + 1));
-    hipLaunchKernelGGL(k_msm_precompute<F>, dim3(ceil_div(n, 64)), dim3(64), 0, ctx->stream, d_points, n, c, t.windows, t.table.p);
+    // scratch of the shared inversion: 2 x (windows - 1) field elements per point of a launch, at most ~0.8 GiB (2^20 points in G1)
+    const size_t chunk = std::min<size_t>(n, ((size_t)1 << 25) / sizeof(F));
+    DevBuf<F> zbuf(std::max<size_t>((size_t)(t.windows - 1) * chunk, 1)), pbuf(std::max<size_t>((size_t)(t.windows - 1) * chunk, 1));
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t count = std::min(chunk, n - first);
+        hipLaunchKernelGGL(k_msm_precompute<F>, dim3(ceil_div(count, 64)), dim3(64), 0, ctx->stream, d_points, n, first, count, c, t.windows, t.table.p, zbuf.p, pbuf.p);
+    }
     ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(ctx->stream));   // the scratch arrays go out of scope here (one-off set-up path)
 }
 template void msm_build_table<ZK_MSM_FIELD>(zk_ctx*, const Aff<ZK_MSM_FIELD>*, size_t, int, MsmTable<ZK_MSM_FIELD>&);
 
