@@ -741,7 +741,10 @@ hipStream_t msm_run(zk_ctx* ctx, MsmWorkspace& ws, hipStream_t st, const MsmTabl
     // (one run of at most 128 entries up to 64 entries per bucket on average -- the separate products of 2^20 .. 2^21 points --, of at
     // most RUN_MAX = 256 beyond: the merged L + H product of a proof holds 104 per bucket, and 128 would cut one bucket in a hundred)
     const size_t entries_est = entries >> shard_log;   // what the run-length rules are tuned on
-    const bool whole = entries_est / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill;
+    // (a bucket-range shard holds as many entries per bucket as the whole product in 1 / N of the buckets: one run per bucket would leave
+    // the chip 1 / N of its lanes, so its buckets are cut into runs like a small product's -- ms per proof and rank at N = 2 / 4 / 8:
+    // 5.77 / 4.06 / 3.20 -> 5.51 / 3.65 / 2.75, profiles/r6_experiments.txt item 6)
+    const bool whole = entries_est / (size_t)buckets <= (size_t)std::max<long>(ctx->opt_run_whole, 0) && (size_t)buckets >= fill && !bshard;
     if (whole) T = entries_est / (size_t)buckets <= 64 ? 128 : RUN_MAX;
     else if (ctx->opt_run_fill && entries_est / T > (size_t)(g2 ? 2 : 3) * 256 * (size_t)ctx->cu_count) {
         // More runs than the chip holds lanes (3 waves per SIMD in G1, 2 in G2): every run beyond a bucket's first costs a full
