@@ -306,6 +306,48 @@ def test_msm_fold_equal_and_opposite_images(ctx, orc, c, pattern):
         ctx.set_option("msm_quad_buckets", 65536)
 
 
+@pytest.mark.parametrize("c", [10, 13])
+def test_msm_accumulation_meets_its_own_sum(ctx, orc, c):
+    """The G1 accumulation's fast loop (csrc/madd_asm.inc: the whole mixed addition as one asm body, in place) overwrites the accumulator
+    before it knows that the point has the accumulator's x; such a lane rebuilds 2 P or infinity from the affine point alone, leaves the
+    loop in the canonical state and finishes its run in the generic loop.  Random data never goes there.  Here every bucket is ONE run of
+    four entries whose sum pattern forces it, whatever order the sort leaves them in:
+      {A, B, D, -(A+B+D)}   any three sum to minus the fourth: P + (-P) at position 4 (the odd body), always
+      {A, B, D,   A+B+D }   the same point at position 4 when the sum comes last (a quarter of the buckets): doubling
+      {A, B, -(A+B), D}     P + (-P) at position 3 (the even body) when D comes last; then D starts the accumulator again
+      {A, B,   A+B,  D}     doubling at position 3 in a twelfth of the buckets
+      {A, inf, B, D}        a table entry at infinity inside the run (the lane leaves the fast loop without consuming it)
+    Scalars are single digits of window 0, so bucket d holds exactly the points given scalar d (and G2 takes the same route through its
+    own loop).  Against the oracle's folded double-and-add."""
+    rng = SplitMix64(6100 + c)
+    nb = 320                                               # buckets used: digits 1 .. nb (<= 2^(c-1))
+    A, B, D = g1_points(orc, rng, nb), g1_points(orc, rng, nb), g1_points(orc, rng, nb)
+    A2, B2, D2 = g2_points(orc, rng, nb), g2_points(orc, rng, nb), g2_points(orc, rng, nb)
+    minus1 = np.tile(ints_to_limbs([R_MODULUS - 1]), (nb, 1))
+    AB, AB2 = orc.g1_add_batch(A, B), orc.g2_add_batch(A2, B2)
+    ABD, ABD2 = orc.g1_add_batch(AB, D), orc.g2_add_batch(AB2, D2)
+    neg = lambda p: orc.g1_mul_batch(p, minus1)             # noqa: E731
+    neg2 = lambda p: orc.g2_mul_batch(p, minus1)            # noqa: E731
+    pts, pts2, sc = [], [], []
+    for d in range(nb):
+        kind = d % 5
+        quad = {0: (A[d], B[d], D[d], neg(ABD[d:d + 1])[0]), 1: (A[d], B[d], D[d], ABD[d]), 2: (A[d], B[d], neg(AB[d:d + 1])[0], D[d]),
+                3: (A[d], B[d], AB[d], D[d]), 4: (A[d], np.zeros(8, np.uint64), B[d], D[d])}[kind]
+        quad2 = {0: (A2[d], B2[d], D2[d], neg2(ABD2[d:d + 1])[0]), 1: (A2[d], B2[d], D2[d], ABD2[d]), 2: (A2[d], B2[d], neg2(AB2[d:d + 1])[0], D2[d]),
+                 3: (A2[d], B2[d], AB2[d], D2[d]), 4: (A2[d], np.zeros(16, np.uint64), B2[d], D2[d])}[kind]
+        for q, q2 in zip(quad, quad2):
+            pts.append(q); pts2.append(q2); sc.append(d + 1)
+    order = np.random.default_rng(c).permutation(len(sc))    # the entries of a bucket come from all over the scalar array
+    p1 = np.ascontiguousarray(np.array(pts, dtype=np.uint64)[order])
+    p2 = np.ascontiguousarray(np.array(pts2, dtype=np.uint64)[order])
+    k = ints_to_limbs([sc[i] for i in order])
+    assert np.array_equal(ctx.msm_g1(p1, k, c), orc.msm_g1(p1, k, 0))
+    assert np.array_equal(ctx.msm_g2(p2, k, c), orc.msm_g2(p2, k, 0))
+    # and with the signs of all scalars flipped (negative digits: the gathered y is negated before it meets the accumulator)
+    kn = ints_to_limbs([R_MODULUS - sc[i] for i in order])
+    assert np.array_equal(ctx.msm_g1(p1, kn, c), orc.msm_g1(p1, kn, 0))
+
+
 def test_msm_linearity_large(ctx, orc):
     """Size-independent property at 2^18 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b)."""
     rng = SplitMix64(78)
