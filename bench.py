@@ -10,7 +10,9 @@ default) a step is one ROUND of N proofs: rank j runs the SpMV / NTT stage of pr
 rank the scalars that multiply its own point range of the four inner products, the rank accumulates them for all N
 proofs in grouped MSMs, a second all-to-all returns the 768-byte partial sums to the owners (scaling "weak": per-GPU
 work per step does not depend on N).  --mode shard is the latency form (one proof at a time, every rank repeats
-the NTT stage, one all-gather; scaling "strong"); --mode replicas runs one independent prover per GPU.
+the NTT stage, one all-gather; scaling "strong"; --shard windows | buckets | points says what a rank owns of every inner product);
+--mode replicas runs one independent prover per GPU.  Whatever the primary mode, the N > 1 line also carries the other legs -- and
+`config5` (BASELINE config 5: one proof at a time over N GPUs, the faster of the window shard and its balanced bucket-range form).
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel, HIP-event
 timed inside the library over the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle's
